@@ -1,0 +1,94 @@
+/*
+ * sigsvgd_hip.h -- C ABI of libsigsvgd_hip.so: the MI355X (gfx950) implementation of the
+ * signature-kernel SVGD hot path of lubaroli/sigsvgd.
+ *
+ * What each entry point replaces in the reference (Python; there is no native code there):
+ *
+ *   sigsvgd_gram_fwd       sigkernel.SigKernel.compute_Gram(X, Y) forward
+ *                          call sites: src/kernels/_traj_kernels.py:203-206,
+ *                                      src/inference/trajectory_svgd.py:60-63
+ *                          static kernel fused in: src/kernels/_traj_kernels.py:176-195
+ *   sigsvgd_gram_fwd_bwd   the same forward + its autograd backward for grad_output
+ *                          (d sum(grad_out*K) / dX, first argument only), triggered by
+ *                          src/inference/score.py:68-69, src/inference/trajectory_svgd.py:65
+ *   sigsvgd_svgd_phi       SVGD._velocity dense part: v = -((K @ score - grad_k)/N) [* mask]
+ *                          src/inference/svgd.py:82-83, src/inference/trajectory_svgd.py:84
+ *                          optionally fused with the optimizer=None update X - lr*v (svgd.py:115)
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers (HIP), row-major contiguous; the caller owns every buffer
+ *     and keeps it alive until the work queued on `stream` has completed;
+ *   - inputs are read-only; outputs are fully overwritten; nothing persistent is allocated;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls only enqueue work
+ *     (no host synchronisation, graph-capturable);
+ *   - return value 0 = ok, negative = error (see SIGSVGD_E_*); sigsvgd_last_error() gives text;
+ *   - `dtype` selects the I/O element type of X, Y, grad_out, K_out, gradX_out:
+ *     SIGSVGD_F32 or SIGSVGD_F64.  Arithmetic is always: fp64 static kernel + increments + PDE
+ *     sweeps, fp32 storage of per-pair intermediates, fp32 gradient contraction, fp64 reduction
+ *     over pairs (DESIGN.md "precision plan").
+ */
+#ifndef SIGSVGD_HIP_H
+#define SIGSVGD_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SIGSVGD_ABI_VERSION 1
+
+/* dtype */
+#define SIGSVGD_F32 0
+#define SIGSVGD_F64 1
+
+/* static kernel kinds */
+#define SIGSVGD_STATIC_RBF 0    /* k(x,y) = exp(-|x-y|^2 * inv_h)   (reference: exp(-dist/h)) */
+#define SIGSVGD_STATIC_LINEAR 1 /* k(x,y) = <x,y>                                              */
+
+/* flags */
+#define SIGSVGD_FLAG_NAIVE_SOLVER 1u /* first-order stencil (sigkernel _naive_solver=True)      */
+#define SIGSVGD_FLAG_SYM 2u          /* sigkernel sym=True backward weighting: go + go^T (A==B) */
+#define SIGSVGD_FLAG_Y_IS_X 4u       /* caller guarantees Y aliases X (same values): lets the   */
+                                     /* library solve each unordered pair once                  */
+#define SIGSVGD_FLAG_FORCE_GENERIC 8u /* testing: bypass the register-resident fast kernels     */
+
+/* errors */
+#define SIGSVGD_OK 0
+#define SIGSVGD_E_BADARG -1
+#define SIGSVGD_E_UNSUPPORTED -2 /* shape does not fit the device limits (LDS) */
+#define SIGSVGD_E_WORKSPACE -3   /* workspace too small */
+#define SIGSVGD_E_HIP -4         /* a HIP runtime call failed */
+
+int sigsvgd_abi_version(void);
+const char *sigsvgd_last_error(void);
+
+/* Bytes of scratch the two Gram entry points need for this problem (0 is possible).
+ * want_grad = 0 for sigsvgd_gram_fwd, 1 for sigsvgd_gram_fwd_bwd.  Returns 0 and sets *bytes. */
+int sigsvgd_gram_workspace_bytes(int A, int B, int T, int d, int dyadic_order, int want_grad,
+                                 unsigned flags, size_t *bytes);
+
+/* K_out[A,B] = signature-kernel Gram matrix of paths X[A,T,d], Y[B,T,d]. */
+int sigsvgd_gram_fwd(const void *X, const void *Y, int A, int B, int T, int d, int dtype,
+                     double inv_h, int dyadic_order, int static_kind, unsigned flags,
+                     void *K_out, void *workspace, size_t workspace_bytes, void *stream);
+
+/* As above, plus gradX_out[A,T,d] = d( sum_ij grad_out[i,j] K[i,j] ) / dX  (first slot only;
+ * Y receives no gradient, as in the reference).  grad_out == NULL means all ones (the only case
+ * the reference produces: callers differentiate K.sum()). */
+int sigsvgd_gram_fwd_bwd(const void *X, const void *Y, int A, int B, int T, int d, int dtype,
+                         double inv_h, int dyadic_order, int static_kind, unsigned flags,
+                         const void *grad_out, void *K_out, void *gradX_out, void *workspace,
+                         size_t workspace_bytes, void *stream);
+
+/* v_out[N,D] = -((K[N,N] @ score[N,D] - grad_k[N,D]) / N) * (mask ? mask[N,D] : 1)   (fp32)
+ * If X_in and X_out are non-NULL additionally X_out = X_in - lr * v_out (optimizer=None update).
+ * The N x N x D product runs on the fp32 MFMA (exact fp32 FMA chain). */
+int sigsvgd_svgd_phi(const float *K, const float *score, const float *grad_k, const float *mask,
+                     int N, int D, float *v_out, const float *X_in, float *X_out, float lr,
+                     void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIGSVGD_HIP_H */

@@ -1,0 +1,100 @@
+"""ctypes binding of libsigsvgd_hip.so (C ABI in include/sigsvgd_hip.h) + in-tree build helper.
+
+There is deliberately NO fallback: if the shared library is missing or fails to load, every hot-path
+op raises.  `build()` cross-compiles for gfx950 with hipcc (works without a GPU).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import shutil
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_PKG, "csrc")
+LIB_PATH = os.path.join(_PKG, "libsigsvgd_hip.so")
+SOURCES = ["capi.hip", "gram_generic.hip", "gram_fast.hip", "svgd_phi.hip"]
+HEADERS = [os.path.join(_CSRC, "sig_common.h"), os.path.join(_PKG, "..", "include", "sigsvgd_hip.h")]
+
+# mirror of include/sigsvgd_hip.h
+F32, F64 = 0, 1
+STATIC_RBF, STATIC_LINEAR = 0, 1
+FLAG_NAIVE_SOLVER, FLAG_SYM, FLAG_Y_IS_X, FLAG_FORCE_GENERIC = 1, 2, 4, 8
+ABI_VERSION = 1
+
+EXPORTS = [
+    "sigsvgd_abi_version",
+    "sigsvgd_last_error",
+    "sigsvgd_gram_workspace_bytes",
+    "sigsvgd_gram_fwd",
+    "sigsvgd_gram_fwd_bwd",
+    "sigsvgd_svgd_phi",
+]
+
+_lib = None
+
+
+def _hipcc() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (need ROCm's hipcc to build libsigsvgd_hip.so)")
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(_CSRC, s) for s in SOURCES] + HEADERS
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 -shared -> sigsvgd_amd/libsigsvgd_hip.so (in-tree)."""
+    if not force and not needs_build():
+        return LIB_PATH
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB_PATH]
+    cmd += [os.path.join(_CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+def load():
+    """Load the library and declare signatures.  Raises RuntimeError if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"sigsvgd_amd: HIP extension {LIB_PATH} is not built; run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). There is no CPU fallback."
+        )
+    L = ctypes.CDLL(LIB_PATH)
+    vp, ci, cd, cu, cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_uint, ctypes.c_float
+    L.sigsvgd_abi_version.restype = ci
+    L.sigsvgd_abi_version.argtypes = []
+    L.sigsvgd_last_error.restype = ctypes.c_char_p
+    L.sigsvgd_last_error.argtypes = []
+    L.sigsvgd_gram_workspace_bytes.restype = ci
+    L.sigsvgd_gram_workspace_bytes.argtypes = [ci, ci, ci, ci, ci, ci, cu, ctypes.POINTER(ctypes.c_size_t)]
+    L.sigsvgd_gram_fwd.restype = ci
+    L.sigsvgd_gram_fwd.argtypes = [vp, vp, ci, ci, ci, ci, ci, cd, ci, ci, cu, vp, vp, ctypes.c_size_t, vp]
+    L.sigsvgd_gram_fwd_bwd.restype = ci
+    L.sigsvgd_gram_fwd_bwd.argtypes = [vp, vp, ci, ci, ci, ci, ci, cd, ci, ci, cu, vp, vp, vp, vp, ctypes.c_size_t, vp]
+    L.sigsvgd_svgd_phi.restype = ci
+    L.sigsvgd_svgd_phi.argtypes = [vp, vp, vp, vp, ci, ci, vp, vp, vp, cf, vp]
+    if L.sigsvgd_abi_version() != ABI_VERSION:
+        raise RuntimeError("sigsvgd_amd: libsigsvgd_hip.so ABI version mismatch; rebuild it")
+    _lib = L
+    return L
+
+
+def last_error() -> str:
+    return load().sigsvgd_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise RuntimeError(f"sigsvgd_amd: {what} failed (rc={rc}): {last_error()}")

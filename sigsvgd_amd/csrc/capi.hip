@@ -1,0 +1,126 @@
+// extern "C" entry points of libsigsvgd_hip.so (declared in include/sigsvgd_hip.h).
+#include <cstdarg>
+#include <cstdio>
+
+#include "sig_common.h"
+
+namespace sigsvgd {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int hip_fail(hipError_t e, const char *what)
+{
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return SIGSVGD_E_HIP;
+}
+
+int phi_launch(const float *K, const float *score, const float *grad_k, const float *mask, int N, int D,
+               float *v_out, const float *X_in, float *X_out, float lr, hipStream_t stream);
+
+static int check_common(const void *X, const void *Y, int A, int B, int T, int d, int dtype, double inv_h,
+                        int n, int kind, const void *K_out)
+{
+    if (!X || !Y || !K_out) {
+        set_error("null pointer argument");
+        return SIGSVGD_E_BADARG;
+    }
+    if (A < 1 || B < 1 || T < 2 || d < 1) {
+        set_error("bad shape A=%d B=%d T=%d d=%d (need A,B,d >= 1 and T >= 2)", A, B, T, d);
+        return SIGSVGD_E_BADARG;
+    }
+    if (dtype != SIGSVGD_F32 && dtype != SIGSVGD_F64) {
+        set_error("bad dtype %d", dtype);
+        return SIGSVGD_E_BADARG;
+    }
+    if (kind != SIGSVGD_STATIC_RBF && kind != SIGSVGD_STATIC_LINEAR) {
+        set_error("bad static kernel kind %d", kind);
+        return SIGSVGD_E_BADARG;
+    }
+    if (n < 0 || n > 10) {
+        set_error("bad dyadic order %d", n);
+        return SIGSVGD_E_BADARG;
+    }
+    if (kind == SIGSVGD_STATIC_RBF && !(inv_h > 0.0)) {
+        set_error("RBF static kernel needs inv_h > 0 (got %g)", inv_h);
+        return SIGSVGD_E_BADARG;
+    }
+    return SIGSVGD_OK;
+}
+
+static int dispatch(const GramProblem &p)
+{
+    const int want_grad = p.gradX_out != nullptr;
+    (void)want_grad;
+    if (!(p.flags & SIGSVGD_FLAG_FORCE_GENERIC) && fast_supported(p.A, p.B, p.T, p.d, p.n, p.kind, p.flags))
+        return fast_launch(p);
+    return generic_launch(p);
+}
+
+} // namespace sigsvgd
+
+using namespace sigsvgd;
+
+extern "C" {
+
+int sigsvgd_abi_version(void) { return SIGSVGD_ABI_VERSION; }
+
+const char *sigsvgd_last_error(void) { return g_err; }
+
+int sigsvgd_gram_workspace_bytes(int A, int B, int T, int d, int dyadic_order, int want_grad, unsigned flags,
+                                 size_t *bytes)
+{
+    if (!bytes) {
+        set_error("bytes == NULL");
+        return SIGSVGD_E_BADARG;
+    }
+    // size for whichever kernel dispatch() would pick; the static kind does not change the size
+    if (!(flags & SIGSVGD_FLAG_FORCE_GENERIC) && fast_supported(A, B, T, d, dyadic_order, SIGSVGD_STATIC_RBF, flags))
+        return fast_workspace_bytes(A, B, T, d, want_grad, flags, bytes);
+    return generic_workspace_bytes(A, B, T, d, dyadic_order, want_grad, bytes);
+}
+
+int sigsvgd_gram_fwd(const void *X, const void *Y, int A, int B, int T, int d, int dtype, double inv_h,
+                     int dyadic_order, int static_kind, unsigned flags, void *K_out, void *workspace,
+                     size_t workspace_bytes, void *stream)
+{
+    int rc = check_common(X, Y, A, B, T, d, dtype, inv_h, dyadic_order, static_kind, K_out);
+    if (rc) return rc;
+    GramProblem p{X, Y, A, B, T, d, dtype, inv_h, dyadic_order, static_kind, flags, nullptr,
+                  K_out, nullptr, workspace, workspace_bytes, static_cast<hipStream_t>(stream)};
+    return dispatch(p);
+}
+
+int sigsvgd_gram_fwd_bwd(const void *X, const void *Y, int A, int B, int T, int d, int dtype, double inv_h,
+                         int dyadic_order, int static_kind, unsigned flags, const void *grad_out, void *K_out,
+                         void *gradX_out, void *workspace, size_t workspace_bytes, void *stream)
+{
+    int rc = check_common(X, Y, A, B, T, d, dtype, inv_h, dyadic_order, static_kind, K_out);
+    if (rc) return rc;
+    if (!gradX_out) {
+        set_error("gradX_out == NULL (use sigsvgd_gram_fwd for forward only)");
+        return SIGSVGD_E_BADARG;
+    }
+    if ((flags & SIGSVGD_FLAG_Y_IS_X) && A != B) {
+        set_error("Y_IS_X needs A == B");
+        return SIGSVGD_E_BADARG;
+    }
+    GramProblem p{X, Y, A, B, T, d, dtype, inv_h, dyadic_order, static_kind, flags, grad_out,
+                  K_out, gradX_out, workspace, workspace_bytes, static_cast<hipStream_t>(stream)};
+    return dispatch(p);
+}
+
+int sigsvgd_svgd_phi(const float *K, const float *score, const float *grad_k, const float *mask, int N, int D,
+                     float *v_out, const float *X_in, float *X_out, float lr, void *stream)
+{
+    return phi_launch(K, score, grad_k, mask, N, D, v_out, X_in, X_out, lr, static_cast<hipStream_t>(stream));
+}
+
+} // extern "C"

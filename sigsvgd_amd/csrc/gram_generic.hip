@@ -1,0 +1,360 @@
+// Generic signature-kernel Gram forward/backward kernel: any path length T, dyadic order n and
+// channel count d whose per-pair state fits the CU's 160 KB LDS.  One wavefront per (i, j-chunk)
+// work item; the refined P x P PDE grid is swept in bands of 64 rows, one grid row per lane,
+// anti-diagonal by anti-diagonal (lane l is at column s-l on step s).  Neighbour values move
+// between lanes with wave shifts; the band boundary row lives in LDS.  For the backward pass the
+// forward solution is parked in a per-workgroup HBM scratch in [step][lane] order (coalesced
+// 256-B rows, written and re-read by the same wavefront, so it stays in L2).
+//
+// This is the coverage kernel (reference call sites use T=3..30 with n=2..6); the
+// headline shapes (n=0, T<=64) take the register-resident kernel in gram_fast.hip.
+//
+// Reference semantics: sigkernel _SigKernelGram.forward/backward [RECALLED, SURVEY.md App. A];
+// static kernel src/kernels/_traj_kernels.py:176-195.
+#include "sig_common.h"
+
+namespace sigsvgd {
+
+struct GenericArgs {
+    const void *X, *Y, *grad_out;
+    void *K_out;
+    double *partials; // [A][nchunks][T*d]
+    float *wsk;       // [grid][nbands*nsteps*64]
+    int A, B, T, d, dp, n, r, P, Tm, TmS, nbands, nsteps, JC, nchunks, kind, naive, sym, want_grad;
+    double inv_h, inv_r2;
+    long long total_items;
+    size_t wsk_per_block;
+};
+
+__host__ __device__ inline size_t generic_lds_bytes(int T, int d, int n, int want_grad)
+{
+    const int dp = (d % 2 == 0) ? d + 1 : d;
+    const int Tm = T - 1, TmS = Tm | 1, P = (1 << n) * Tm;
+    size_t dbl = (size_t)2 * T * dp + 2 * T + (P + 2);
+    if (want_grad) dbl += (size_t)Tm * Tm + (size_t)T * dp;
+    return dbl * sizeof(double) + (size_t)Tm * TmS * sizeof(float);
+}
+
+template <typename IO>
+__global__ __launch_bounds__(64) void gram_generic_kernel(GenericArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int lane = threadIdx.x;
+    const int T = a.T, d = a.d, dp = a.dp, Tm = a.Tm, TmS = a.TmS, P = a.P, n = a.n, r = a.r;
+    const bool naive = a.naive != 0;
+    const bool rbf = a.kind == SIGSVGD_STATIC_RBF;
+
+    double *xs = reinterpret_cast<double *>(smem_raw);
+    double *ys = xs + (size_t)T * dp;
+    double *xn = ys + (size_t)T * dp;
+    double *yn = xn + T;
+    double *rowbuf = yn + T;
+    double *Sm = rowbuf + (P + 2);
+    double *acc = Sm + (a.want_grad ? (size_t)Tm * Tm : 0);
+    float *Dm = reinterpret_cast<float *>(acc + (a.want_grad ? (size_t)T * dp : 0));
+
+    const IO *X = static_cast<const IO *>(a.X);
+    const IO *Y = static_cast<const IO *>(a.Y);
+    const IO *GO = static_cast<const IO *>(a.grad_out);
+    IO *Kout = static_cast<IO *>(a.K_out);
+    float *wsk = a.wsk + (size_t)blockIdx.x * a.wsk_per_block;
+
+    for (long long item = blockIdx.x; item < a.total_items; item += gridDim.x) {
+        const int i = (int)(item / a.nchunks);
+        const int chunk = (int)(item % a.nchunks);
+        const int j0 = chunk * a.JC;
+        const int j1 = min(a.B, j0 + a.JC);
+        const IO *xi = X + (size_t)i * T * d;
+
+        // ---- stage x_i (centred on its first point for the translation-invariant RBF) ----------
+        __syncthreads();
+        for (int e = lane; e < T * dp; e += kWave) {
+            const int t = e / dp, c = e % dp;
+            double v = 0.0;
+            if (c < d) v = (double)xi[t * d + c] - (rbf ? (double)xi[c] : 0.0);
+            xs[e] = v;
+            if (a.want_grad) acc[e] = 0.0;
+        }
+        __syncthreads();
+        for (int t = lane; t < T; t += kWave) {
+            double s = 0.0;
+            for (int c = 0; c < d; ++c) s = __builtin_fma(xs[t * dp + c], xs[t * dp + c], s);
+            xn[t] = s;
+        }
+
+        for (int j = j0; j < j1; ++j) {
+            const IO *yj = Y + (size_t)j * T * d;
+            __syncthreads();
+            for (int e = lane; e < T * dp; e += kWave) {
+                const int t = e / dp, c = e % dp;
+                double v = 0.0;
+                if (c < d) v = (double)yj[t * d + c] - (rbf ? (double)xi[c] : 0.0);
+                ys[e] = v;
+            }
+            if (a.want_grad)
+                for (int e = lane; e < Tm * Tm; e += kWave) Sm[e] = 0.0;
+            __syncthreads();
+            for (int t = lane; t < T; t += kWave) {
+                double s = 0.0;
+                for (int c = 0; c < d; ++c) s = __builtin_fma(ys[t * dp + c], ys[t * dp + c], s);
+                yn[t] = s;
+            }
+            __syncthreads();
+
+            // ---- phase 1: static kernel rows -> increments D (fp64 arithmetic, fp32 storage) --
+            for (int rb = 0; rb < Tm; rb += kWave - 1) {
+                const int p = rb + lane;
+                const bool valid = p < T;
+                double g_prev = 0.0;
+                for (int q = 0; q < T; ++q) {
+                    double gq = 0.0;
+                    if (valid) {
+                        double dot = 0.0;
+                        for (int c = 0; c < d; ++c) dot = __builtin_fma(xs[p * dp + c], ys[q * dp + c], dot);
+                        gq = rbf ? exp64((2.0 * dot - xn[p] - yn[q]) * a.inv_h) : dot;
+                    }
+                    const double rd = gq - g_prev;
+                    g_prev = gq;
+                    const double rdn = shfl_down_f64(rd);
+                    if (q >= 1 && lane < kWave - 1 && p + 1 < T) Dm[p * TmS + (q - 1)] = (float)(rdn - rd);
+                }
+            }
+            __syncthreads();
+
+            // ---- phase 2: forward Goursat sweep ------------------------------------------------
+            double Kval = 1.0;
+            for (int kb = 0; kb < a.nbands; ++kb) {
+                const int p = kb * kWave + lane;
+                const bool rowvalid = p < P;
+                const float *Drow = Dm + (size_t)(min(p, P - 1) >> n) * TmS;
+                double cur = 1.0, upprev = 1.0;
+                for (int s = 0; s < a.nsteps; ++s) {
+                    const int q = s - lane;
+                    const bool active = rowvalid && q >= 0 && q < P;
+                    double up_in = shfl_up_f64(cur);
+                    if (lane == 0) up_in = (kb == 0 || !active) ? 1.0 : rowbuf[q + 1];
+                    if (active) {
+                        const double g = (double)Drow[q >> n] * a.inv_r2;
+                        const double nw = stencil(cur, up_in, upprev, g, naive);
+                        if (a.want_grad) wsk[((size_t)kb * a.nsteps + s) * kWave + lane] = (float)upprev;
+                        cur = nw;
+                        upprev = up_in;
+                        if (lane == kWave - 1) rowbuf[q + 1] = nw;
+                    }
+                }
+                if (p == P - 1) Kval = cur;
+            }
+            if (((P - 1) & (kWave - 1)) == lane) Kout[(size_t)i * a.B + j] = (IO)Kval;
+
+            if (!a.want_grad) continue;
+            __syncthreads();
+
+            // ---- phase 3: reverse sweep, GG = K_fwd[p,q] * U[p+1,q+1], block-summed into S ------
+            for (int kb = a.nbands - 1; kb >= 0; --kb) {
+                const int p = kb * kWave + lane;
+                const bool rowvalid = p < P;
+                const int L = min(kWave, P - kb * kWave);
+                const int arow = min(p, P - 1) >> n;
+                const float *Drow = Dm + (size_t)arow * TmS;
+                double cur = 1.0, dprev = 1.0, sb = 0.0;
+                const int nsp = P + L - 1;
+                for (int sp = 0; sp < nsp; ++sp) {
+                    const int q = P - 1 - (sp - (L - 1 - lane));
+                    const bool active = rowvalid && q >= 0 && q < P;
+                    double down_in = shfl_down_f64(cur);
+                    if (lane == L - 1) down_in = (kb == a.nbands - 1 || !active) ? 1.0 : rowbuf[q];
+                    if (active) {
+                        const double g = (double)Drow[q >> n] * a.inv_r2;
+                        const double kf = (double)wsk[((size_t)kb * a.nsteps + lane + q) * kWave + lane];
+                        sb = __builtin_fma(kf, dprev, sb);
+                        if ((q & (r - 1)) == 0) {
+                            atomicAdd(&Sm[arow * Tm + (q >> n)], sb * a.inv_r2);
+                            sb = 0.0;
+                        }
+                        const double nw = stencil(cur, down_in, dprev, g, naive);
+                        cur = nw;
+                        dprev = down_in;
+                        if (lane == 0 && kb > 0) rowbuf[q] = nw;
+                    }
+                }
+            }
+            __syncthreads();
+
+            // ---- phase 4: chain S -> R -> static-kernel derivative -> per-point gradient --------
+            double w = 1.0;
+            if (GO) {
+                w = (double)GO[(size_t)i * a.B + j];
+                if (a.sym) w += (double)GO[(size_t)j * a.B + i];
+            } else if (a.sym) {
+                w = 2.0;
+            }
+            for (int m = lane; m < T; m += kWave) {
+                for (int c0 = 0; c0 < d; c0 += 16) {
+                    double accv[16];
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) accv[c] = 0.0;
+                    double s0 = 0.0;
+                    for (int nn = 0; nn < T; ++nn) {
+                        double R = 0.0;
+                        if (m >= 1 && nn >= 1) R += Sm[(m - 1) * Tm + nn - 1];
+                        if (m < Tm && nn < Tm) R += Sm[m * Tm + nn];
+                        if (m >= 1 && nn < Tm) R -= Sm[(m - 1) * Tm + nn];
+                        if (m < Tm && nn >= 1) R -= Sm[m * Tm + nn - 1];
+                        double rg = R;
+                        if (rbf) {
+                            double dot = 0.0;
+                            for (int c = 0; c < d; ++c) dot = __builtin_fma(xs[m * dp + c], ys[nn * dp + c], dot);
+                            rg = R * exp64((2.0 * dot - xn[m] - yn[nn]) * a.inv_h);
+                            s0 += rg;
+                        }
+#pragma unroll
+                        for (int c = 0; c < 16; ++c)
+                            if (c0 + c < d) accv[c] = __builtin_fma(rg, ys[nn * dp + c0 + c], accv[c]);
+                    }
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) {
+                        if (c0 + c < d) {
+                            const double val = rbf ? (-2.0 * a.inv_h) * (xs[m * dp + c0 + c] * s0 - accv[c]) : accv[c];
+                            acc[m * dp + c0 + c] = __builtin_fma(w, val, acc[m * dp + c0 + c]);
+                        }
+                    }
+                }
+            }
+        } // j
+
+        if (a.want_grad) {
+            __syncthreads();
+            double *dst = a.partials + ((size_t)i * a.nchunks + chunk) * T * d;
+            for (int e = lane; e < T * d; e += kWave) dst[e] = acc[(e / d) * dp + (e % d)];
+        }
+    }
+}
+
+// gradX[i][e] = sum_chunk partials[i][chunk][e]  (fixed order => deterministic)
+template <typename IO>
+__global__ void reduce_partials_kernel(const double *partials, IO *gradX, int A, int nchunks, int TD)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)A * TD) return;
+    const size_t i = idx / TD, e = idx % TD;
+    double s = 0.0;
+    for (int c = 0; c < nchunks; ++c) s += partials[(i * nchunks + c) * TD + e];
+    gradX[idx] = (IO)s;
+}
+
+namespace {
+struct GenericPlan {
+    int dp, Tm, TmS, r, P, nbands, nsteps, JC, nchunks, grid;
+    long long items;
+    size_t lds, partial_bytes, wsk_per_block, wsk_bytes;
+};
+
+int make_plan(int A, int B, int T, int d, int n, int want_grad, GenericPlan &pl)
+{
+    if (A < 1 || B < 1 || T < 2 || d < 1 || n < 0 || n > 10) {
+        set_error("generic: bad shape A=%d B=%d T=%d d=%d n=%d", A, B, T, d, n);
+        return SIGSVGD_E_BADARG;
+    }
+    pl.dp = (d % 2 == 0) ? d + 1 : d;
+    pl.Tm = T - 1;
+    pl.TmS = pl.Tm | 1;
+    pl.r = 1 << n;
+    const long long P64 = (long long)pl.r * pl.Tm;
+    if (P64 > 16384) {
+        set_error("generic: refined grid P=%lld too large", P64);
+        return SIGSVGD_E_UNSUPPORTED;
+    }
+    pl.P = (int)P64;
+    pl.nbands = (pl.P + kWave - 1) / kWave;
+    pl.nsteps = pl.P + kWave - 1;
+    pl.lds = generic_lds_bytes(T, d, n, want_grad);
+    if (pl.lds > 160 * 1024) {
+        set_error("generic: per-pair state needs %zu B of LDS (> 160 KiB): T=%d d=%d n=%d", pl.lds, T, d, n);
+        return SIGSVGD_E_UNSUPPORTED;
+    }
+    // j-chunk: enough work items to fill the chip, few enough partial slabs
+    int JC = 32;
+    while (JC > 1 && (long long)A * ((B + JC - 1) / JC) < 2048) JC >>= 1;
+    pl.JC = JC;
+    pl.nchunks = (B + JC - 1) / JC;
+    pl.items = (long long)A * pl.nchunks;
+    const int per_cu = (int)((160 * 1024) / (pl.lds ? pl.lds : 1));
+    int grid = 256 * (per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu));
+    if ((long long)grid > pl.items) grid = (int)pl.items;
+    pl.grid = grid;
+    pl.partial_bytes = want_grad ? (size_t)A * pl.nchunks * T * d * sizeof(double) : 0;
+    pl.wsk_per_block = want_grad ? (size_t)pl.nbands * pl.nsteps * kWave : 0;
+    pl.wsk_bytes = pl.wsk_per_block * sizeof(float) * grid;
+    return SIGSVGD_OK;
+}
+} // namespace
+
+int generic_workspace_bytes(int A, int B, int T, int d, int n, int want_grad, size_t *bytes)
+{
+    GenericPlan pl;
+    int rc = make_plan(A, B, T, d, n, want_grad, pl);
+    if (rc) return rc;
+    *bytes = pl.partial_bytes + pl.wsk_bytes + 256;
+    return SIGSVGD_OK;
+}
+
+int generic_launch(const GramProblem &p)
+{
+    const int want_grad = p.gradX_out != nullptr;
+    GenericPlan pl;
+    int rc = make_plan(p.A, p.B, p.T, p.d, p.n, want_grad, pl);
+    if (rc) return rc;
+    const size_t need = pl.partial_bytes + pl.wsk_bytes + 256;
+    if (want_grad && (p.ws == nullptr || p.ws_bytes < need)) {
+        set_error("generic: workspace %zu B < required %zu B", p.ws_bytes, need);
+        return SIGSVGD_E_WORKSPACE;
+    }
+    const bool sym = (p.flags & SIGSVGD_FLAG_SYM) != 0;
+    if (sym && p.A != p.B) {
+        set_error("sym backward needs A == B");
+        return SIGSVGD_E_BADARG;
+    }
+    GenericArgs a;
+    a.X = p.X; a.Y = p.Y; a.grad_out = p.grad_out; a.K_out = p.K_out;
+    unsigned char *base = static_cast<unsigned char *>(p.ws);
+    a.partials = want_grad ? reinterpret_cast<double *>((reinterpret_cast<uintptr_t>(base) + 255) & ~(uintptr_t)255) : nullptr;
+    a.wsk = want_grad ? reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(a.partials) + pl.partial_bytes) : nullptr;
+    a.A = p.A; a.B = p.B; a.T = p.T; a.d = p.d; a.dp = pl.dp; a.n = p.n; a.r = pl.r; a.P = pl.P;
+    a.Tm = pl.Tm; a.TmS = pl.TmS; a.nbands = pl.nbands; a.nsteps = pl.nsteps; a.JC = pl.JC;
+    a.nchunks = pl.nchunks; a.kind = p.kind; a.naive = (p.flags & SIGSVGD_FLAG_NAIVE_SOLVER) ? 1 : 0;
+    a.sym = sym ? 1 : 0; a.want_grad = want_grad; a.inv_h = p.inv_h;
+    a.inv_r2 = 1.0 / ((double)pl.r * (double)pl.r);
+    a.total_items = pl.items; a.wsk_per_block = pl.wsk_per_block;
+
+    hipError_t e;
+    if (p.dtype == SIGSVGD_F64) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gram_generic_kernel<double>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
+        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(generic<f64>)");
+        hipLaunchKernelGGL(gram_generic_kernel<double>, dim3(pl.grid), dim3(kWave), pl.lds, p.stream, a);
+    } else {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gram_generic_kernel<float>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
+        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(generic<f32>)");
+        hipLaunchKernelGGL(gram_generic_kernel<float>, dim3(pl.grid), dim3(kWave), pl.lds, p.stream, a);
+    }
+    e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "launch gram_generic_kernel");
+    if (want_grad) {
+        const int TD = p.T * p.d;
+        const size_t tot = (size_t)p.A * TD;
+        const int bs = 256;
+        const unsigned gs = (unsigned)((tot + bs - 1) / bs);
+        if (p.dtype == SIGSVGD_F64)
+            hipLaunchKernelGGL(reduce_partials_kernel<double>, dim3(gs), dim3(bs), 0, p.stream, a.partials,
+                               static_cast<double *>(p.gradX_out), p.A, pl.nchunks, TD);
+        else
+            hipLaunchKernelGGL(reduce_partials_kernel<float>, dim3(gs), dim3(bs), 0, p.stream, a.partials,
+                               static_cast<float *>(p.gradX_out), p.A, pl.nchunks, TD);
+        e = hipGetLastError();
+        if (e != hipSuccess) return hip_fail(e, "launch reduce_partials_kernel");
+    }
+    return SIGSVGD_OK;
+}
+
+} // namespace sigsvgd

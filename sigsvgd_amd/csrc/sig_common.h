@@ -1,0 +1,103 @@
+// Shared device helpers for the signature-kernel HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/sigsvgd_hip.h"
+
+namespace sigsvgd {
+
+constexpr int kWave = 64;
+
+// ---- error plumbing (host) -------------------------------------------------------------------
+void set_error(const char *fmt, ...);
+int hip_fail(hipError_t e, const char *what);
+
+// ---- fp64 exp -----------------------------------------------------------------------------
+// exp(a) = 2^k * P(r), k = rint(a*log2e), r = a - k*ln2 (two-word ln2), P = degree-11 Taylor/Horner
+// on |r| <= ln2/2.  Relative error < 3e-16 * few; enough for the 4-corner cancellation in the
+// kernel increments (needs ~1e-10).  One v_rndne_f64 + v_cvt_i32_f64 + v_ldexp_f64 + 14 FMA/MUL.
+__device__ __forceinline__ double exp64(double a)
+{
+    a = fmin(fmax(a, -1000.0), 700.0);
+    const double kf = __builtin_rint(a * 1.4426950408889634074);
+    double r = __builtin_fma(kf, -6.93147180369123816490e-01, a);
+    r = __builtin_fma(kf, -1.90821492927058770002e-10, r);
+    double p = 2.50521083854417187751e-08;              // 1/11!
+    p = __builtin_fma(p, r, 2.75573192239858906526e-07); // 1/10!
+    p = __builtin_fma(p, r, 2.75573192239858906526e-06); // 1/9!
+    p = __builtin_fma(p, r, 2.48015873015873015873e-05); // 1/8!
+    p = __builtin_fma(p, r, 1.98412698412698412698e-04); // 1/7!
+    p = __builtin_fma(p, r, 1.38888888888888888889e-03); // 1/6!
+    p = __builtin_fma(p, r, 8.33333333333333333333e-03); // 1/5!
+    p = __builtin_fma(p, r, 4.16666666666666666667e-02); // 1/4!
+    p = __builtin_fma(p, r, 1.66666666666666666667e-01); // 1/3!
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    return ldexp(p, (int)kf);
+}
+
+// ---- Goursat stencils -------------------------------------------------------------------------
+// default (second order):  K11 = (K10 + K01)*(1 + g/2 + g^2/12) - K00*(1 - g^2/12)
+// written in delta form so that the O(1) parts cancel exactly in fp64:
+//   K11 = (t - K00) + t*a + K00*b,  t = K10 + K01, a = g/2 + g^2/12, b = g^2/12
+// naive (first order):     K11 = K10 + K01 + K00*(g - 1)
+__device__ __forceinline__ double stencil(double k10, double k01, double k00, double g, bool naive)
+{
+    const double t = k10 + k01;
+    if (naive) return __builtin_fma(k00, g, t - k00);
+    const double b = g * g * (1.0 / 12.0);
+    const double a = __builtin_fma(g, 0.5, b);
+    double u = t - k00;
+    u = __builtin_fma(t, a, u);
+    return __builtin_fma(k00, b, u);
+}
+
+template <typename T>
+__device__ __forceinline__ double ld_as_f64(const T *p, size_t i)
+{
+    return (double)p[i];
+}
+
+template <typename T>
+__device__ __forceinline__ void st_from_f64(T *p, size_t i, double v)
+{
+    p[i] = (T)v;
+}
+
+__device__ __forceinline__ double shfl_up_f64(double v)   // lane l <- lane l-1 (lane 0 keeps own)
+{
+    return __shfl_up(v, 1, kWave);
+}
+__device__ __forceinline__ double shfl_down_f64(double v) // lane l <- lane l+1 (lane 63 keeps own)
+{
+    return __shfl_down(v, 1, kWave);
+}
+
+// ---- launch descriptors shared by host code -----------------------------------------------------
+struct GramProblem {
+    const void *X, *Y;
+    int A, B, T, d, dtype;
+    double inv_h;
+    int n;            // dyadic order
+    int kind;         // SIGSVGD_STATIC_*
+    unsigned flags;
+    const void *grad_out; // nullable
+    void *K_out;
+    void *gradX_out;  // nullable => forward only
+    void *ws;
+    size_t ws_bytes;
+    hipStream_t stream;
+};
+
+// generic (any T, n, d that fits LDS) -- gram_generic.hip
+int generic_workspace_bytes(int A, int B, int T, int d, int n, int want_grad, size_t *bytes);
+int generic_launch(const GramProblem &p);
+
+// register-resident fast path (n == 0, T <= 64, RBF/linear) -- gram_fast.hip
+bool fast_supported(int A, int B, int T, int d, int n, int kind, unsigned flags);
+int fast_workspace_bytes(int A, int B, int T, int d, int want_grad, unsigned flags, size_t *bytes);
+int fast_launch(const GramProblem &p);
+
+} // namespace sigsvgd

@@ -1,0 +1,177 @@
+"""Thin torch-facing wrappers over the C ABI (the ONLY place the package touches the HIP library).
+
+Every function takes/returns torch tensors living on an MI355X (`device.type == "cuda"` on ROCm),
+checks dtype/contiguity, passes raw device pointers + the current HIP stream to the library and
+converts status codes into RuntimeError.  CPU tensors are rejected: there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+_WS = {}  # (device index, stream) -> uint8 workspace tensor
+
+
+def _require_gpu(*tensors) -> torch.device:
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if t.device.type != "cuda":
+            raise RuntimeError(
+                "sigsvgd_amd: the signature-kernel/SVGD hot path runs only on a HIP device (MI355X); "
+                f"got a tensor on '{t.device}'. There is no CPU fallback."
+            )
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError(f"sigsvgd_amd: tensors on different devices ({dev} vs {t.device})")
+    return dev
+
+
+def _stream_ptr(dev: torch.device) -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _workspace(dev: torch.device, nbytes: int) -> Tuple[Optional[torch.Tensor], int]:
+    if nbytes == 0:
+        return None, 0
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=dev)
+        _WS[key] = ws
+    return ws, ws.numel()
+
+
+def _io_dtype(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return _lib.F32
+    if t.dtype == torch.float64:
+        return _lib.F64
+    raise TypeError(f"sigsvgd_amd: paths must be float32 or float64, got {t.dtype}")
+
+
+def _prep_paths(X: torch.Tensor, Y: torch.Tensor):
+    if X.dim() != 3 or Y.dim() != 3:
+        raise ValueError(f"paths must be [batch, length, dim]; got {tuple(X.shape)} and {tuple(Y.shape)}")
+    if X.shape[1:] != Y.shape[1:]:
+        raise ValueError(
+            f"X and Y must share length and dim (got {tuple(X.shape)} vs {tuple(Y.shape)}); "
+            "unequal path lengths are not supported by this build"
+        )
+    if X.dtype != Y.dtype:
+        Y = Y.to(X.dtype)
+    if X.shape[0] == 0 or Y.shape[0] == 0:
+        raise ValueError("empty batch")
+    if X.shape[1] < 2:
+        raise ValueError("paths need at least 2 points")
+    return X.detach().contiguous(), Y.detach().contiguous()
+
+
+def _flags(naive: bool, sym: bool, y_is_x: bool, force_generic: bool) -> int:
+    f = 0
+    if naive:
+        f |= _lib.FLAG_NAIVE_SOLVER
+    if sym:
+        f |= _lib.FLAG_SYM
+    if y_is_x:
+        f |= _lib.FLAG_Y_IS_X
+    if force_generic:
+        f |= _lib.FLAG_FORCE_GENERIC
+    return f
+
+
+def gram_fwd(X, Y, inv_h: float, dyadic_order: int = 0, static_kind: int = _lib.STATIC_RBF,
+             naive: bool = False, force_generic: bool = False) -> torch.Tensor:
+    """K[A,B] = signature-kernel Gram matrix (forward only)."""
+    L = _lib.load()
+    dev = _require_gpu(X, Y)
+    Xc, Yc = _prep_paths(X, Y)
+    A, T, d = Xc.shape
+    B = Yc.shape[0]
+    flags = _flags(naive, False, False, force_generic)
+    nbytes = ctypes.c_size_t(0)
+    _lib.check(L.sigsvgd_gram_workspace_bytes(A, B, T, d, dyadic_order, 0, flags, ctypes.byref(nbytes)),
+               "gram_workspace_bytes")
+    ws, wsn = _workspace(dev, nbytes.value)
+    K = torch.empty((A, B), dtype=Xc.dtype, device=dev)
+    with torch.cuda.device(dev):
+        rc = L.sigsvgd_gram_fwd(Xc.data_ptr(), Yc.data_ptr(), A, B, T, d, _io_dtype(Xc), float(inv_h),
+                                int(dyadic_order), int(static_kind), flags, K.data_ptr(),
+                                ws.data_ptr() if ws is not None else None, wsn, _stream_ptr(dev))
+    _lib.check(rc, "gram_fwd")
+    return K
+
+
+def gram_fwd_bwd(X, Y, inv_h: float, dyadic_order: int = 0, static_kind: int = _lib.STATIC_RBF,
+                 grad_out: Optional[torch.Tensor] = None, naive: bool = False, sym: bool = False,
+                 y_is_x: bool = False, force_generic: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(K[A,B], gradX[A,T,d]) with gradX = d sum(grad_out*K)/dX (first slot); grad_out None = ones."""
+    L = _lib.load()
+    dev = _require_gpu(X, Y, grad_out)
+    Xc, Yc = _prep_paths(X, Y)
+    A, T, d = Xc.shape
+    B = Yc.shape[0]
+    go = None
+    if grad_out is not None:
+        if tuple(grad_out.shape) != (A, B):
+            raise ValueError(f"grad_out must be [{A},{B}], got {tuple(grad_out.shape)}")
+        go = grad_out.detach().to(Xc.dtype).contiguous()
+    flags = _flags(naive, sym, y_is_x, force_generic)
+    nbytes = ctypes.c_size_t(0)
+    _lib.check(L.sigsvgd_gram_workspace_bytes(A, B, T, d, dyadic_order, 1, flags, ctypes.byref(nbytes)),
+               "gram_workspace_bytes")
+    ws, wsn = _workspace(dev, nbytes.value)
+    K = torch.empty((A, B), dtype=Xc.dtype, device=dev)
+    gX = torch.empty((A, T, d), dtype=Xc.dtype, device=dev)
+    with torch.cuda.device(dev):
+        rc = L.sigsvgd_gram_fwd_bwd(Xc.data_ptr(), Yc.data_ptr(), A, B, T, d, _io_dtype(Xc), float(inv_h),
+                                    int(dyadic_order), int(static_kind), flags,
+                                    go.data_ptr() if go is not None else None, K.data_ptr(), gX.data_ptr(),
+                                    ws.data_ptr() if ws is not None else None, wsn, _stream_ptr(dev))
+    _lib.check(rc, "gram_fwd_bwd")
+    return K, gX
+
+
+def svgd_phi(K, score, grad_k, mask=None, X=None, lr: Optional[float] = None):
+    """v = -((K @ score - grad_k)/N) [* mask]; with X and lr also returns X - lr*v.
+
+    All fp32, shapes K [N,N], score/grad_k/mask/X [N, ...] (flattened to [N,D]).
+    Returns v (shaped like score) or (v, X_new)."""
+    L = _lib.load()
+    dev = _require_gpu(K, score, grad_k, mask, X)
+    N = K.shape[0]
+    if K.dim() != 2 or K.shape[1] != N:
+        raise ValueError(f"K must be square, got {tuple(K.shape)}")
+    shape = score.shape
+    f = lambda t: t.detach().to(torch.float32).reshape(N, -1).contiguous()
+    Kc = K.detach().to(torch.float32).contiguous()
+    s, gk = f(score), f(grad_k)
+    D = s.shape[1]
+    if gk.shape != s.shape:
+        raise ValueError(f"grad_k shape {tuple(grad_k.shape)} does not match score {tuple(score.shape)}")
+    m = None
+    if mask is not None:
+        m = torch.broadcast_to(torch.as_tensor(mask, dtype=torch.float32, device=dev), shape)
+        m = m.reshape(N, -1).contiguous()
+    v = torch.empty_like(s)
+    Xc = Xn = None
+    if X is not None:
+        if lr is None:
+            raise ValueError("lr is required with X")
+        Xc = f(X)
+        Xn = torch.empty_like(Xc)
+    with torch.cuda.device(dev):
+        rc = L.sigsvgd_svgd_phi(Kc.data_ptr(), s.data_ptr(), gk.data_ptr(), m.data_ptr() if m is not None else None,
+                                N, D, v.data_ptr(), Xc.data_ptr() if Xc is not None else None,
+                                Xn.data_ptr() if Xn is not None else None, float(lr or 0.0), _stream_ptr(dev))
+    _lib.check(rc, "svgd_phi")
+    v = v.reshape(shape)
+    if X is not None:
+        return v, Xn.reshape(X.shape)
+    return v

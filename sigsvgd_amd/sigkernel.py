@@ -1,0 +1,157 @@
+"""`sigkernel`-compatible front end of the HIP signature-kernel path.
+
+The reference delegates the Goursat-PDE arithmetic to the third-party package `sigkernel`
+(/root/reference/setup.py:71) and uses exactly this surface of it:
+
+    sigkernel.SigKernel(static_kernel, dyadic_order)            src/kernels/_traj_kernels.py:201
+        .compute_Gram(X.double(), Y.double(), sym=False)        src/kernels/_traj_kernels.py:205,
+                                                                src/inference/trajectory_svgd.py:60-62
+    sigkernel.RBFKernel(sigma)                                  examples/script_control_particle_maze.py:43
+    isinstance(kernel, sigkernel.SigKernel)                     src/inference/trajectory_svgd.py:55
+
+This module provides those names on top of libsigsvgd_hip.so, so `sys.modules["sigkernel"] =
+sigsvgd_amd.sigkernel` makes the reference's own code run on the MI355X path.
+`compute_Gram` is an autograd node: backward receives grad_output [A,B] and returns the gradient
+for X only (None for everything else), like upstream.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib, ops
+
+__all__ = ["SigKernel", "RBFKernel", "LinearKernel", "gram_and_grad"]
+
+
+# ------------------------------------------------------------------------------------------------
+# static kernels
+# ------------------------------------------------------------------------------------------------
+class LinearKernel:
+    """k(x, y) = <x, y>."""
+
+    static_kind = _lib.STATIC_LINEAR
+
+    def inv_bandwidth(self, X, Y) -> float:
+        return 1.0
+
+    def batch_kernel(self, X, Y):
+        return torch.bmm(X, Y.permute(0, 2, 1))
+
+    def Gram_matrix(self, X, Y):
+        return torch.einsum("ipk,jqk->ijpq", X, Y)
+
+
+class RBFKernel:
+    """k(x, y) = exp(-|x-y|^2 / sigma)   (sigkernel's convention: divide by sigma, not 2 sigma^2)."""
+
+    static_kind = _lib.STATIC_RBF
+
+    def __init__(self, sigma):
+        self.sigma = sigma
+
+    def inv_bandwidth(self, X, Y) -> float:
+        return 1.0 / float(self.sigma)
+
+    def batch_kernel(self, X, Y):
+        Xs = torch.sum(X**2, dim=2)
+        Ys = torch.sum(Y**2, dim=2)
+        dist = -2.0 * torch.bmm(X, Y.permute(0, 2, 1))
+        dist = dist + Xs[:, :, None] + Ys[:, None, :]
+        return torch.exp(-dist / self.sigma)
+
+    def Gram_matrix(self, X, Y):
+        Xs = torch.sum(X**2, dim=2)
+        Ys = torch.sum(Y**2, dim=2)
+        dist = -2.0 * torch.einsum("ipk,jqk->ijpq", X, Y)
+        dist = dist + Xs[:, None, :, None] + Ys[None, :, None, :]
+        return torch.exp(-dist / self.sigma)
+
+
+def _resolve_static(static_kernel, X, Y):
+    """-> (static_kind, inv_h).  Accepts this module's kernels and anything exposing the same two
+    members (e.g. sigsvgd_amd.kernels.BatchGaussianKernel).  Arbitrary user static kernels would
+    need their own device code and are rejected (no silent slow path)."""
+    if hasattr(static_kernel, "static_kind") and hasattr(static_kernel, "inv_bandwidth"):
+        return int(static_kernel.static_kind), float(static_kernel.inv_bandwidth(X, Y))
+    raise NotImplementedError(
+        f"static kernel {type(static_kernel).__name__} is not supported by the HIP path "
+        "(supported: RBFKernel, LinearKernel, BatchGaussianKernel)"
+    )
+
+
+# ------------------------------------------------------------------------------------------------
+# autograd node
+# ------------------------------------------------------------------------------------------------
+class _SigKernelGram(torch.autograd.Function):
+    """forward: K = Gram(X, Y).  backward: d sum(grad_output*K)/dX, nothing for Y.
+
+    When X needs a gradient the forward already runs the fused forward+backward kernel for
+    grad_output = 1 (the only grad_output the reference ever produces: callers differentiate
+    K.sum(), score.py:69 / trajectory_svgd.py:65), so the usual backward is a scale by a scalar.
+    Any other grad_output triggers one more fused launch with the real weights."""
+
+    @staticmethod
+    def forward(ctx, X, Y, static_kind, inv_h, dyadic_order, naive, sym, y_is_x, speculate):
+        ctx.cfg = (static_kind, inv_h, dyadic_order, naive, sym, y_is_x)
+        ctx.g_ones = None
+        Xd = X.detach()
+        Yd = Y.detach()
+        if ctx.needs_input_grad[0] and speculate:
+            K, g1 = ops.gram_fwd_bwd(Xd, Yd, inv_h, dyadic_order, static_kind, None, naive, sym, y_is_x)
+            ctx.g_ones = g1
+        else:
+            K = ops.gram_fwd(Xd, Yd, inv_h, dyadic_order, static_kind, naive)
+        ctx.save_for_backward(Xd, Yd)
+        return K
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        X, Y = ctx.saved_tensors
+        static_kind, inv_h, dyadic_order, naive, sym, y_is_x = ctx.cfg
+        gX = None
+        if ctx.g_ones is not None:
+            scalar = None
+            if grad_output.stride() == (0, 0):  # expanded scalar, e.g. from K.sum().backward()
+                scalar = grad_output.reshape(-1)[:1]
+            else:
+                first = grad_output.reshape(-1)[:1]
+                if bool((grad_output == first).all()):  # one host sync; uniform weights => scale
+                    scalar = first
+            if scalar is not None:
+                gX = ctx.g_ones * scalar.to(ctx.g_ones.dtype)
+        if gX is None:
+            _, gX = ops.gram_fwd_bwd(X, Y, inv_h, dyadic_order, static_kind, grad_output, naive, sym, False)
+        return gX, None, None, None, None, None, None, None, None
+
+
+class SigKernel:
+    """Signature kernel with a static kernel and a dyadic refinement order (PDE solver)."""
+
+    def __init__(self, static_kernel, dyadic_order: int, _naive_solver: bool = False):
+        self.static_kernel = static_kernel
+        self.dyadic_order = int(dyadic_order)
+        self._naive_solver = bool(_naive_solver)
+        self.speculate_ones = True
+
+    def compute_Gram(self, X: torch.Tensor, Y: torch.Tensor, sym: bool = False) -> torch.Tensor:
+        """K[i,j] = k_sig(X_i, Y_j), X [A,T,d], Y [B,T,d] on a HIP device; same dtype/device as X."""
+        static_kind, inv_h = _resolve_static(self.static_kernel, X, Y)
+        y_is_x = (
+            Y.data_ptr() == X.data_ptr() and Y.shape == X.shape and Y.stride() == X.stride() and Y.dtype == X.dtype
+        )
+        return _SigKernelGram.apply(X, Y, static_kind, inv_h, self.dyadic_order, self._naive_solver, bool(sym),
+                                    y_is_x, self.speculate_ones)
+
+    def gram_and_grad(self, X: torch.Tensor, Y: Optional[torch.Tensor] = None, grad_out=None, sym: bool = False):
+        """One fused launch: (K, d sum(grad_out*K)/dX) with detached tensors.  Equivalent to
+        `K = compute_Gram(X, Y); g = autograd.grad((grad_out*K).sum(), X)` (score.py:68-69)."""
+        Yv = X if Y is None else Y
+        static_kind, inv_h = _resolve_static(self.static_kernel, X, Yv)
+        return ops.gram_fwd_bwd(X, Yv, inv_h, self.dyadic_order, static_kind, grad_out, self._naive_solver, sym,
+                                y_is_x=Y is None)
+
+
+def gram_and_grad(kernel: SigKernel, X, Y=None, grad_out=None):
+    return kernel.gram_and_grad(X, Y, grad_out)

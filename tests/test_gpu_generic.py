@@ -1,0 +1,79 @@
+"""GPU parity: generic HIP kernel vs the fp64 oracle (through the C ABI via sigsvgd_amd.ops)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import sigkernel_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5  # north_star: within 1e-5 relative fp32
+
+
+def _paths(A, T, d, seed, scale=0.3):
+    rng = np.random.default_rng(seed)
+    return np.cumsum(scale * rng.standard_normal((A, T, d)), axis=1).astype(np.float32)
+
+
+def _rel(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - b).max() / np.abs(b).max())
+
+
+CASES = [
+    # A, B, T, d, n, kind, naive
+    (5, 4, 7, 3, 0, 0, False),
+    (5, 4, 7, 3, 2, 0, False),
+    (3, 6, 5, 2, 5, 0, False),   # reference obstacle-field shape: T=5, depth=5
+    (4, 4, 3, 7, 6, 0, False),   # reference robot shape: T=3 knots, depth=6, d=7
+    (6, 5, 20, 2, 2, 0, False),  # C1: T=20, d=2, depth 2
+    (3, 3, 30, 2, 3, 0, False),  # particle-maze: T=30, dyadic 3 (P=232, 4 bands)
+    (4, 5, 9, 3, 1, 1, False),   # linear static kernel
+    (4, 5, 9, 3, 1, 0, True),    # naive solver
+    (2, 3, 70, 3, 0, 0, False),  # T > 64 (two bands at n=0)
+    (3, 2, 33, 17, 0, 0, False), # d > 16
+]
+
+
+@pytest.mark.parametrize("A,B,T,d,n,kind,naive", CASES)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_generic_fwd_bwd(gpu, A, B, T, d, n, kind, naive, dtype):
+    from sigsvgd_amd import ops
+
+    X = _paths(A, T, d, 1)
+    Y = _paths(B, T, d, 2)
+    h = 1.7
+    rng = np.random.default_rng(3)
+    go = rng.standard_normal((A, B))
+    Kref, gref = O.gram_backward(X, Y, go, kind, h, n, naive)
+    Xg = torch.as_tensor(X, device=gpu).to(dtype)
+    Yg = torch.as_tensor(Y, device=gpu).to(dtype)
+    gog = torch.as_tensor(go, device=gpu).to(dtype)
+    K1 = ops.gram_fwd(Xg, Yg, 1.0 / h, n, kind, naive=naive, force_generic=True)
+    K2, g2 = ops.gram_fwd_bwd(Xg, Yg, 1.0 / h, n, kind, grad_out=gog, naive=naive, force_generic=True)
+    torch.cuda.synchronize()
+    assert _rel(K1.cpu().numpy(), Kref) < TOL
+    assert _rel(K2.cpu().numpy(), Kref) < TOL
+    # grad_out is rounded to the I/O dtype on the way in
+    gref_io = O.gram_backward(X, Y, gog.cpu().numpy().astype(np.float64), kind, h, n, naive)[1]
+    assert _rel(g2.cpu().numpy(), gref_io) < TOL
+    # ones path (NULL grad_out)
+    K3, g3 = ops.gram_fwd_bwd(Xg, Yg, 1.0 / h, n, kind, naive=naive, force_generic=True)
+    assert _rel(g3.cpu().numpy(), O.gram_backward(X, Y, None, kind, h, n, naive)[1]) < TOL
+
+
+def test_phi(gpu):
+    from sigsvgd_amd import ops
+
+    rng = np.random.default_rng(0)
+    for N, D in [(16, 40), (100, 20), (128, 224), (257, 65)]:
+        K = rng.standard_normal((N, N)).astype(np.float32)
+        s = rng.standard_normal((N, D)).astype(np.float32)
+        gk = rng.standard_normal((N, D)).astype(np.float32)
+        m = (rng.random((N, D)) > 0.3).astype(np.float32)
+        X = rng.standard_normal((N, D)).astype(np.float32)
+        vref = O.svgd_velocity(K, s, gk, m)
+        v, Xn = ops.svgd_phi(*(torch.as_tensor(t, device=gpu) for t in (K, s, gk, m)), X=torch.as_tensor(X, device=gpu), lr=0.1)
+        assert _rel(v.cpu().numpy(), vref) < TOL
+        assert _rel(Xn.cpu().numpy(), X - 0.1 * vref) < TOL
+        v2 = ops.svgd_phi(*(torch.as_tensor(t, device=gpu) for t in (K, s, gk)))
+        assert _rel(v2.cpu().numpy(), O.svgd_velocity(K, s, gk)) < TOL
