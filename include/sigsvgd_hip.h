@@ -81,6 +81,19 @@ int sigsvgd_gram_fwd_bwd(const void *X, const void *Y, int A, int B, int T, int 
                          const void *grad_out, void *K_out, void *gradX_out, void *workspace,
                          size_t workspace_bytes, void *stream);
 
+/* Multi-GPU building block (particles sharded over ranks; new design, the reference has no
+ * distributed code -- SURVEY.md §8e).  Solves the unordered pairs {i <= j} whose row tile
+ * (8 consecutive rows i for d <= 8, 4 for d <= 16) has index tile_offset + k*tile_stride, on the
+ * full gathered particle tensor X[N,T,d], and ACCUMULATES into caller-zeroed buffers:
+ *   K_partial[N,N]      (dtype)  both orientations K[i,j], K[j,i] of every owned pair, 0 elsewhere
+ *   grad_partial[N,T,d] (fp64)   this rank's share of d sum(grad_out*K)/dX (row- and column-side)
+ * Summing the buffers over tile_offset = 0..tile_stride-1 gives exactly sigsvgd_gram_fwd_bwd's
+ * outputs.  Only the register-resident shapes (dyadic_order 0, 3 <= T <= 64, d <= 16, RBF). */
+int sigsvgd_gram_sym_partial(const void *X, int N, int T, int d, int dtype, double inv_h,
+                             int static_kind, unsigned flags, int tile_offset, int tile_stride,
+                             const void *grad_out, void *K_partial, double *grad_partial,
+                             void *stream);
+
 /* v_out[N,D] = -((K[N,N] @ score[N,D] - grad_k[N,D]) / N) * (mask ? mask[N,D] : 1)   (fp32)
  * If X_in and X_out are non-NULL additionally X_out = X_in - lr * v_out (optimizer=None update).
  * The N x N x D product runs on the fp32 MFMA (exact fp32 FMA chain). */

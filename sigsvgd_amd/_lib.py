@@ -28,6 +28,7 @@ EXPORTS = [
     "sigsvgd_gram_workspace_bytes",
     "sigsvgd_gram_fwd",
     "sigsvgd_gram_fwd_bwd",
+    "sigsvgd_gram_sym_partial",
     "sigsvgd_svgd_phi",
 ]
 
@@ -71,6 +72,11 @@ def load():
             f"sigsvgd_amd: HIP extension {LIB_PATH} is not built; run "
             "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). There is no CPU fallback."
         )
+    # PyTorch-ROCm ships its own libamdhip64/libhsa-runtime64; they must be the ones already in the
+    # process when this library's NEEDED entries are resolved, or two HIP runtimes end up loaded
+    # (symptom: "no ROCm-capable device is detected" from the second one).
+    import torch  # noqa: F401
+
     L = ctypes.CDLL(LIB_PATH)
     vp, ci, cd, cu, cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_uint, ctypes.c_float
     L.sigsvgd_abi_version.restype = ci
@@ -83,6 +89,8 @@ def load():
     L.sigsvgd_gram_fwd.argtypes = [vp, vp, ci, ci, ci, ci, ci, cd, ci, ci, cu, vp, vp, ctypes.c_size_t, vp]
     L.sigsvgd_gram_fwd_bwd.restype = ci
     L.sigsvgd_gram_fwd_bwd.argtypes = [vp, vp, ci, ci, ci, ci, ci, cd, ci, ci, cu, vp, vp, vp, vp, ctypes.c_size_t, vp]
+    L.sigsvgd_gram_sym_partial.restype = ci
+    L.sigsvgd_gram_sym_partial.argtypes = [vp, ci, ci, ci, ci, cd, ci, cu, ci, ci, vp, vp, vp, vp]
     L.sigsvgd_svgd_phi.restype = ci
     L.sigsvgd_svgd_phi.argtypes = [vp, vp, vp, vp, ci, ci, vp, vp, vp, cf, vp]
     if L.sigsvgd_abi_version() != ABI_VERSION:

@@ -117,6 +117,21 @@ int sigsvgd_gram_fwd_bwd(const void *X, const void *Y, int A, int B, int T, int 
     return dispatch(p);
 }
 
+int sigsvgd_gram_sym_partial(const void *X, int N, int T, int d, int dtype, double inv_h, int static_kind,
+                             unsigned flags, int tile_offset, int tile_stride, const void *grad_out,
+                             void *K_partial, double *grad_partial, void *stream)
+{
+    int rc = check_common(X, X, N, N, T, d, dtype, inv_h, 0, static_kind, K_partial);
+    if (rc) return rc;
+    if (!grad_partial) {
+        set_error("grad_partial == NULL");
+        return SIGSVGD_E_BADARG;
+    }
+    GramProblem p{X, X, N, N, T, d, dtype, inv_h, 0, static_kind, flags | SIGSVGD_FLAG_Y_IS_X, grad_out,
+                  K_partial, grad_partial, nullptr, 0, static_cast<hipStream_t>(stream)};
+    return fast_sym_partial(p, tile_offset, tile_stride, grad_partial);
+}
+
 int sigsvgd_svgd_phi(const float *K, const float *score, const float *grad_k, const float *mask, int N, int D,
                      float *v_out, const float *X_in, float *X_out, float lr, void *stream)
 {

@@ -1,6 +1,541 @@
+// Register-resident signature-kernel Gram forward/backward for the headline shapes:
+// dyadic order 0, path length T <= 64, RBF static kernel, second-order stencil.
+//
+// Mapping (one wavefront per trajectory pair, as BASELINE.json north_star asks):
+//   * lane l owns row l of the T x T static-kernel matrix G, row l of the (T-1)^2 increment matrix D,
+//     row l+1 of the forward PDE solution K and row l of the reverse solution U;
+//   * on anti-diagonal sigma (= row + column) every lane works on column sigma - l, so every
+//     per-cell quantity a lane will need again (D, K_fwd, G) is filed under slot sigma & 63:
+//     the slot index is a compile-time constant of the (fully unrolled) step, the same for all
+//     lanes, so D and K_fwd live in 2 x 64 VGPRs and G in a [slot][lane] LDS image (XOR-swizzled so
+//     that the transposed read of the symmetric pass is also bank-conflict free);
+//   * neighbour rows are reached with wave-wide DPP shifts (no LDS round trip in the recurrence);
+//   * the static kernel, the 4-corner increments and both PDE sweeps run in fp64 (the increments
+//     cancel ~1e-2 of G; the sweep accumulates ~4e3 cells), everything that is only stored or
+//     contracted (D, K_fwd, G, S = K_fwd*U, R, gradient sums per pair) is fp32, the reduction over
+//     pairs is fp64 -- measured to keep K within 3e-8 and grad within 1e-6 of the fp64 oracle.
+//
+// A workgroup is NW wavefronts = NW consecutive rows i of X against a chunk of columns j; the
+// column trajectory (centred on its first point, fp64 + fp32 copies) is staged once per j in LDS
+// and shared by the NW pairs.  With Y == X each unordered pair {i<j} is solved once: the row-side
+// contraction gives d k(x_i,x_j)/d x_i, the column-side contraction (transposed read of R*G from
+// LDS) gives d k(x_j,x_i)/d x_j.  Gradients are accumulated per lane in fp64 over the j loop and
+// added to an fp64 accumulation buffer with one atomic per element per workgroup.
+//
+// Reference semantics: sigkernel _SigKernelGram.forward/backward [RECALLED, SURVEY.md App. A];
+// static kernel src/kernels/_traj_kernels.py:176-195; callers src/inference/score.py:68-69.
+#include <cstdlib>
+
 #include "sig_common.h"
+
 namespace sigsvgd {
-bool fast_supported(int, int, int, int, int, int, unsigned) { return false; }
-int fast_workspace_bytes(int, int, int, int, int, unsigned, size_t *bytes) { *bytes = 0; return SIGSVGD_OK; }
-int fast_launch(const GramProblem &) { set_error("fast path not built"); return SIGSVGD_E_UNSUPPORTED; }
+
+struct FastArgs {
+    const void *X, *Y, *go;
+    void *K;
+    double *gacc; // [A][T][d] fp64 accumulation buffer (zeroed by the launcher)
+    int io64, A, B, T, d, JC, symw;
+    int dbg; // TEMP timing experiments
+    int tile_offset, tile_stride; // row tiles owned by this launch: offset + k*stride (multi-GPU sharding)
+    double inv_h;
+};
+
+// ---- wave-wide shifts on the DPP path ----------------------------------------------------------
+// wave_shr:1 (0x138): lane l reads lane l-1; wave_shl:1 (0x130): lane l reads lane l+1.
+// With bound_ctrl = 0 a lane without a source keeps `old`, which carries the PDE boundary value.
+__device__ __forceinline__ int dpp_shr1_i(int v, int bound)
+{
+    return __builtin_amdgcn_update_dpp(bound, v, 0x138, 0xF, 0xF, false);
 }
+__device__ __forceinline__ int dpp_shl1_i(int v, int bound)
+{
+    return __builtin_amdgcn_update_dpp(bound, v, 0x130, 0xF, 0xF, false);
+}
+__device__ __forceinline__ double dpp_shr1(double v, double bound)
+{
+    const int lo = dpp_shr1_i(__double2loint(v), __double2loint(bound));
+    const int hi = dpp_shr1_i(__double2hiint(v), __double2hiint(bound));
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double dpp_shl1(double v, double bound)
+{
+    const int lo = dpp_shl1_i(__double2loint(v), __double2loint(bound));
+    const int hi = dpp_shl1_i(__double2hiint(v), __double2hiint(bound));
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float dpp_shr1(float v, float bound)
+{
+    return __int_as_float(dpp_shr1_i(__float_as_int(v), __float_as_int(bound)));
+}
+
+// [slot][lane] image of G (then R*G) with row stride 65 floats: every in-sweep access is
+// lane*4 + constant (one ds instruction with an immediate offset, nothing to keep in registers),
+// and the transposed read of the symmetric pass ((m+n)&63)*65 + m hits 32 distinct banks.
+constexpr int GS_STRIDE = 65;
+constexpr int GS_WAVE = 64 * GS_STRIDE;
+__device__ __forceinline__ int gs_index(int slot, int lane) { return slot * GS_STRIDE + lane; }
+
+template <typename IO>
+__device__ __forceinline__ double load_io(const void *base, size_t idx)
+{
+    return (double)static_cast<const IO *>(base)[idx];
+}
+__device__ __forceinline__ double load_any(const void *base, size_t idx, int io64)
+{
+    return io64 ? load_io<double>(base, idx) : load_io<float>(base, idx);
+}
+__device__ __forceinline__ void store_any(void *base, size_t idx, double v, int io64)
+{
+    if (io64)
+        static_cast<double *>(base)[idx] = v;
+    else
+        static_cast<float *>(base)[idx] = (float)v;
+}
+
+template <int DPAD, int NW, bool GRAD, bool SYM>
+__global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
+{
+    constexpr int NT = NW * 64;
+    // y rows are stored twice (row r and r + 64) so that the skewed row (t - lane) & 63 becomes
+    // (64 - lane) + t: a per-lane base plus a compile-time offset.
+    __shared__ float Gs_all[GRAD ? NW * GS_WAVE : 1];
+    __shared__ float xf_all[(GRAD && SYM) ? NW * 64 * DPAD : 1];
+    __shared__ __align__(16) double yd[128 * DPAD];
+    __shared__ double ynd[128];
+    __shared__ double yref[DPAD];
+    __shared__ __align__(16) float yf[GRAD ? 128 * DPAD : 1];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int T = a.T, d = a.d, P = T - 1, io64 = a.io64;
+    // Block -> (row tile, column chunk).  Symmetric launches enumerate only the chunks that reach the
+    // diagonal of their row tile (a 1-D grid of real work: no early-exit workgroups, which would each
+    // have to wait for a CU with all 160 KB of LDS free just to return).
+    int itile, jchunk;
+    if (SYM) {
+        const int nJ = (a.B + a.JC - 1) / a.JC;
+        int rem = blockIdx.x, k = 0;
+        for (;; ++k) {
+            const int t = k * a.tile_stride + a.tile_offset;
+            const int cnt = nJ - (t * NW) / a.JC; // chunks c >= floor(t*NW/JC) touch or cross the diagonal
+            if (rem < cnt) {
+                itile = t;
+                jchunk = (t * NW) / a.JC + rem;
+                break;
+            }
+            rem -= cnt;
+        }
+    } else {
+        itile = blockIdx.y * a.tile_stride + a.tile_offset;
+        jchunk = blockIdx.x;
+    }
+    const int j0 = jchunk * a.JC;
+    const int j1 = min(a.B, j0 + a.JC);
+    const int i = itile * NW + wave;
+    const bool row_ok = i < a.A;
+    const bool rowD = lane < P;
+    float *Gs = Gs_all + (GRAD ? wave * GS_WAVE : 0);
+    float *xf = xf_all + ((GRAD && SYM) ? wave * 64 * DPAD : 0);
+    const double inv_h = a.inv_h;
+    const float m2h = (float)(-2.0 * inv_h);
+
+    // per-lane fp64 accumulators of d sum_j w_ij k(x_i, y_j) / d x_i[lane, c]
+    double gacc[DPAD];
+#pragma unroll
+    for (int c = 0; c < DPAD; ++c) gacc[c] = 0.0;
+
+    // raw row of x_i owned by this lane (fp64 copy of the fp32/fp64 input; exact)
+    double xraw[DPAD];
+#pragma unroll
+    for (int c = 0; c < DPAD; ++c)
+        xraw[c] = (row_ok && lane < T && c < d) ? load_any(a.X, ((size_t)i * T + lane) * d + c, io64) : 0.0;
+
+    // ---- staging of column trajectory y_j: element e -> (t = e / DPAD, c = e % DPAD) -------------
+    constexpr int EPT = (64 * DPAD + NT - 1) / NT; // elements per thread
+    double stage_v[EPT], stage_r[EPT];
+    auto stage_load = [&](int j) {
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            const int e = tid + k * NT;
+            const int t = e / DPAD, c = e % DPAD;
+            const bool ok = e < 64 * DPAD && t < T && c < d && j < a.B;
+            stage_v[k] = ok ? load_any(a.Y, ((size_t)j * T + t) * d + c, io64) : 0.0;
+            stage_r[k] = ok ? load_any(a.Y, (size_t)j * T * d + c, io64) : 0.0;
+        }
+    };
+    auto stage_store = [&]() {
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            const int e = tid + k * NT;
+            if (e < 64 * DPAD) {
+                const int t = e / DPAD, c = e % DPAD;
+                const double v = stage_v[k] - stage_r[k];
+                yd[e] = v;
+                yd[e + 64 * DPAD] = v;
+                if (GRAD) {
+                    yf[e] = (float)v;
+                    yf[e + 64 * DPAD] = (float)v;
+                }
+                if (t == 0) yref[c] = stage_r[k];
+                double s = v * v; // |y~_t|^2 via xor-reduction over the DPAD lanes of a row
+#pragma unroll
+                for (int off = 1; off < DPAD; off <<= 1) s += __shfl_xor(s, off, 64);
+                if (c == 0) {
+                    ynd[t] = s;
+                    ynd[t + 64] = s;
+                }
+            }
+        }
+    };
+
+    stage_load(j0);
+    stage_store();
+    __syncthreads();
+
+    for (int j = j0; j < j1; ++j) {
+        const bool pair_ok = row_ok && (!SYM || j >= i);
+        if (j + 1 < j1) stage_load(j + 1); // in flight during the pair
+
+        float Dsl[64];
+        float Ksl[64];
+        float ypts[DPAD];
+#pragma unroll
+        for (int c = 0; c < DPAD; ++c) ypts[c] = 0.f;
+
+        if (pair_ok) {
+            // ---- phase 0: centre x_i on y_j[0] ----------------------------------------------------
+            double xt[DPAD];
+            double xn = 0.0;
+#pragma unroll
+            for (int c = 0; c < DPAD; ++c) {
+                xt[c] = (lane < T && c < d) ? xraw[c] - yref[c] : 0.0;
+                xn = __builtin_fma(xt[c], xt[c], xn);
+            }
+            if (GRAD && SYM) {
+#pragma unroll
+                for (int c = 0; c < DPAD; ++c) xf[lane * DPAD + c] = (float)xt[c];
+            }
+
+            // ---- phase 1: G rows (skewed: column (t - lane) & 63 on iteration t) -> D slots --------
+            {
+                double g0 = 0.0, g1 = 0.0, gprev = 0.0, rdprev = 0.0;
+                const double *ybase = yd + (64 - lane) * DPAD; // row (t - lane) & 63 == ybase + t*DPAD
+                const double *nbase = ynd + (64 - lane);
+#pragma unroll
+                for (int t = 0; t < 66; ++t) {
+                    double g;
+                    if (t < 64) {
+                        const double *yr = ybase + t * DPAD;
+                        double dot = 0.0;
+#pragma unroll
+                        for (int c = 0; c < DPAD; ++c) dot = __builtin_fma(xt[c], yr[c], dot);
+                        g = exp64((2.0 * dot - xn - nbase[t]) * inv_h);
+                        if (GRAD) Gs[gs_index(t, lane)] = (float)g;
+                        if (t == 0) g0 = g;
+                        if (t == 1) g1 = g;
+                    } else {
+                        g = (t == 64) ? g0 : g1;
+                    }
+                    const double rd = g - gprev; // G[l, q] - G[l, q-1]
+                    gprev = g;
+                    if (t >= 2) {
+                        // lane l+1 holds the same column difference one iteration later
+                        const double nb = dpp_shl1(rd, 0.0);
+                        Dsl[(t - 2) & 63] = (float)(nb - rdprev);
+                    }
+                    rdprev = rd;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+
+            // ---- phase 2: forward sweep, anti-diagonal sigma = 0 .. 2P-2 ---------------------------
+            {
+                double cur = 1.0, diag = 1.0;
+                const int smax = 2 * P - 2;
+                for (int rnd = 0; rnd < 2; ++rnd) {
+                    if (rnd * 64 > smax) break;
+#pragma unroll
+                    for (int k = 0; k < 64; ++k) {
+                        const int sigma = rnd * 64 + k;
+                        const bool act = rowD && (unsigned)(sigma - lane) < (unsigned)P;
+                        const double up = dpp_shr1(cur, 1.0);
+                        float g = Dsl[k];
+                        asm volatile("" : "+v"(g)); // keep the coefficient math inside the round loop (no LICM)
+                        const float b = g * g * (1.0f / 12.0f);
+                        const float aa = __builtin_fmaf(g, 0.5f, b);
+                        const double t = cur + up;
+                        double u = t - diag;
+                        u = __builtin_fma(t, (double)aa, u);
+                        const double nw = __builtin_fma(diag, (double)b, u);
+                        if (act) {
+                            if (GRAD) Ksl[k] = (float)diag; // K[l, q]
+                            cur = nw;
+                            diag = up;
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                if (lane == P - 1) { // this lane's last value is K[P, P]
+                    store_any(a.K, (size_t)i * a.B + j, cur, io64);
+                    if (SYM && j != i) store_any(a.K, (size_t)j * a.B + i, cur, io64);
+                }
+            }
+
+            if (GRAD) {
+                // ---- phase 3: reverse sweep + lagged R -> row-side contraction ----------------------
+                double cur = 1.0, ddiag = 1.0;
+                float Sb = 0.f, Sc = 0.f, Nb = 0.f, s0 = 0.f;
+                float acc[DPAD];
+#pragma unroll
+                for (int c = 0; c < DPAD; ++c) acc[c] = 0.f;
+                const int smax = 2 * P - 2;
+
+                int yfrow = 64 - lane;                          // row (sigma + 2 - lane) & 63 == yfrow + k2
+                int gsoff = (GRAD ? wave * GS_WAVE : 0) + lane; // this wave's [slot][lane] image
+                auto grad_part = [&](int sigma, float Snew) {
+                    const int k2 = (sigma + 2) & 63;
+                    const float Na = dpp_shr1(Snew, 0.f); // S[l-1, q+1]
+                    const float R = (Na + Sc) - (Nb + Sb);
+                    Sc = Sb;
+                    Sb = Snew;
+                    Nb = Na;
+                    const int gi = gsoff + k2 * GS_STRIDE;
+                    const float rg = R * Gs_all[gi];
+                    // each slot is passed two or three times (sigma+2 = m+n, m+n+64, ...); only the pass
+                    // whose column n = sigma+2-lane is real may replace G by R*G
+                    if (SYM && !(a.dbg & 1) && (unsigned)(sigma + 2 - lane) < 64u) Gs_all[gi] = rg;
+                    const float *yr = yf + (yfrow + k2) * DPAD;
+                    s0 += rg;
+#pragma unroll
+                    for (int c = 0; c < DPAD; ++c) acc[c] = __builtin_fmaf(rg, yr[c], acc[c]);
+                    // pin the running sums here: the contraction must stay inside its step
+#pragma unroll
+                    for (int c = 0; c < DPAD; ++c) asm volatile("" : "+v"(acc[c]));
+                    asm volatile("" : "+v"(s0));
+                };
+
+                for (int rnd = 1; rnd >= 0; --rnd) {
+                    if (rnd * 64 > smax) continue;
+                    asm volatile("" : "+v"(yfrow), "+v"(gsoff)); // loads below are not round-invariant
+#pragma unroll
+                    for (int kk = 0; kk < 64; ++kk) {
+                        const int k = 63 - kk;
+                        const int sigma = rnd * 64 + k;
+                        const bool act = rowD && (unsigned)(sigma - lane) < (unsigned)P;
+                        const double down = dpp_shl1(cur, 1.0);
+                        float g = Dsl[k];
+                        asm volatile("" : "+v"(g));
+                        const float b = g * g * (1.0f / 12.0f);
+                        const float aa = __builtin_fmaf(g, 0.5f, b);
+                        const double t = cur + down;
+                        double u = t - ddiag;
+                        u = __builtin_fma(t, (double)aa, u);
+                        const double nw = __builtin_fma(ddiag, (double)b, u);
+                        float Snew = 0.f;
+                        if (act) {
+                            Snew = Ksl[k] * (float)ddiag; // K[l,q] * U[l+1,q+1]
+                            cur = nw;
+                            ddiag = down;
+                        }
+                        grad_part(sigma, Snew);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                grad_part(-1, 0.f);
+                grad_part(-2, 0.f);
+
+                // row-side gradient of this pair: -(2/h) * sum_n R G (x~_m - y~_n)
+                float w_ij = 1.f, w_ji = 1.f;
+                if (a.go) {
+                    w_ij = (float)load_any(a.go, (size_t)i * a.B + j, io64);
+                    if (SYM || a.symw) w_ji = (float)load_any(a.go, (size_t)j * a.B + i, io64);
+                    if (a.symw) { w_ij += w_ji; w_ji = w_ij; }
+                } else if (a.symw) {
+                    w_ij = 2.f; w_ji = 2.f;
+                }
+#pragma unroll
+                for (int c = 0; c < DPAD; ++c) {
+                    const float xc = (lane < T && c < d) ? (float)(xraw[c] - yref[c]) : 0.f; // x~ again (not kept live)
+                    gacc[c] += (double)(w_ij * m2h * (xc * s0 - acc[c]));
+                }
+
+                if (SYM && j != i && !(a.dbg & 2)) {
+                    // ---- column-side contraction: lane n sums over rows m (transposed LDS read) ----
+                    float t0 = 0.f, tacc[DPAD];
+#pragma unroll
+                    for (int c = 0; c < DPAD; ++c) tacc[c] = 0.f;
+                    for (int m = 0; m <= P; ++m) {
+                        const int slot = (m + lane) & 63;
+                        const float rg = Gs[slot * GS_STRIDE + m];
+                        const float *xr = xf + m * DPAD;
+                        t0 += rg;
+#pragma unroll
+                        for (int c = 0; c < DPAD; ++c) tacc[c] = __builtin_fmaf(rg, xr[c], tacc[c]);
+                    }
+                    const float *yr = yf + lane * DPAD;
+#pragma unroll
+                    for (int c = 0; c < DPAD; ++c) ypts[c] = (lane <= P) ? w_ji * m2h * (yr[c] * t0 - tacc[c]) : 0.f;
+                }
+            }
+
+        }
+
+        if (GRAD && SYM) {
+            // park the column-side result in this wave's own G region ([lane][c]) for the block sum
+#pragma unroll
+            for (int c = 0; c < DPAD; ++c) Gs[lane * DPAD + c] = ypts[c];
+        }
+        __syncthreads(); // every wave is done with y_j (and has parked its column-side result)
+        if (GRAD && SYM) {
+            for (int e = tid; e < 64 * DPAD; e += NT) {
+                const int n = e / DPAD, c = e % DPAD;
+                double s = 0.0;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) s += (double)Gs_all[w * GS_WAVE + e];
+                if (n < T && c < d && s != 0.0 && !(a.dbg & 4)) unsafeAtomicAdd(&a.gacc[((size_t)j * T + n) * d + c], s);
+            }
+        }
+        if (j + 1 < j1) stage_store();
+        __syncthreads();
+    }
+
+    if (GRAD && row_ok && lane < T) {
+#pragma unroll
+        for (int c = 0; c < DPAD; ++c)
+            if (c < d) unsafeAtomicAdd(&a.gacc[((size_t)i * T + lane) * d + c], gacc[c]);
+    }
+}
+
+template <typename IO>
+__global__ void finalize_grad_kernel(const double *gacc, IO *gradX, size_t n)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < n) gradX[idx] = (IO)gacc[idx];
+}
+
+// ---- host side ---------------------------------------------------------------------------------
+bool fast_supported(int A, int B, int T, int d, int n, int kind, unsigned flags)
+{
+    (void)A; (void)B;
+    if (n != 0 || T < 3 || T > 64 || d > 16) return false;
+    if (kind != SIGSVGD_STATIC_RBF) return false;
+    if (flags & SIGSVGD_FLAG_NAIVE_SOLVER) return false;
+    return true;
+}
+
+int fast_workspace_bytes(int A, int B, int T, int d, int want_grad, unsigned flags, size_t *bytes)
+{
+    (void)B; (void)flags;
+    *bytes = want_grad ? (size_t)A * T * d * sizeof(double) + 256 : 0;
+    return SIGSVGD_OK;
+}
+
+namespace {
+template <int DPAD, int NW>
+int launch_variant(const GramProblem &p, FastArgs &a, bool grad, bool sym)
+{
+    const int ntile = (p.A + NW - 1) / NW;
+    // column chunk: as long as possible (amortises the per-tile flush) while still >= ~2 waves of
+    // workgroups over the 256 CUs
+    int JC = 16;
+    auto nblocks = [&](int jc) {
+        long long nb = (long long)ntile * ((p.B + jc - 1) / jc);
+        return sym ? nb / 2 + ntile : nb;
+    };
+    while (JC > 1 && nblocks(JC) < 1024) JC >>= 1;
+    a.JC = JC;
+    const int owned = (ntile - a.tile_offset + a.tile_stride - 1) / a.tile_stride;
+    if (owned <= 0) return SIGSVGD_OK;
+    dim3 grid((p.B + JC - 1) / JC, owned);
+    if (sym) { // 1-D grid over the chunks on or right of the diagonal of each owned row tile
+        const int nJ = (p.B + JC - 1) / JC;
+        long long total = 0;
+        for (int k = 0; k < owned; ++k) total += nJ - ((k * a.tile_stride + a.tile_offset) * NW) / JC;
+        grid = dim3((unsigned)total, 1);
+    }
+    dim3 block(NW * 64);
+    if (!grad)
+        hipLaunchKernelGGL((gram_fast_kernel<DPAD, NW, false, false>), grid, block, 0, p.stream, a);
+    else if (sym)
+        hipLaunchKernelGGL((gram_fast_kernel<DPAD, NW, true, true>), grid, block, 0, p.stream, a);
+    else
+        hipLaunchKernelGGL((gram_fast_kernel<DPAD, NW, true, false>), grid, block, 0, p.stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "launch gram_fast_kernel");
+    return SIGSVGD_OK;
+}
+} // namespace
+
+int fast_launch(const GramProblem &p)
+{
+    const bool grad = p.gradX_out != nullptr;
+    const bool sym = grad && (p.flags & SIGSVGD_FLAG_Y_IS_X) && p.A == p.B;
+    FastArgs a;
+    a.X = p.X; a.Y = p.Y; a.go = p.grad_out; a.K = p.K_out;
+    a.io64 = p.dtype == SIGSVGD_F64; a.A = p.A; a.B = p.B; a.T = p.T; a.d = p.d;
+    a.symw = (p.flags & SIGSVGD_FLAG_SYM) ? 1 : 0; a.inv_h = p.inv_h; a.JC = 1;
+    a.tile_offset = 0; a.tile_stride = 1;
+    a.dbg = getenv("SIGSVGD_DBG") ? atoi(getenv("SIGSVGD_DBG")) : 0;
+    a.gacc = nullptr;
+    if (a.symw && p.A != p.B) {
+        set_error("sym backward needs A == B");
+        return SIGSVGD_E_BADARG;
+    }
+    const size_t nacc = (size_t)p.A * p.T * p.d;
+    if (grad) {
+        const size_t need = nacc * sizeof(double) + 256;
+        if (!p.ws || p.ws_bytes < need) {
+            set_error("fast: workspace %zu B < required %zu B", p.ws_bytes, need);
+            return SIGSVGD_E_WORKSPACE;
+        }
+        a.gacc = reinterpret_cast<double *>((reinterpret_cast<uintptr_t>(p.ws) + 255) & ~(uintptr_t)255);
+        hipError_t e = hipMemsetAsync(a.gacc, 0, nacc * sizeof(double), p.stream);
+        if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(gacc)");
+    }
+    int rc;
+    if (p.d <= 4)
+        rc = launch_variant<4, 8>(p, a, grad, sym);
+    else if (p.d <= 8)
+        rc = launch_variant<8, 8>(p, a, grad, sym);
+    else
+        rc = launch_variant<16, 4>(p, a, grad, sym); // 1 wave per SIMD: 512-VGPR budget, no spills
+    if (rc) return rc;
+    if (grad) {
+        const int bs = 256;
+        const unsigned gs = (unsigned)((nacc + bs - 1) / bs);
+        if (p.dtype == SIGSVGD_F64)
+            hipLaunchKernelGGL(finalize_grad_kernel<double>, dim3(gs), dim3(bs), 0, p.stream, a.gacc,
+                               static_cast<double *>(p.gradX_out), nacc);
+        else
+            hipLaunchKernelGGL(finalize_grad_kernel<float>, dim3(gs), dim3(bs), 0, p.stream, a.gacc,
+                               static_cast<float *>(p.gradX_out), nacc);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return hip_fail(e, "launch finalize_grad_kernel");
+    }
+    return SIGSVGD_OK;
+}
+
+// Symmetric partial solve for particle sharding: this launch owns the row tiles
+// tile_offset + k*tile_stride of the upper triangle of Gram(X, X) and ACCUMULATES into caller-zeroed
+// buffers: K_partial[N,N] (both orientations of every owned pair) and grad_partial[N,T,d] (fp64).
+int fast_sym_partial(const GramProblem &p, int tile_offset, int tile_stride, double *grad_partial)
+{
+    if (!fast_supported(p.A, p.B, p.T, p.d, p.n, p.kind, p.flags) || p.A != p.B) {
+        set_error("sym_partial: shape/kernel outside the register-resident path (need n=0, 3<=T<=64, d<=16, RBF)");
+        return SIGSVGD_E_UNSUPPORTED;
+    }
+    if (tile_stride < 1 || tile_offset < 0 || tile_offset >= tile_stride) {
+        set_error("sym_partial: bad tile_offset/stride %d/%d", tile_offset, tile_stride);
+        return SIGSVGD_E_BADARG;
+    }
+    FastArgs a;
+    a.X = p.X; a.Y = p.X; a.go = p.grad_out; a.K = p.K_out;
+    a.io64 = p.dtype == SIGSVGD_F64; a.A = p.A; a.B = p.B; a.T = p.T; a.d = p.d;
+    a.symw = (p.flags & SIGSVGD_FLAG_SYM) ? 1 : 0; a.inv_h = p.inv_h; a.JC = 1;
+    a.tile_offset = tile_offset; a.tile_stride = tile_stride; a.dbg = 0;
+    a.gacc = grad_partial;
+    if (p.d <= 4) return launch_variant<4, 8>(p, a, true, true);
+    if (p.d <= 8) return launch_variant<8, 8>(p, a, true, true);
+    return launch_variant<16, 4>(p, a, true, true);
+}
+
+} // namespace sigsvgd

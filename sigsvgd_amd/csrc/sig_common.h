@@ -99,5 +99,6 @@ int generic_launch(const GramProblem &p);
 bool fast_supported(int A, int B, int T, int d, int n, int kind, unsigned flags);
 int fast_workspace_bytes(int A, int B, int T, int d, int want_grad, unsigned flags, size_t *bytes);
 int fast_launch(const GramProblem &p);
+int fast_sym_partial(const GramProblem &p, int tile_offset, int tile_stride, double *grad_partial);
 
 } // namespace sigsvgd

@@ -175,3 +175,26 @@ def svgd_phi(K, score, grad_k, mask=None, X=None, lr: Optional[float] = None):
     if X is not None:
         return v, Xn.reshape(X.shape)
     return v
+
+
+def gram_sym_partial(X, inv_h: float, tile_offset: int, tile_stride: int, static_kind: int = _lib.STATIC_RBF,
+                     grad_out: Optional[torch.Tensor] = None, sym: bool = False):
+    """This rank's share of the symmetric Gram + gradient on the gathered particles X [N,T,d]:
+    returns (K_partial [N,N] X.dtype, grad_partial [N,T,d] fp64), zero outside the owned pairs.
+    Summed over tile_offset = 0..tile_stride-1 they equal gram_fwd_bwd(X, X, y_is_x=True)."""
+    L = _lib.load()
+    dev = _require_gpu(X, grad_out)
+    Xc, _ = _prep_paths(X, X)
+    N, T, d = Xc.shape
+    go = None
+    if grad_out is not None:
+        go = grad_out.detach().to(Xc.dtype).contiguous()
+    Kp = torch.zeros((N, N), dtype=Xc.dtype, device=dev)
+    gp = torch.zeros((N, T, d), dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        rc = L.sigsvgd_gram_sym_partial(Xc.data_ptr(), N, T, d, _io_dtype(Xc), float(inv_h), int(static_kind),
+                                        _flags(False, sym, True, False), int(tile_offset), int(tile_stride),
+                                        go.data_ptr() if go is not None else None, Kp.data_ptr(), gp.data_ptr(),
+                                        _stream_ptr(dev))
+    _lib.check(rc, "gram_sym_partial")
+    return Kp, gp
