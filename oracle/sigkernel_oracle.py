@@ -73,7 +73,9 @@ def bw_median(sq_dists: np.ndarray, bw_scale: float = 1.0, tol: float = 1e-8) ->
     """reference src/utils/math.py:28-34 (torch.median = LOWER median of the flattened tensor)."""
     flat = np.sort(np.asarray(sq_dists, dtype=np.float64).ravel())
     med = flat[(flat.size - 1) // 2]
-    h = med / np.log(sq_dists.shape[0] + 1.0)
+    # the reference takes the log of a float32 0-dim tensor (torch.tensor(rows + 1.0).log()), so the
+    # divisor carries float32 rounding; reproduce it
+    h = med / np.float64(np.log(np.float32(sq_dists.shape[0] + 1.0), dtype=np.float32))
     h = bw_scale * np.sqrt(h)
     return float(max(h, tol))
 

@@ -1,0 +1,84 @@
+"""CPU tests of the C-ABI shared library: it loads, exports every symbol include/*.h declares, and its
+host-side argument checking / workspace queries work without a GPU (no compute calls here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    names = []
+    inc = os.path.join(ROOT, "include")
+    for fn in os.listdir(inc):
+        if fn.endswith(".h"):
+            txt = open(os.path.join(inc, fn)).read()
+            txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+            names += re.findall(r"\b(sigsvgd_[a-z_0-9]+)\s*\(", txt)
+    return sorted(set(names))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from sigsvgd_amd import _lib
+
+    if _lib.needs_build():
+        _lib.build()
+    return _lib.load()
+
+
+def test_every_declared_symbol_is_exported(lib):
+    from sigsvgd_amd import _lib
+
+    declared = _declared_functions()
+    assert len(declared) >= 7
+    assert sorted(_lib.EXPORTS) == declared  # the Python binding covers exactly the header
+    for name in declared:
+        assert getattr(lib, name) is not None
+
+
+def test_abi_version(lib):
+    from sigsvgd_amd import _lib
+
+    assert lib.sigsvgd_abi_version() == _lib.ABI_VERSION
+
+
+def test_workspace_query_is_host_only(lib):
+    n = ctypes.c_size_t(123)
+    # fast path (n=0, T<=64): fp64 accumulation buffer A*T*d*8 (+ alignment slack)
+    assert lib.sigsvgd_gram_workspace_bytes(1024, 1024, 64, 7, 0, 1, 0, ctypes.byref(n)) == 0
+    assert 1024 * 64 * 7 * 8 <= n.value <= 1024 * 64 * 7 * 8 + 4096
+    assert lib.sigsvgd_gram_workspace_bytes(1024, 1024, 64, 7, 0, 0, 0, ctypes.byref(n)) == 0 and n.value == 0
+    # generic path (dyadic refinement): partial slabs + per-workgroup forward-solution scratch
+    assert lib.sigsvgd_gram_workspace_bytes(16, 16, 20, 2, 2, 1, 0, ctypes.byref(n)) == 0 and n.value > 0
+    # does not fit in LDS -> UNSUPPORTED with a message
+    assert lib.sigsvgd_gram_workspace_bytes(4, 4, 400, 3, 0, 1, 0, ctypes.byref(n)) == -2
+    assert b"LDS" in lib.sigsvgd_last_error()
+    assert lib.sigsvgd_gram_workspace_bytes(4, 4, 10, 3, 0, 1, 0, None) == -1
+
+
+def test_argument_errors_are_status_codes(lib):
+    """bad arguments are rejected on the host before anything is launched"""
+    one = ctypes.c_void_p(16)  # never dereferenced: the checks below fail first
+    rc = lib.sigsvgd_gram_fwd(None, one, 2, 2, 5, 2, 0, 1.0, 0, 0, 0, one, None, 0, None)
+    assert rc == -1 and b"null" in lib.sigsvgd_last_error()
+    rc = lib.sigsvgd_gram_fwd(one, one, 2, 2, 1, 2, 0, 1.0, 0, 0, 0, one, None, 0, None)
+    assert rc == -1  # T < 2
+    rc = lib.sigsvgd_gram_fwd(one, one, 2, 2, 5, 2, 7, 1.0, 0, 0, 0, one, None, 0, None)
+    assert rc == -1 and b"dtype" in lib.sigsvgd_last_error()
+    rc = lib.sigsvgd_gram_fwd(one, one, 2, 2, 5, 2, 0, -1.0, 0, 0, 0, one, None, 0, None)
+    assert rc == -1 and b"inv_h" in lib.sigsvgd_last_error()
+    rc = lib.sigsvgd_gram_fwd_bwd(one, one, 2, 2, 5, 2, 0, 1.0, 0, 0, 0, None, one, None, None, 0, None)
+    assert rc == -1 and b"gradX_out" in lib.sigsvgd_last_error()
+    rc = lib.sigsvgd_gram_fwd_bwd(one, one, 2, 3, 5, 2, 0, 1.0, 0, 0, 4, None, one, one, None, 0, None)
+    assert rc == -1  # Y_IS_X with A != B
+    rc = lib.sigsvgd_gram_fwd_bwd(one, one, 2, 2, 5, 2, 0, 1.0, 0, 0, 0, None, one, one, None, 0, None)
+    assert rc == -3 and b"workspace" in lib.sigsvgd_last_error()  # workspace missing
+    rc = lib.sigsvgd_gram_sym_partial(one, 4, 5, 2, 0, 1.0, 0, 0, 2, 2, None, one, one, None)
+    assert rc == -1  # tile_offset >= tile_stride
+    rc = lib.sigsvgd_gram_sym_partial(one, 4, 100, 2, 0, 1.0, 0, 0, 0, 1, None, one, one, None)
+    assert rc == -2  # T > 64 is outside the register-resident path
+    rc = lib.sigsvgd_svgd_phi(None, one, one, None, 4, 4, one, None, None, 0.1, None)
+    assert rc == -1

@@ -1,0 +1,209 @@
+"""GPU tests of the drop-in surface on the real HIP path: the reference-generated fixtures replayed
+through sigsvgd_amd's classes on cuda:0, autograd behaviour of SigKernel.compute_Gram, the sharded
+partial solve, and size-independent properties at the benchmark size."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import golden
+from oracle import sigkernel_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def rel(a, b):
+    a = a.detach().double().cpu().numpy() if hasattr(a, "detach") else np.asarray(a, np.float64)
+    return float(np.abs(a - b).max() / np.abs(b).max())
+
+
+def _cost_fn(x, w):
+    c = w * (x**2).sum((1, 2)) + ((x[:, 1:] - x[:, :-1]) ** 2).sum((1, 2))
+    return c, {"aux": c.detach() * 2}
+
+
+def test_signature_kernel_and_score_estimator_fixtures(gpu):
+    from sigsvgd_amd.inference import ScoreEstimator
+    from sigsvgd_amd.kernels import SignatureKernel
+    from sigsvgd_amd.utils import SquareRootScheduler
+
+    G = golden()
+    sk = SignatureKernel(bandwidth_fn=lambda _: 1.5, depth=2)
+    x = torch.as_tensor(G["c1_X"], device=gpu).requires_grad_(True)
+    K = sk(x, x.detach())
+    assert K.dtype == torch.float32 and K.device == x.device
+    assert rel(K, G["c1_K"].astype(np.float64)) < TOL
+    g = torch.autograd.grad(K.sum(), x)[0]
+    assert rel(g, G["c1_gradk"].astype(np.float64)) < TOL
+    est = ScoreEstimator(sk, _cost_fn, {"w": 0.5}, scheduler=SquareRootScheduler(1.0), ctx={"device": gpu})
+    glp, sd = est.score(x)
+    assert rel(glp, G["c1_score_glp"].astype(np.float64)) < TOL
+    assert rel(sd["k_xx"], G["c1_score_kxx"].astype(np.float64)) < TOL
+    assert rel(sd["grad_k"], G["c1_score_gradk"].astype(np.float64)) < TOL
+    _, sd2 = est.score(x)
+    assert rel(sd2["grad_k"], G["c1_score_gradk_2nd"].astype(np.float64)) < TOL
+
+
+@pytest.mark.parametrize("mode", ["adam", "manual"])
+def test_svgd_optimize_fixture_on_gpu(gpu, mode):
+    """3 SVGD iterations (kernel + gradient + velocity + optimizer) == the reference's loop"""
+    from sigsvgd_amd.inference import SVGD, ScoreEstimator
+    from sigsvgd_amd.kernels import SignatureKernel
+
+    G = golden()
+    sk = SignatureKernel(bandwidth_fn=lambda _: 1.5, depth=2)
+    est = ScoreEstimator(sk, _cost_fn, {"w": 0.5}, ctx={"device": gpu})
+    s = SVGD(sk, optimizer_class=torch.optim.Adam, lr=0.05) if mode == "adam" else SVGD(sk, optimizer_class=None, lr=0.01)
+    Xp = torch.as_tensor(G["c1_X"], device=gpu).clone()
+    data, _ = s.optimize(Xp, est.score, n_steps=3)
+    ref = G[f"c1_opt_{mode}_trace"].astype(np.float64)
+    assert data["trace"].device.type == "cpu" and tuple(data["trace"].shape) == ref.shape
+    assert np.abs(data["trace"].numpy() - ref).max() < 3e-5  # Adam normalises the step: absolute tolerance
+    assert all(v.device.type == "cpu" for v in data[0].values() if hasattr(v, "device"))
+    assert rel(Xp, ref[-1]) < 3e-5
+    # device-resident iter_dict variant
+    s2 = SVGD(sk, optimizer_class=None, lr=0.01, iter_dict_device=None)
+    d2, _ = s2.optimize(torch.as_tensor(G["c1_X"], device=gpu).clone(), est.score, n_steps=1)
+    assert d2[0]["k_xx"].device.type == "cuda"
+
+
+def test_svgd_manual_modes_fixture_on_gpu(gpu):
+    from sigsvgd_amd.inference import SVGD, TrajectorySVGD
+
+    class _Dummy:
+        pass
+
+    G = golden()
+
+    def fake(x):
+        xf = x.detach().flatten(1)
+        diff = xf[:, None, :] - xf[None, :, :]
+        K = torch.exp(-(diff**2).sum(-1) / 2.0)
+        return -x.detach(), {"k_xx": K, "grad_k": (-diff * K[..., None]).sum(1).reshape(x.shape),
+                             "loss": (x.detach() ** 2).sum((1, 2))}
+
+    for mode, kw in [("manual", dict(optimizer_class=None, lr=0.1)),
+                     ("adagrad", dict(optimizer_class=None, adaptive_gradient=True, lr=0.1)),
+                     ("adam", dict(optimizer_class=torch.optim.Adam, lr=0.05))]:
+        Xp = torch.as_tensor(G["svgd_X0"], device=gpu).clone()
+        data, _ = SVGD(_Dummy(), **kw).optimize(Xp, fake, n_steps=4)
+        assert np.abs(data["trace"].numpy() - G[f"svgd_{mode}_trace"]).max() < 2e-5, mode
+    ts = TrajectorySVGD(_Dummy(), gradient_mask=torch.as_tensor(G["tsvgd_mask"], device=gpu), optimizer_class=None, lr=0.1)
+    v, _ = ts._velocity(torch.as_tensor(G["svgd_X0"], device=gpu), torch.as_tensor(G["svgd_step_in_score"], device=gpu),
+                        k_xx=torch.as_tensor(G["svgd_step_in_K"], device=gpu), grad_k=torch.as_tensor(G["svgd_step_in_gk"], device=gpu))
+    assert rel(v, G["tsvgd_velocity"].astype(np.float64)) < TOL
+
+
+def test_trajectory_svgd_sigkernel_branch_on_gpu(gpu):
+    """fp64 upcast / chained autograd through a rollout graph, as DuSt drives it"""
+    from sigsvgd_amd.inference import TrajectorySVGD
+    from sigsvgd_amd.sigkernel import RBFKernel, SigKernel
+
+    G = golden()
+    actions = torch.as_tensor(G["traj_actions"], device=gpu).clone().requires_grad_(True)
+    Np, hz = actions.shape[0], actions.shape[1]
+    pos = torch.cumsum(actions, dim=1)
+    traj = torch.cat([torch.zeros(Np, 1, 4, device=gpu), torch.cat([pos, actions], dim=-1)], dim=1)
+    sigk = SigKernel(RBFKernel(sigma=(2 + hz) ** 0.5), dyadic_order=1)
+    ts = TrajectorySVGD(sigk, gradient_mask=torch.ones(Np, hz, 2, device=gpu), optimizer_class=None, lr=0.1)
+    kxx, gk = ts._compute_kernel(actions, trajectories=traj, actions=actions, sample_shape=None)
+    assert rel(kxx, G["traj_kxx"].astype(np.float64)) < TOL and rel(gk, G["traj_gradk"].astype(np.float64)) < TOL
+    # the reference's own call pattern: fp64 tensors in, fp64 out
+    tau = traj[..., 1:, :2]
+    K64 = sigk.compute_Gram(tau.double(), tau.detach().double(), sym=False)
+    assert K64.dtype == torch.float64 and rel(K64, G["traj_kxx"].astype(np.float64)) < TOL
+
+
+def test_compute_gram_autograd_variants(gpu):
+    from sigsvgd_amd.sigkernel import LinearKernel, RBFKernel, SigKernel
+
+    rng = np.random.default_rng(0)
+    Xn = np.cumsum(0.1 * rng.standard_normal((9, 30, 3)), axis=1).astype(np.float32)
+    Yn = np.cumsum(0.1 * rng.standard_normal((7, 30, 3)), axis=1).astype(np.float32)
+    for kern, kind, n in [(RBFKernel(0.8), O.RBF, 0), (RBFKernel(0.8), O.RBF, 2), (LinearKernel(), O.LINEAR, 1)]:
+        sk = SigKernel(kern, n)
+        x = torch.as_tensor(Xn, device=gpu).requires_grad_(True)
+        y = torch.as_tensor(Yn, device=gpu)
+        K = sk.compute_Gram(x, y)
+        Kref, gref = O.gram_backward(Xn, Yn, None, kind, 0.8, n)
+        assert rel(K, Kref) < TOL
+        (3.0 * K).sum().backward()  # uniform weights: scaled speculative gradient
+        assert rel(x.grad, 3.0 * gref) < TOL
+        x.grad = None
+        w = torch.as_tensor(rng.standard_normal((9, 7)).astype(np.float32), device=gpu)
+        K = sk.compute_Gram(x, y)
+        (K * w).sum().backward()  # general weights: second fused launch
+        assert rel(x.grad, O.gram_backward(Xn, Yn, w.cpu().numpy().astype(np.float64), kind, 0.8, n)[1]) < TOL
+    # sym=True (never used by the reference): go + go^T weighting
+    sk = SigKernel(RBFKernel(0.8), 0)
+    x = torch.as_tensor(Xn, device=gpu).requires_grad_(True)
+    K = sk.compute_Gram(x, x.detach(), sym=True)
+    w = torch.as_tensor(rng.standard_normal((9, 9)).astype(np.float32), device=gpu)
+    (K * w).sum().backward()
+    assert rel(x.grad, O.gram_backward(Xn, Xn, w.cpu().numpy().astype(np.float64), O.RBF, 0.8, 0, False, True)[1]) < TOL
+    # naive solver + gradient
+    skn = SigKernel(RBFKernel(0.8), 1, _naive_solver=True)
+    x = torch.as_tensor(Xn, device=gpu).requires_grad_(True)
+    skn.compute_Gram(x, y).sum().backward()
+    assert rel(x.grad, O.gram_backward(Xn, Yn, None, O.RBF, 0.8, 1, True)[1]) < TOL
+
+
+def test_default_median_bandwidth_on_gpu(gpu):
+    """bandwidth_fn=None -> bw_median of the full distance tensor, as examples/script_planning_robot.py gets"""
+    from sigsvgd_amd.kernels import SignatureKernel
+
+    X = np.cumsum(0.3 * np.random.default_rng(1).standard_normal((6, 3, 7)), axis=1).astype(np.float32)
+    h = O.bw_median(O.pairwise_sqdist(X, X))
+    K = SignatureKernel(depth=3)(torch.as_tensor(X, device=gpu), torch.as_tensor(X, device=gpu))
+    assert rel(K, O.gram(X, X, O.RBF, h, 3)) < TOL
+
+
+@pytest.mark.parametrize("N,T,d,stride", [(24, 64, 7, 2), (40, 32, 3, 3), (20, 20, 14, 4)])
+def test_sym_partials_sum_to_full(gpu, N, T, d, stride):
+    """multi-GPU building block on one GPU: the per-rank partial solves add up to the full result"""
+    from sigsvgd_amd import ops
+
+    X, s = O.synthetic_inputs(N, T, d)
+    Xg = X.to(gpu)
+    K, g = ops.gram_fwd_bwd(Xg, Xg, 1.0, y_is_x=True)
+    parts = [ops.gram_sym_partial(Xg, 1.0, off, stride) for off in range(stride)]
+    Ksum = sum(p[0] for p in parts)
+    gsum = sum(p[1] for p in parts)
+    assert torch.equal(Ksum, K)  # disjoint supports: bitwise
+    assert rel(gsum, g.double().cpu().numpy()) < 1e-6
+    nz = sum((p[0] != 0).sum().item() for p in parts)
+    assert nz == N * N  # every entry owned exactly once (K > 0 everywhere)
+    Kref, gref = O.gram_backward(X.numpy(), X.numpy(), None, O.RBF, 1.0, 0)
+    assert rel(Ksum, Kref) < TOL and rel(gsum, gref) < TOL
+
+
+def test_properties_at_benchmark_size(gpu):
+    """size-independent checks at N=1024, T=64, d=7 (the oracle covers row samples in test_gpu_fast)"""
+    from sigsvgd_amd import ops
+
+    X, score = O.synthetic_inputs(1024, 64, 7)
+    Xg, sg = X.to(gpu), score.to(gpu)
+    K, g = ops.gram_fwd_bwd(Xg, Xg, 1.0, y_is_x=True)
+    # (a) symmetric solve == ordered solve == forward-only solve
+    K2, g2 = ops.gram_fwd_bwd(Xg, Xg, 1.0)
+    K3 = ops.gram_fwd(Xg, Xg, 1.0)
+    assert rel(K2, K.double().cpu().numpy()) < 1e-6 and torch.equal(K2, K3)
+    assert rel(g2, g.double().cpu().numpy()) < TOL
+    # (b) translation invariance of the RBF signature kernel
+    K4, g4 = ops.gram_fwd_bwd(Xg + 3.0, Xg + 3.0, 1.0, y_is_x=True)
+    assert rel(K4, K.double().cpu().numpy()) < TOL and rel(g4, g.double().cpu().numpy()) < TOL
+    # (c) k(x, constant path) = 1 and boundary: two-point constant paths
+    const = Xg[:, :1, :].expand(-1, 64, -1).contiguous()
+    assert float((ops.gram_fwd(Xg[:64], const[:64], 1.0) - 1).abs().max()) < 1e-6
+    # (d) permutation equivariance: K[perm][:, perm], grad[perm]
+    perm = torch.randperm(1024, generator=torch.Generator().manual_seed(0)).to(gpu)
+    Kp, gp = ops.gram_fwd_bwd(Xg[perm].contiguous(), Xg[perm].contiguous(), 1.0, y_is_x=True)
+    assert rel(Kp, K[perm][:, perm].double().cpu().numpy()) < 1e-6
+    assert rel(gp, g[perm].double().cpu().numpy()) < TOL
+    # (e) velocity: linear in (score, grad_k); fused update consistent
+    v, Xn = ops.svgd_phi(K, sg, g, X=Xg, lr=1e-3)
+    v2 = ops.svgd_phi(K, 2 * sg, 2 * g)
+    assert rel(v2, 2 * v.double().cpu().numpy()) < 1e-6
+    assert rel(Xn, (Xg - 1e-3 * v).double().cpu().numpy()) < 1e-6
+    vref = -((K.double() @ sg.double().flatten(1) - g.double().flatten(1)) / 1024).reshape(v.shape)
+    assert rel(v, vref.cpu().numpy()) < TOL
