@@ -6,33 +6,8 @@ from __future__ import annotations
 import torch
 
 from .. import _lib
-from ..sigkernel import SigKernel
+from ..sigkernel import SigKernel, gram_sqdist, inv_bandwidth_from_fn
 from ._kernels import BaseKernel, kernel_output, scalar_function
-
-# refuse to materialise distance tensors larger than this for data-dependent bandwidths
-_MAX_DIST_BYTES = 4 << 30
-
-
-class _ConstantProbe:
-    """Stand-in handed to `bandwidth_fn` first: constant lambdas (`lambda _: 0.03`, the norm in the
-    reference's scripts, e.g. examples/script_planning_obstacle_field.py:321) return without touching
-    it, so the [A,B,T,T] distance tensor never has to exist.  Any use of it raises."""
-
-    class Touched(Exception):
-        pass
-
-    def _touch(self, *a, **k):
-        raise _ConstantProbe.Touched()
-
-    __getattr__ = _touch
-    __add__ = __radd__ = __sub__ = __rsub__ = __mul__ = __rmul__ = __truediv__ = __rtruediv__ = _touch
-    __neg__ = __pow__ = __getitem__ = __len__ = __iter__ = __float__ = __array__ = _touch
-    __lt__ = __le__ = __gt__ = __ge__ = __bool__ = _touch
-
-    @classmethod
-    def __torch_function__(cls, func, types, args=(), kwargs=None):
-        raise _ConstantProbe.Touched()
-
 
 class BatchGaussianKernel(BaseKernel):
     """RBF kernel on path points, k(x, y) = exp(-|x-y|^2 / h), h = bandwidth_fn(dist)."""
@@ -44,15 +19,6 @@ class BatchGaussianKernel(BaseKernel):
 
     def __call__(self, X: torch.Tensor, Y: torch.Tensor, **kwargs) -> kernel_output:
         return self.batch_kernel(X, Y, **kwargs)
-
-    @staticmethod
-    def _gram_dist(X, Y):
-        A, B, M, N = X.shape[0], Y.shape[0], X.shape[1], Y.shape[1]
-        Xs = torch.sum(X**2, dim=2)
-        Ys = torch.sum(Y**2, dim=2)
-        dist = -2.0 * torch.einsum("ipk,jqk->ijpq", X, Y)
-        dist += torch.reshape(Xs, (A, 1, M, 1)) + torch.reshape(Ys, (1, B, 1, N))
-        return dist
 
     def batch_kernel(self, X, Y, h=None):
         """X [batch, len_X, dim], Y [batch, len_Y, dim] -> k(X^i_s, Y^i_t) [batch, len_X, len_Y]."""
@@ -66,27 +32,13 @@ class BatchGaussianKernel(BaseKernel):
 
     def Gram_matrix(self, X, Y, h=None):
         """X [A, len_X, dim], Y [B, len_Y, dim] -> k(X^i_s, Y^j_t) [A, B, len_X, len_Y]."""
-        dist = self._gram_dist(X, Y)
+        dist = gram_sqdist(X, Y)
         h = self.get_bandwidth(dist) if h is None else float(h)
         return torch.exp(-dist / h)
 
     def inv_bandwidth(self, X, Y) -> float:
-        """1/h for the fused HIP path.  Constant bandwidth functions are resolved without forming
-        the distance tensor; data-dependent ones (bw_median default) get the real [A,B,T,T] fp64
-        tensor, exactly what the reference passes (src/kernels/_traj_kernels.py:191-194)."""
-        try:
-            h = self.get_bandwidth(_ConstantProbe())
-            return 1.0 / float(h)
-        except _ConstantProbe.Touched:
-            pass
-        nbytes = X.shape[0] * Y.shape[0] * X.shape[1] * Y.shape[1] * 8
-        if nbytes > _MAX_DIST_BYTES:
-            raise RuntimeError(
-                f"data-dependent bandwidth needs the full distance tensor ({nbytes / 2**30:.1f} GiB here); "
-                "pass a constant bandwidth_fn (e.g. lambda _: h) for batches this large"
-            )
-        dist = self._gram_dist(X.detach().double(), Y.detach().double())
-        return 1.0 / float(self.get_bandwidth(dist))
+        """1/h for the fused HIP path (constant bandwidth functions never form the distance tensor)."""
+        return inv_bandwidth_from_fn(self.get_bandwidth, X, Y)
 
 
 class SignatureKernel:

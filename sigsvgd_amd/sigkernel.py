@@ -69,12 +69,68 @@ class RBFKernel:
         return torch.exp(-dist / self.sigma)
 
 
+# refuse to materialise distance tensors larger than this for data-dependent bandwidths
+_MAX_DIST_BYTES = 4 << 30
+
+
+class _ConstantProbe:
+    """Stand-in handed to a `bandwidth_fn` first: constant lambdas (`lambda _: 0.03`, the norm in the
+    reference's scripts, e.g. examples/script_planning_obstacle_field.py:321) return without touching
+    it, so the [A,B,T,T] distance tensor never has to exist.  Any use of it raises."""
+
+    class Touched(Exception):
+        pass
+
+    def _touch(self, *a, **k):
+        raise _ConstantProbe.Touched()
+
+    __getattr__ = _touch
+    __add__ = __radd__ = __sub__ = __rsub__ = __mul__ = __rmul__ = __truediv__ = __rtruediv__ = _touch
+    __neg__ = __pow__ = __getitem__ = __len__ = __iter__ = __float__ = __array__ = _touch
+    __lt__ = __le__ = __gt__ = __ge__ = __bool__ = _touch
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        raise _ConstantProbe.Touched()
+
+
+def gram_sqdist(X, Y):
+    """dist[i,j,p,q] = |X_ip|^2 + |Y_jq|^2 - 2<X_ip,Y_jq> (reference _traj_kernels.py:186-190)."""
+    A, B, M, N = X.shape[0], Y.shape[0], X.shape[1], Y.shape[1]
+    Xs = torch.sum(X**2, dim=2)
+    Ys = torch.sum(Y**2, dim=2)
+    dist = -2.0 * torch.einsum("ipk,jqk->ijpq", X, Y)
+    dist += torch.reshape(Xs, (A, 1, M, 1)) + torch.reshape(Ys, (1, B, 1, N))
+    return dist
+
+
+def inv_bandwidth_from_fn(get_bandwidth, X, Y) -> float:
+    """1/h for the fused HIP path from a reference-style bandwidth function.  Constant functions are
+    resolved without forming the distance tensor; data-dependent ones (the bw_median default) get the
+    real [A,B,T,T] fp64 tensor, exactly what the reference passes (_traj_kernels.py:191-194)."""
+    try:
+        return 1.0 / float(get_bandwidth(_ConstantProbe()))
+    except _ConstantProbe.Touched:
+        pass
+    nbytes = X.shape[0] * Y.shape[0] * X.shape[1] * Y.shape[1] * 8
+    if nbytes > _MAX_DIST_BYTES:
+        raise RuntimeError(
+            f"data-dependent bandwidth needs the full distance tensor ({nbytes / 2**30:.1f} GiB here); "
+            "pass a constant bandwidth_fn (e.g. lambda _: h) for batches this large"
+        )
+    return 1.0 / float(get_bandwidth(gram_sqdist(X.detach().double(), Y.detach().double())))
+
+
 def _resolve_static(static_kernel, X, Y):
-    """-> (static_kind, inv_h).  Accepts this module's kernels and anything exposing the same two
-    members (e.g. sigsvgd_amd.kernels.BatchGaussianKernel).  Arbitrary user static kernels would
-    need their own device code and are rejected (no silent slow path)."""
+    """-> (static_kind, inv_h).  Accepts this module's kernels, anything exposing `static_kind` +
+    `inv_bandwidth` (sigsvgd_amd.kernels.BatchGaussianKernel) and the REFERENCE's own unpatched
+    `BatchGaussianKernel` (recognised by `get_bandwidth` + `Gram_matrix`; it is an RBF with
+    exp(-dist/h), src/kernels/_traj_kernels.py:176-195).  Arbitrary user static kernels would need
+    their own device code and are rejected (no silent slow path)."""
     if hasattr(static_kernel, "static_kind") and hasattr(static_kernel, "inv_bandwidth"):
         return int(static_kernel.static_kind), float(static_kernel.inv_bandwidth(X, Y))
+    if type(static_kernel).__name__ == "BatchGaussianKernel" and hasattr(static_kernel, "get_bandwidth"):
+        return _lib.STATIC_RBF, inv_bandwidth_from_fn(static_kernel.get_bandwidth, X, Y)
     raise NotImplementedError(
         f"static kernel {type(static_kernel).__name__} is not supported by the HIP path "
         "(supported: RBFKernel, LinearKernel, BatchGaussianKernel)"
