@@ -24,8 +24,6 @@
 //
 // Reference semantics: sigkernel _SigKernelGram.forward/backward [RECALLED, SURVEY.md App. A];
 // static kernel src/kernels/_traj_kernels.py:176-195; callers src/inference/score.py:68-69.
-#include <cstdlib>
-
 #include "sig_common.h"
 
 namespace sigsvgd {
@@ -35,7 +33,6 @@ struct FastArgs {
     void *K;
     double *gacc; // [A][T][d] fp64 accumulation buffer (zeroed by the launcher)
     int io64, A, B, T, d, JC, symw;
-    int dbg; // TEMP timing experiments
     int tile_offset, tile_stride; // row tiles owned by this launch: offset + k*stride (multi-GPU sharding)
     double inv_h;
 };
@@ -51,28 +48,35 @@ __device__ __forceinline__ int dpp_shl1_i(int v, int bound)
 {
     return __builtin_amdgcn_update_dpp(bound, v, 0x130, 0xF, 0xF, false);
 }
-__device__ __forceinline__ double dpp_shr1(double v, double bound)
+// bound_ctrl = 1 forms: a lane without a source gets 0 and no `old` register has to be initialised.
+__device__ __forceinline__ int dpp_shr1_z(int v) { return __builtin_amdgcn_mov_dpp(v, 0x138, 0xF, 0xF, true); }
+__device__ __forceinline__ int dpp_shl1_z(int v) { return __builtin_amdgcn_mov_dpp(v, 0x130, 0xF, 0xF, true); }
+// shifts carrying the PDE boundary value 1.0 = {hi 0x3FF00000, lo 0}: only the high word needs `old`
+__device__ __forceinline__ double dpp_shr1_one(double v)
 {
-    const int lo = dpp_shr1_i(__double2loint(v), __double2loint(bound));
-    const int hi = dpp_shr1_i(__double2hiint(v), __double2hiint(bound));
+    const int lo = dpp_shr1_z(__double2loint(v));
+    const int hi = dpp_shr1_i(__double2hiint(v), 0x3FF00000);
     return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double dpp_shl1(double v, double bound)
+__device__ __forceinline__ double dpp_shl1_one(double v)
 {
-    const int lo = dpp_shl1_i(__double2loint(v), __double2loint(bound));
-    const int hi = dpp_shl1_i(__double2hiint(v), __double2hiint(bound));
+    const int lo = dpp_shl1_z(__double2loint(v));
+    const int hi = dpp_shl1_i(__double2hiint(v), 0x3FF00000);
     return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ float dpp_shr1(float v, float bound)
+__device__ __forceinline__ double dpp_shl1_zero(double v)
 {
-    return __int_as_float(dpp_shr1_i(__float_as_int(v), __float_as_int(bound)));
+    return __hiloint2double(dpp_shl1_z(__double2hiint(v)), dpp_shl1_z(__double2loint(v)));
 }
+__device__ __forceinline__ float dpp_shr1_zero(float v) { return __int_as_float(dpp_shr1_z(__float_as_int(v))); }
 
 // [slot][lane] image of G (then R*G) with row stride 65 floats: every in-sweep access is
 // lane*4 + constant (one ds instruction with an immediate offset, nothing to keep in registers),
 // and the transposed read of the symmetric pass ((m+n)&63)*65 + m hits 32 distinct banks.
 constexpr int GS_STRIDE = 65;
 constexpr int GS_WAVE = 64 * GS_STRIDE;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+
 __device__ __forceinline__ int gs_index(int slot, int lane) { return slot * GS_STRIDE + lane; }
 
 template <typename IO>
@@ -98,12 +102,17 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
     constexpr int NT = NW * 64;
     // y rows are stored twice (row r and r + 64) so that the skewed row (t - lane) & 63 becomes
     // (64 - lane) + t: a per-lane base plus a compile-time offset.
+    // Row strides are padded (YDS doubles / YFS floats) so that the 16 lanes a ds_read_b128 services per
+    // cycle -- consecutive rows, one per lane -- start on 16 distinct 16-byte bank groups: with the
+    // natural 64-B (fp64, d<=8) / 32-B (fp32) rows they alias 4-way / 2-way (measured: 54 % of all LDS
+    // cycles were bank-conflict cycles).
+    constexpr int YDS = DPAD + 2; // doubles per fp64 row: 80 B at DPAD=8 -> 80*l mod 256 distinct for 16 l
+    constexpr int YFS = (DPAD == 4) ? 12 : DPAD + 4; // floats per fp32 row: 48 B at DPAD<=8, 80 B at 16
     __shared__ float Gs_all[GRAD ? NW * GS_WAVE : 1];
-    __shared__ float xf_all[(GRAD && SYM) ? NW * 64 * DPAD : 1];
-    __shared__ __align__(16) double yd[128 * DPAD];
+    __shared__ __align__(16) double yd[128 * YDS];
     __shared__ double ynd[128];
     __shared__ double yref[DPAD];
-    __shared__ __align__(16) float yf[GRAD ? 128 * DPAD : 1];
+    __shared__ __align__(16) float yf[GRAD ? 128 * YFS : 1];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int T = a.T, d = a.d, P = T - 1, io64 = a.io64;
@@ -134,7 +143,6 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
     const bool row_ok = i < a.A;
     const bool rowD = lane < P;
     float *Gs = Gs_all + (GRAD ? wave * GS_WAVE : 0);
-    float *xf = xf_all + ((GRAD && SYM) ? wave * 64 * DPAD : 0);
     const double inv_h = a.inv_h;
     const float m2h = (float)(-2.0 * inv_h);
 
@@ -162,6 +170,7 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
             stage_r[k] = ok ? load_any(a.Y, (size_t)j * T * d + c, io64) : 0.0;
         }
     };
+    const double nscale = -inv_h * 1.4426950408889634074; // exponent scale: exp(-d/h) = 2^(nscale*d)
     auto stage_store = [&]() {
 #pragma unroll
         for (int k = 0; k < EPT; ++k) {
@@ -169,14 +178,14 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
             if (e < 64 * DPAD) {
                 const int t = e / DPAD, c = e % DPAD;
                 const double v = stage_v[k] - stage_r[k];
-                yd[e] = v;
-                yd[e + 64 * DPAD] = v;
+                yd[t * YDS + c] = v;
+                yd[(t + 64) * YDS + c] = v;
                 if (GRAD) {
-                    yf[e] = (float)v;
-                    yf[e + 64 * DPAD] = (float)v;
+                    yf[t * YFS + c] = (float)v;
+                    yf[(t + 64) * YFS + c] = (float)v;
                 }
                 if (t == 0) yref[c] = stage_r[k];
-                double s = v * v; // |y~_t|^2 via xor-reduction over the DPAD lanes of a row
+                double s = v * v * nscale; // -log2(e)/h * |y~_t|^2 via xor-reduction over the DPAD lanes of a row
 #pragma unroll
                 for (int off = 1; off < DPAD; off <<= 1) s += __shfl_xor(s, off, 64);
                 if (c == 0) {
@@ -197,38 +206,35 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
 
         float Dsl[64];
         float Ksl[64];
-        float ypts[DPAD];
-#pragma unroll
-        for (int c = 0; c < DPAD; ++c) ypts[c] = 0.f;
 
         if (pair_ok) {
             // ---- phase 0: centre x_i on y_j[0] ----------------------------------------------------
-            double xt[DPAD];
+            // x~ pre-scaled so that the exponent argument in base 2 is one fused dot product:
+            //   log2(e) * (-|x~ - y~|^2 / h) = xn + ynd[q] + sum_c xs[c] * y~[q][c]
+            double xs[DPAD];
             double xn = 0.0;
 #pragma unroll
             for (int c = 0; c < DPAD; ++c) {
-                xt[c] = (lane < T && c < d) ? xraw[c] - yref[c] : 0.0;
-                xn = __builtin_fma(xt[c], xt[c], xn);
+                const double xc = (lane < T && c < d) ? xraw[c] - yref[c] : 0.0;
+                xn = __builtin_fma(xc, xc, xn);
+                xs[c] = xc * (-2.0 * nscale);
             }
-            if (GRAD && SYM) {
-#pragma unroll
-                for (int c = 0; c < DPAD; ++c) xf[lane * DPAD + c] = (float)xt[c];
-            }
+            xn *= nscale;
 
             // ---- phase 1: G rows (skewed: column (t - lane) & 63 on iteration t) -> D slots --------
             {
                 double g0 = 0.0, g1 = 0.0, gprev = 0.0, rdprev = 0.0;
-                const double *ybase = yd + (64 - lane) * DPAD; // row (t - lane) & 63 == ybase + t*DPAD
+                const double *ybase = yd + (64 - lane) * YDS; // row (t - lane) & 63 == ybase + t*YDS
                 const double *nbase = ynd + (64 - lane);
 #pragma unroll
                 for (int t = 0; t < 66; ++t) {
                     double g;
                     if (t < 64) {
-                        const double *yr = ybase + t * DPAD;
-                        double dot = 0.0;
+                        const double *yr = ybase + t * YDS;
+                        double e2 = xn + nbase[t];
 #pragma unroll
-                        for (int c = 0; c < DPAD; ++c) dot = __builtin_fma(xt[c], yr[c], dot);
-                        g = exp64((2.0 * dot - xn - nbase[t]) * inv_h);
+                        for (int c = 0; c < DPAD; ++c) e2 = __builtin_fma(xs[c], yr[c], e2);
+                        g = exp2_p8(e2);
                         if (GRAD) Gs[gs_index(t, lane)] = (float)g;
                         if (t == 0) g0 = g;
                         if (t == 1) g1 = g;
@@ -239,11 +245,11 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
                     gprev = g;
                     if (t >= 2) {
                         // lane l+1 holds the same column difference one iteration later
-                        const double nb = dpp_shl1(rd, 0.0);
+                        const double nb = dpp_shl1_zero(rd);
                         Dsl[(t - 2) & 63] = (float)(nb - rdprev);
                     }
                     rdprev = rd;
-                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_sched_barrier(0); // one column per scheduling region: bounds live ranges
                 }
             }
 
@@ -257,7 +263,7 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
                     for (int k = 0; k < 64; ++k) {
                         const int sigma = rnd * 64 + k;
                         const bool act = rowD && (unsigned)(sigma - lane) < (unsigned)P;
-                        const double up = dpp_shr1(cur, 1.0);
+                        const double up = dpp_shr1_one(cur);
                         float g = Dsl[k];
                         asm volatile("" : "+v"(g)); // keep the coefficient math inside the round loop (no LICM)
                         const float b = g * g * (1.0f / 12.0f);
@@ -284,16 +290,16 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
                 // ---- phase 3: reverse sweep + lagged R -> row-side contraction ----------------------
                 double cur = 1.0, ddiag = 1.0;
                 float Sb = 0.f, Sc = 0.f, Nb = 0.f, s0 = 0.f;
-                float acc[DPAD];
+                f32x2 acc[DPAD / 2]; // packed pairs: the contraction runs on v_pk_fma_f32
 #pragma unroll
-                for (int c = 0; c < DPAD; ++c) acc[c] = 0.f;
+                for (int c = 0; c < DPAD / 2; ++c) acc[c] = f32x2{0.f, 0.f};
                 const int smax = 2 * P - 2;
 
                 int yfrow = 64 - lane;                          // row (sigma + 2 - lane) & 63 == yfrow + k2
                 int gsoff = (GRAD ? wave * GS_WAVE : 0) + lane; // this wave's [slot][lane] image
                 auto grad_part = [&](int sigma, float Snew) {
                     const int k2 = (sigma + 2) & 63;
-                    const float Na = dpp_shr1(Snew, 0.f); // S[l-1, q+1]
+                    const float Na = dpp_shr1_zero(Snew); // S[l-1, q+1]
                     const float R = (Na + Sc) - (Nb + Sb);
                     Sc = Sb;
                     Sb = Snew;
@@ -302,14 +308,15 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
                     const float rg = R * Gs_all[gi];
                     // each slot is passed two or three times (sigma+2 = m+n, m+n+64, ...); only the pass
                     // whose column n = sigma+2-lane is real may replace G by R*G
-                    if (SYM && !(a.dbg & 1) && (unsigned)(sigma + 2 - lane) < 64u) Gs_all[gi] = rg;
-                    const float *yr = yf + (yfrow + k2) * DPAD;
+                    if (SYM && (unsigned)(sigma + 2 - lane) < 64u) Gs_all[gi] = rg;
+                    const f32x2 *yr = reinterpret_cast<const f32x2 *>(yf + (yfrow + k2) * YFS);
+                    const f32x2 rg2 = {rg, rg};
                     s0 += rg;
 #pragma unroll
-                    for (int c = 0; c < DPAD; ++c) acc[c] = __builtin_fmaf(rg, yr[c], acc[c]);
+                    for (int c = 0; c < DPAD / 2; ++c) acc[c] = __builtin_elementwise_fma(rg2, yr[c], acc[c]);
                     // pin the running sums here: the contraction must stay inside its step
 #pragma unroll
-                    for (int c = 0; c < DPAD; ++c) asm volatile("" : "+v"(acc[c]));
+                    for (int c = 0; c < DPAD / 2; ++c) asm volatile("" : "+v"(acc[c]));
                     asm volatile("" : "+v"(s0));
                 };
 
@@ -321,7 +328,7 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
                         const int k = 63 - kk;
                         const int sigma = rnd * 64 + k;
                         const bool act = rowD && (unsigned)(sigma - lane) < (unsigned)P;
-                        const double down = dpp_shl1(cur, 1.0);
+                        const double down = dpp_shl1_one(cur);
                         float g = Dsl[k];
                         asm volatile("" : "+v"(g));
                         const float b = g * g * (1.0f / 12.0f);
@@ -355,34 +362,49 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
 #pragma unroll
                 for (int c = 0; c < DPAD; ++c) {
                     const float xc = (lane < T && c < d) ? (float)(xraw[c] - yref[c]) : 0.f; // x~ again (not kept live)
-                    gacc[c] += (double)(w_ij * m2h * (xc * s0 - acc[c]));
+                    gacc[c] += (double)(w_ij * m2h * (xc * s0 - acc[c / 2][c % 2]));
                 }
 
-                if (SYM && j != i && !(a.dbg & 2)) {
+                if (SYM && j != i) {
                     // ---- column-side contraction: lane n sums over rows m (transposed LDS read) ----
                     float t0 = 0.f, tacc[DPAD];
+                    float xc32[DPAD]; // this lane's x~ row (fp32); row m is broadcast with v_readlane below
 #pragma unroll
-                    for (int c = 0; c < DPAD; ++c) tacc[c] = 0.f;
-                    for (int m = 0; m <= P; ++m) {
-                        const int slot = (m + lane) & 63;
-                        const float rg = Gs[slot * GS_STRIDE + m];
-                        const float *xr = xf + m * DPAD;
-                        t0 += rg;
-#pragma unroll
-                        for (int c = 0; c < DPAD; ++c) tacc[c] = __builtin_fmaf(rg, xr[c], tacc[c]);
+                    for (int c = 0; c < DPAD; ++c) {
+                        tacc[c] = 0.f;
+                        xc32[c] = (lane < T && c < d) ? (float)(xraw[c] - yref[c]) : 0.f;
                     }
-                    const float *yr = yf + lane * DPAD;
+                    for (int m0 = 0; m0 <= P; m0 += 8) { // 8 rows per trip: 8 LDS reads in flight
+                        float rgv[8];
 #pragma unroll
-                    for (int c = 0; c < DPAD; ++c) ypts[c] = (lane <= P) ? w_ji * m2h * (yr[c] * t0 - tacc[c]) : 0.f;
+                        for (int u = 0; u < 8; ++u) {
+                            const int m = m0 + u;
+                            const int slot = (m + lane) & 63;
+                            rgv[u] = (m <= P) ? Gs[slot * GS_STRIDE + m] : 0.f;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            t0 += rgv[u];
+#pragma unroll
+                            for (int c = 0; c < DPAD; ++c) {
+                                const float xm = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xc32[c]), m0 + u));
+                                tacc[c] = __builtin_fmaf(rgv[u], xm, tacc[c]);
+                            }
+                        }
+                    }
+                    // park the column-side result in this wave's own G region ([lane][c]) for the block sum
+                    const float *yr = yf + lane * YFS;
+#pragma unroll
+                    for (int c = 0; c < DPAD; ++c)
+                        Gs[lane * DPAD + c] = (lane <= P) ? w_ji * m2h * (yr[c] * t0 - tacc[c]) : 0.f;
+                } else if (SYM) {
+#pragma unroll
+                    for (int c = 0; c < DPAD; ++c) Gs[lane * DPAD + c] = 0.f; // diagonal pair: no column side
                 }
             }
-
-        }
-
-        if (GRAD && SYM) {
-            // park the column-side result in this wave's own G region ([lane][c]) for the block sum
+        } else if (GRAD && SYM) {
 #pragma unroll
-            for (int c = 0; c < DPAD; ++c) Gs[lane * DPAD + c] = ypts[c];
+            for (int c = 0; c < DPAD; ++c) Gs[lane * DPAD + c] = 0.f; // idle wave contributes nothing
         }
         __syncthreads(); // every wave is done with y_j (and has parked its column-side result)
         if (GRAD && SYM) {
@@ -391,7 +413,7 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
                 double s = 0.0;
 #pragma unroll
                 for (int w = 0; w < NW; ++w) s += (double)Gs_all[w * GS_WAVE + e];
-                if (n < T && c < d && s != 0.0 && !(a.dbg & 4)) unsafeAtomicAdd(&a.gacc[((size_t)j * T + n) * d + c], s);
+                if (n < T && c < d && s != 0.0) unsafeAtomicAdd(&a.gacc[((size_t)j * T + n) * d + c], s);
             }
         }
         if (j + 1 < j1) stage_store();
@@ -474,7 +496,6 @@ int fast_launch(const GramProblem &p)
     a.io64 = p.dtype == SIGSVGD_F64; a.A = p.A; a.B = p.B; a.T = p.T; a.d = p.d;
     a.symw = (p.flags & SIGSVGD_FLAG_SYM) ? 1 : 0; a.inv_h = p.inv_h; a.JC = 1;
     a.tile_offset = 0; a.tile_stride = 1;
-    a.dbg = getenv("SIGSVGD_DBG") ? atoi(getenv("SIGSVGD_DBG")) : 0;
     a.gacc = nullptr;
     if (a.symw && p.A != p.B) {
         set_error("sym backward needs A == B");
@@ -531,7 +552,7 @@ int fast_sym_partial(const GramProblem &p, int tile_offset, int tile_stride, dou
     a.X = p.X; a.Y = p.X; a.go = p.grad_out; a.K = p.K_out;
     a.io64 = p.dtype == SIGSVGD_F64; a.A = p.A; a.B = p.B; a.T = p.T; a.d = p.d;
     a.symw = (p.flags & SIGSVGD_FLAG_SYM) ? 1 : 0; a.inv_h = p.inv_h; a.JC = 1;
-    a.tile_offset = tile_offset; a.tile_stride = tile_stride; a.dbg = 0;
+    a.tile_offset = tile_offset; a.tile_stride = tile_stride;
     a.gacc = grad_partial;
     if (p.d <= 4) return launch_variant<4, 8>(p, a, true, true);
     if (p.d <= 8) return launch_variant<8, 8>(p, a, true, true);

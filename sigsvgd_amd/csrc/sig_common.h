@@ -38,6 +38,26 @@ __device__ __forceinline__ double exp64(double a)
     return ldexp(p, (int)kf);
 }
 
+// 2^t for the register-resident kernel: t arrives already scaled by log2(e) (the scale is folded into
+// the particle coordinates), so the reduction is exact: k = rint(t), f = t - k in [-1/2, 1/2], and
+// 2^f is a degree-8 Chebyshev-interpolant (max relative error 1.1e-12, measured on 2e4 points;
+// the 4-corner increments need ~1e-10).  12 fp64-rate instructions.
+__device__ __forceinline__ double exp2_p8(double t)
+{
+    const double kf = __builtin_rint(t);
+    const double f = t - kf;
+    double p = 1.3255197199834888e-06;
+    p = __builtin_fma(p, f, 1.5310079063632544e-05);
+    p = __builtin_fma(p, f, 1.5403455940423864e-04);
+    p = __builtin_fma(p, f, 1.3333450569733936e-03);
+    p = __builtin_fma(p, f, 9.618129159303683e-03);
+    p = __builtin_fma(p, f, 5.550410941203932e-02);
+    p = __builtin_fma(p, f, 2.4022650695813685e-01);
+    p = __builtin_fma(p, f, 6.931471805459342e-01);
+    p = __builtin_fma(p, f, 0.9999999999999997);
+    return ldexp(p, (int)kf);
+}
+
 // ---- Goursat stencils -------------------------------------------------------------------------
 // default (second order):  K11 = (K10 + K01)*(1 + g/2 + g^2/12) - K00*(1 - g^2/12)
 // written in delta form so that the O(1) parts cancel exactly in fp64:
