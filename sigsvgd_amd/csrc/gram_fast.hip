@@ -68,6 +68,22 @@ __device__ __forceinline__ double dpp_shl1_zero(double v)
 {
     return __hiloint2double(dpp_shl1_z(__double2hiint(v)), dpp_shl1_z(__double2loint(v)));
 }
+// wave_rol:1 (0x134): lane l reads lane l+1, lane 63 reads lane 0 (full-wave rotation)
+__device__ __forceinline__ float dpp_rol1(float v)
+{
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x134, 0xF, 0xF, false));
+}
+// rotate-and-add in ONE VALU instruction: returns acc[lane+1] + v.  (hipcc does not fold a wave_rol
+// v_mov_b32_dpp into the add.)  hipcc does not pad hazards inside an asm statement: a DPP read needs
+// 2 wait states after a VALU write of the same VGPR.  `acc` is written one sweep step (>30
+// instructions) earlier, except possibly on the first step, when the compiler may materialise the
+// zero initialisation right in front -- the caller issues one `s_nop 1` per step for that.
+__device__ __forceinline__ float add_rol1(float acc, float v)
+{
+    float out;
+    asm("v_add_f32_dpp %0, %1, %2 wave_rol:1 row_mask:0xf bank_mask:0xf" : "=v"(out) : "v"(acc), "v"(v));
+    return out;
+}
 __device__ __forceinline__ float dpp_shr1_zero(float v) { return __int_as_float(dpp_shr1_z(__float_as_int(v))); }
 
 // [slot][lane] image of G (then R*G) with row stride 65 floats: every in-sweep access is
@@ -295,6 +311,23 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
                 for (int c = 0; c < DPAD / 2; ++c) acc[c] = f32x2{0.f, 0.f};
                 const int smax = 2 * P - 2;
 
+                // x~ of this lane's row as packed fp32 pairs (row-side closing formula; column-side products)
+                f32x2 xc2[DPAD / 2];
+#pragma unroll
+                for (int c = 0; c < DPAD / 2; ++c) {
+                    const bool ok0 = lane < T && 2 * c < d, ok1 = lane < T && 2 * c + 1 < d;
+                    xc2[c] = f32x2{ok0 ? (float)(xraw[2 * c] - yref[2 * c]) : 0.f,
+                                   ok1 ? (float)(xraw[2 * c + 1] - yref[2 * c + 1]) : 0.f};
+                }
+                // column-side (SYM): accumulators that TRAVEL one lane down per step.  On step sigma lane m
+                // holds R*G[m, n] with n = sigma+2-m; on the next step lane m-1 holds the same column n, so
+                // sum_m R*G[m,n] * x~_m rides a wave rotation (v_add_f32 with a wave_rol:1 DPP source) and
+                // never needs a transposed pass: finished columns wrap past lane 0 through lanes that
+                // are already idle, and after the last step column n sits in lane (64 - n) & 63.
+                float t0 = 0.f, tacc[DPAD];
+#pragma unroll
+                for (int c = 0; c < DPAD; ++c) tacc[c] = 0.f;
+
                 int yfrow = 64 - lane;                          // row (sigma + 2 - lane) & 63 == yfrow + k2
                 int gsoff = (GRAD ? wave * GS_WAVE : 0) + lane; // this wave's [slot][lane] image
                 auto grad_part = [&](int sigma, float Snew) {
@@ -306,9 +339,6 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
                     Nb = Na;
                     const int gi = gsoff + k2 * GS_STRIDE;
                     const float rg = R * Gs_all[gi];
-                    // each slot is passed two or three times (sigma+2 = m+n, m+n+64, ...); only the pass
-                    // whose column n = sigma+2-lane is real may replace G by R*G
-                    if (SYM && (unsigned)(sigma + 2 - lane) < 64u) Gs_all[gi] = rg;
                     const f32x2 *yr = reinterpret_cast<const f32x2 *>(yf + (yfrow + k2) * YFS);
                     const f32x2 rg2 = {rg, rg};
                     s0 += rg;
@@ -318,6 +348,19 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
 #pragma unroll
                     for (int c = 0; c < DPAD / 2; ++c) asm volatile("" : "+v"(acc[c]));
                     asm volatile("" : "+v"(s0));
+                    if (SYM) {
+                        asm volatile("s_nop 1" ::: "memory");
+                        t0 = add_rol1(t0, rg);
+#pragma unroll
+                        for (int c = 0; c < DPAD / 2; ++c) {
+                            const f32x2 pr = rg2 * xc2[c];
+                            tacc[2 * c] = add_rol1(tacc[2 * c], pr[0]);
+                            tacc[2 * c + 1] = add_rol1(tacc[2 * c + 1], pr[1]);
+                        }
+#pragma unroll
+                        for (int c = 0; c < DPAD; ++c) asm volatile("" : "+v"(tacc[c]));
+                        asm volatile("" : "+v"(t0));
+                    }
                 };
 
                 for (int rnd = 1; rnd >= 0; --rnd) {
@@ -361,42 +404,16 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
                 }
 #pragma unroll
                 for (int c = 0; c < DPAD; ++c) {
-                    const float xc = (lane < T && c < d) ? (float)(xraw[c] - yref[c]) : 0.f; // x~ again (not kept live)
-                    gacc[c] += (double)(w_ij * m2h * (xc * s0 - acc[c / 2][c % 2]));
+                    gacc[c] += (double)(w_ij * m2h * (xc2[c / 2][c % 2] * s0 - acc[c / 2][c % 2]));
                 }
 
                 if (SYM && j != i) {
-                    // ---- column-side contraction: lane n sums over rows m (transposed LDS read) ----
-                    float t0 = 0.f, tacc[DPAD];
-                    float xc32[DPAD]; // this lane's x~ row (fp32); row m is broadcast with v_readlane below
-#pragma unroll
-                    for (int c = 0; c < DPAD; ++c) {
-                        tacc[c] = 0.f;
-                        xc32[c] = (lane < T && c < d) ? (float)(xraw[c] - yref[c]) : 0.f;
-                    }
-                    for (int m0 = 0; m0 <= P; m0 += 8) { // 8 rows per trip: 8 LDS reads in flight
-                        float rgv[8];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            const int m = m0 + u;
-                            const int slot = (m + lane) & 63;
-                            rgv[u] = (m <= P) ? Gs[slot * GS_STRIDE + m] : 0.f;
-                        }
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            t0 += rgv[u];
-#pragma unroll
-                            for (int c = 0; c < DPAD; ++c) {
-                                const float xm = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xc32[c]), m0 + u));
-                                tacc[c] = __builtin_fmaf(rgv[u], xm, tacc[c]);
-                            }
-                        }
-                    }
                     // park the column-side result in this wave's own G region ([lane][c]) for the block sum
-                    const float *yr = yf + lane * YFS;
+                    const int ncol = (64 - lane) & 63; // the column whose finished sums this lane ended up with
+                    const float *yr = yf + ncol * YFS;
 #pragma unroll
                     for (int c = 0; c < DPAD; ++c)
-                        Gs[lane * DPAD + c] = (lane <= P) ? w_ji * m2h * (yr[c] * t0 - tacc[c]) : 0.f;
+                        Gs[ncol * DPAD + c] = (ncol <= P) ? w_ji * m2h * (yr[c] * t0 - tacc[c]) : 0.f;
                 } else if (SYM) {
 #pragma unroll
                     for (int c = 0; c < DPAD; ++c) Gs[lane * DPAD + c] = 0.f; // diagonal pair: no column side
