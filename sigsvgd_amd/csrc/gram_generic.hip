@@ -21,18 +21,21 @@ struct GenericArgs {
     double *partials; // [A][nchunks][T*d]
     float *wsk;       // [grid][nbands*nsteps*64]
     int A, B, T, d, dp, n, r, P, Tm, TmS, nbands, nsteps, JC, nchunks, kind, naive, sym, want_grad;
+    int big; // long paths (dyadic order 0 only): S kept in fp32 (one write per entry), no LDS gradient accumulator
     double inv_h, inv_r2;
     long long total_items;
     size_t wsk_per_block;
 };
 
-__host__ __device__ inline size_t generic_lds_bytes(int T, int d, int n, int want_grad)
+__host__ __device__ inline size_t generic_lds_bytes(int T, int d, int n, int want_grad, int big)
 {
     const int dp = (d % 2 == 0) ? d + 1 : d;
     const int Tm = T - 1, TmS = Tm | 1, P = (1 << n) * Tm;
     size_t dbl = (size_t)2 * T * dp + 2 * T + (P + 2);
-    if (want_grad) dbl += (size_t)Tm * Tm + (size_t)T * dp;
-    return dbl * sizeof(double) + (size_t)Tm * TmS * sizeof(float);
+    size_t flt = (size_t)Tm * TmS;
+    if (want_grad && !big) dbl += (size_t)Tm * Tm + (size_t)T * dp; // S fp64 + gradient accumulator
+    if (want_grad && big) flt += (size_t)Tm * Tm;                   // S fp32 only
+    return dbl * sizeof(double) + flt * sizeof(float);
 }
 
 template <typename IO>
@@ -49,9 +52,11 @@ __global__ __launch_bounds__(64) void gram_generic_kernel(GenericArgs a)
     double *xn = ys + (size_t)T * dp;
     double *yn = xn + T;
     double *rowbuf = yn + T;
+    const bool big = a.big != 0;
     double *Sm = rowbuf + (P + 2);
-    double *acc = Sm + (a.want_grad ? (size_t)Tm * Tm : 0);
-    float *Dm = reinterpret_cast<float *>(acc + (a.want_grad ? (size_t)T * dp : 0));
+    double *acc = Sm + ((a.want_grad && !big) ? (size_t)Tm * Tm : 0);
+    float *Dm = reinterpret_cast<float *>(acc + ((a.want_grad && !big) ? (size_t)T * dp : 0));
+    float *Sm32 = Dm + (size_t)Tm * TmS; // big mode: S in fp32 (dyadic order 0: each entry written once)
 
     const IO *X = static_cast<const IO *>(a.X);
     const IO *Y = static_cast<const IO *>(a.Y);
@@ -66,6 +71,9 @@ __global__ __launch_bounds__(64) void gram_generic_kernel(GenericArgs a)
         const int j1 = min(a.B, j0 + a.JC);
         const IO *xi = X + (size_t)i * T * d;
 
+        double *slab = a.want_grad ? a.partials + ((size_t)i * a.nchunks + chunk) * T * d : nullptr;
+        if (a.want_grad && big)
+            for (int e = lane; e < T * d; e += kWave) slab[e] = 0.0; // accumulated in place (L2 resident)
         // ---- stage x_i (centred on its first point for the translation-invariant RBF) ----------
         __syncthreads();
         for (int e = lane; e < T * dp; e += kWave) {
@@ -73,7 +81,7 @@ __global__ __launch_bounds__(64) void gram_generic_kernel(GenericArgs a)
             double v = 0.0;
             if (c < d) v = (double)xi[t * d + c] - (rbf ? (double)xi[c] : 0.0);
             xs[e] = v;
-            if (a.want_grad) acc[e] = 0.0;
+            if (a.want_grad && !big) acc[e] = 0.0;
         }
         __syncthreads();
         for (int t = lane; t < T; t += kWave) {
@@ -91,7 +99,7 @@ __global__ __launch_bounds__(64) void gram_generic_kernel(GenericArgs a)
                 if (c < d) v = (double)yj[t * d + c] - (rbf ? (double)xi[c] : 0.0);
                 ys[e] = v;
             }
-            if (a.want_grad)
+            if (a.want_grad && !big)
                 for (int e = lane; e < Tm * Tm; e += kWave) Sm[e] = 0.0;
             __syncthreads();
             for (int t = lane; t < T; t += kWave) {
@@ -166,10 +174,14 @@ __global__ __launch_bounds__(64) void gram_generic_kernel(GenericArgs a)
                     if (active) {
                         const double g = (double)Drow[q >> n] * a.inv_r2;
                         const double kf = (double)wsk[((size_t)kb * a.nsteps + lane + q) * kWave + lane];
-                        sb = __builtin_fma(kf, dprev, sb);
-                        if ((q & (r - 1)) == 0) {
-                            atomicAdd(&Sm[arow * Tm + (q >> n)], sb * a.inv_r2);
-                            sb = 0.0;
+                        if (big) {
+                            Sm32[arow * Tm + q] = (float)(kf * dprev); // r == 1: the block is this cell
+                        } else {
+                            sb = __builtin_fma(kf, dprev, sb);
+                            if ((q & (r - 1)) == 0) {
+                                atomicAdd(&Sm[arow * Tm + (q >> n)], sb * a.inv_r2);
+                                sb = 0.0;
+                            }
                         }
                         const double nw = stencil(cur, down_in, dprev, g, naive);
                         cur = nw;
@@ -196,10 +208,11 @@ __global__ __launch_bounds__(64) void gram_generic_kernel(GenericArgs a)
                     double s0 = 0.0;
                     for (int nn = 0; nn < T; ++nn) {
                         double R = 0.0;
-                        if (m >= 1 && nn >= 1) R += Sm[(m - 1) * Tm + nn - 1];
-                        if (m < Tm && nn < Tm) R += Sm[m * Tm + nn];
-                        if (m >= 1 && nn < Tm) R -= Sm[(m - 1) * Tm + nn];
-                        if (m < Tm && nn >= 1) R -= Sm[m * Tm + nn - 1];
+                        auto Sat = [&](int aa, int bb) { return big ? (double)Sm32[aa * Tm + bb] : Sm[aa * Tm + bb]; };
+                        if (m >= 1 && nn >= 1) R += Sat(m - 1, nn - 1);
+                        if (m < Tm && nn < Tm) R += Sat(m, nn);
+                        if (m >= 1 && nn < Tm) R -= Sat(m - 1, nn);
+                        if (m < Tm && nn >= 1) R -= Sat(m, nn - 1);
                         double rg = R;
                         if (rbf) {
                             double dot = 0.0;
@@ -215,17 +228,19 @@ __global__ __launch_bounds__(64) void gram_generic_kernel(GenericArgs a)
                     for (int c = 0; c < 16; ++c) {
                         if (c0 + c < d) {
                             const double val = rbf ? (-2.0 * a.inv_h) * (xs[m * dp + c0 + c] * s0 - accv[c]) : accv[c];
-                            acc[m * dp + c0 + c] = __builtin_fma(w, val, acc[m * dp + c0 + c]);
+                            if (big)
+                                slab[m * d + c0 + c] = __builtin_fma(w, val, slab[m * d + c0 + c]);
+                            else
+                                acc[m * dp + c0 + c] = __builtin_fma(w, val, acc[m * dp + c0 + c]);
                         }
                     }
                 }
             }
         } // j
 
-        if (a.want_grad) {
+        if (a.want_grad && !big) {
             __syncthreads();
-            double *dst = a.partials + ((size_t)i * a.nchunks + chunk) * T * d;
-            for (int e = lane; e < T * d; e += kWave) dst[e] = acc[(e / d) * dp + (e % d)];
+            for (int e = lane; e < T * d; e += kWave) slab[e] = acc[(e / d) * dp + (e % d)];
         }
     }
 }
@@ -244,7 +259,7 @@ __global__ void reduce_partials_kernel(const double *partials, IO *gradX, int A,
 
 namespace {
 struct GenericPlan {
-    int dp, Tm, TmS, r, P, nbands, nsteps, JC, nchunks, grid;
+    int dp, Tm, TmS, r, P, nbands, nsteps, JC, nchunks, grid, big;
     long long items;
     size_t lds, partial_bytes, wsk_per_block, wsk_bytes;
 };
@@ -267,7 +282,12 @@ int make_plan(int A, int B, int T, int d, int n, int want_grad, GenericPlan &pl)
     pl.P = (int)P64;
     pl.nbands = (pl.P + kWave - 1) / kWave;
     pl.nsteps = pl.P + kWave - 1;
-    pl.lds = generic_lds_bytes(T, d, n, want_grad);
+    pl.big = 0;
+    pl.lds = generic_lds_bytes(T, d, n, want_grad, 0);
+    if (pl.lds > 160 * 1024 && want_grad && n == 0) { // long paths: compact layout (S fp32, no LDS accumulator)
+        pl.big = 1;
+        pl.lds = generic_lds_bytes(T, d, n, want_grad, 1);
+    }
     if (pl.lds > 160 * 1024) {
         set_error("generic: per-pair state needs %zu B of LDS (> 160 KiB): T=%d d=%d n=%d", pl.lds, T, d, n);
         return SIGSVGD_E_UNSUPPORTED;
@@ -324,7 +344,7 @@ int generic_launch(const GramProblem &p)
     a.nchunks = pl.nchunks; a.kind = p.kind; a.naive = (p.flags & SIGSVGD_FLAG_NAIVE_SOLVER) ? 1 : 0;
     a.sym = sym ? 1 : 0; a.want_grad = want_grad; a.inv_h = p.inv_h;
     a.inv_r2 = 1.0 / ((double)pl.r * (double)pl.r);
-    a.total_items = pl.items; a.wsk_per_block = pl.wsk_per_block;
+    a.total_items = pl.items; a.wsk_per_block = pl.wsk_per_block; a.big = pl.big;
 
     hipError_t e;
     if (p.dtype == SIGSVGD_F64) {

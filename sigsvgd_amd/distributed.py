@@ -66,27 +66,50 @@ class ShardedSigSVGD:
     (The CPU tests substitute oracle-backed callables to exercise the sharding algebra under gloo.)"""
 
     def __init__(self, inv_h: float, lr: float, group=None, partial_fn: Optional[Callable] = None,
-                 phi_fn: Optional[Callable] = None):
+                 phi_fn: Optional[Callable] = None, rows_fn: Optional[Callable] = None, rowwise: bool = False):
         self.inv_h = float(inv_h)
         self.lr = float(lr)
         self.group = group
         self.partial_fn = partial_fn or (lambda X, inv_h, off, stride: ops.gram_sym_partial(X, inv_h, off, stride))
         self.phi_fn = phi_fn or (lambda K, s, gk: ops.svgd_phi(K, s, gk))
+        self.rows_fn = rows_fn or (lambda Xs, Xf, inv_h: ops.gram_fwd_bwd(Xs, Xf, inv_h))
+        self.rowwise = bool(rowwise)
         self.last_K_partial = None
+        self.last_K_rows = None
 
     def step(self, X_shard: torch.Tensor, score_shard: torch.Tensor) -> torch.Tensor:
         """Returns the updated shard X_shard - lr * v_rows."""
         rank, world = _world(self.group)
         X_full = all_gather_rows(X_shard, self.group)
         s_full = all_gather_rows(score_shard, self.group)
+        if self.rowwise or not self._partial_supported(X_full):
+            return self._step_rowwise(X_shard, X_full, s_full)
         Kp, gp = self.partial_fn(X_full, self.inv_h, rank, world)
         self.last_K_partial = Kp
         v_part = self.phi_fn(Kp, s_full, gp.to(s_full.dtype))  # -((Kp @ s - gp)/N), linear in (Kp, gp)
         v_rows = reduce_scatter_rows(v_part.reshape(X_full.shape), self.group)
         return X_shard - self.lr * v_rows
 
+    @staticmethod
+    def _partial_supported(X_full) -> bool:
+        """shapes the register-resident symmetric kernel covers (include/sigsvgd_hip.h)"""
+        return 3 <= X_full.shape[1] <= 64 and X_full.shape[2] <= 16
+
+    def _step_rowwise(self, X_shard, X_full, s_full):
+        """Fallback for shapes outside the symmetric partial solve (e.g. T = 128): each rank solves
+        the ordered pairs (own rows) x (all columns), so its rows of K, grad_k and v are complete
+        locally and no reduce-scatter is needed -- at twice the pair solves."""
+        K_rows, g_rows = self.rows_fn(X_shard, X_full, self.inv_h)
+        self.last_K_partial = None
+        self.last_K_rows = K_rows
+        n_all = X_full.shape[0]
+        v_rows = -((K_rows.to(s_full.dtype) @ s_full.flatten(1) - g_rows.flatten(1).to(s_full.dtype)) / n_all)
+        return X_shard - self.lr * v_rows.reshape(X_shard.shape)
+
     def gather_gram(self) -> torch.Tensor:
         """Full K (sum of the partials), on demand -- the per-iteration path never needs it."""
+        if self.last_K_partial is None:  # row-wise step: rows are complete, just gather them
+            return all_gather_rows(self.last_K_rows, self.group)
         K = self.last_K_partial.clone()
         dist.all_reduce(K, group=self.group)
         return K

@@ -14,7 +14,7 @@ import torch.multiprocessing as mp
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, N, T, d, steps, q):
+def _worker(rank, world, port, N, T, d, steps, q, rowwise=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -27,7 +27,8 @@ def _worker(rank, world, port, N, T, d, steps, q):
         r0, r1 = shard_rows(N, rank, world)
         Xs, ss = X[r0:r1].clone(), score[r0:r1].clone()
         sh = ShardedSigSVGD(1.0, 0.05, partial_fn=lambda Xf, ih, off, st: helpers.gram_sym_partial(Xf, ih, off, st),
-                            phi_fn=lambda K, s, gk: helpers.svgd_phi(K, s, gk))
+                            phi_fn=lambda K, s, gk: helpers.svgd_phi(K, s, gk),
+                            rows_fn=lambda Xs_, Xf, ih: helpers.gram_fwd_bwd(Xs_, Xf, ih), rowwise=rowwise)
         for _ in range(steps):
             Xs = sh.step(Xs, ss)
         K = sh.gather_gram()
@@ -36,15 +37,15 @@ def _worker(rank, world, port, N, T, d, steps, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,N", [(2, 16), (4, 16)])
-def test_sharded_iteration_matches_single_process(world, N):
+@pytest.mark.parametrize("world,N,rowwise", [(2, 16, False), (4, 16, False), (2, 16, True)])
+def test_sharded_iteration_matches_single_process(world, N, rowwise):
     from oracle import sigkernel_oracle as O
 
     T, d, steps = 6, 2, 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 1000) + world
-    procs = [ctx.Process(target=_worker, args=(r, world, port, N, T, d, steps, q)) for r in range(world)]
+    port = 29500 + (os.getpid() % 1000) + world + (7 if rowwise else 0)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, N, T, d, steps, q, rowwise)) for r in range(world)]
     for p in procs:
         p.start()
     outs = [q.get(timeout=300) for _ in range(world)]

@@ -31,6 +31,8 @@ CASES = [
     (4, 5, 9, 3, 1, 0, True),    # naive solver
     (2, 3, 70, 3, 0, 0, False),  # T > 64 (two bands at n=0)
     (3, 2, 33, 17, 0, 0, False), # d > 16
+    (3, 2, 128, 14, 0, 0, False), # C5 path shape (T=128, d=14): compact-LDS mode of the generic kernel
+    (2, 3, 100, 3, 0, 0, False),  # long path, three bands
 ]
 
 
