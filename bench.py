@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=256)
+    ap.add_argument("--force-dist", action="store_true", help="use the sharded path even with one rank (rehearsal)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -109,7 +110,8 @@ def main():
     torch.cuda.set_device(dev)
     X0, score0 = O.synthetic_inputs(N, T, D_CH)
 
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch.distributed as dist
 
         from sigsvgd_amd.distributed import ShardedSigSVGD, shard_rows
@@ -148,7 +150,7 @@ def main():
         X = step(X)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
 
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -226,7 +228,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(N, T, D_CH, args.cpu_rows)
         print(json.dumps(out), flush=True)
 
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
 
         dist.barrier()

@@ -207,3 +207,34 @@ def test_properties_at_benchmark_size(gpu):
     assert rel(Xn, (Xg - 1e-3 * v).double().cpu().numpy()) < 1e-6
     vref = -((K.double() @ sg.double().flatten(1) - g.double().flatten(1)) / 1024).reshape(v.shape)
     assert rel(v, vref.cpu().numpy()) < TOL
+
+
+def test_sharded_step_on_rccl_single_rank(gpu):
+    """the particle-sharded iteration through torch.distributed's nccl (= RCCL) backend with one
+    rank equals the single-GPU iteration (the world-size-2/4 algebra is covered by the gloo tests)"""
+    import os
+
+    import torch.distributed as dist
+
+    from sigsvgd_amd import ops
+    from sigsvgd_amd.distributed import ShardedSigSVGD
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=gpu)
+    try:
+        X, s = O.synthetic_inputs(64, 64, 7)
+        Xg, sg = X.to(gpu), s.to(gpu)
+        sh = ShardedSigSVGD(1.0, 1e-2)
+        Xa = sh.step(Xg, sg)
+        Kd = sh.gather_gram()
+        K, g = ops.gram_fwd_bwd(Xg, Xg, 1.0, y_is_x=True)
+        _, Xb = ops.svgd_phi(K, sg, g, X=Xg, lr=1e-2)
+        assert rel(Xa, Xb.double().cpu().numpy()) < 1e-6 and torch.equal(Kd, K)
+        ref = O.svgd_iteration(X.numpy(), s.numpy(), h=1.0, n=0, lr=1e-2)
+        assert rel(Xa, ref["X_new"]) < TOL
+        # row-wise fallback (used for shapes outside the symmetric kernel, e.g. T = 128)
+        Xc = ShardedSigSVGD(1.0, 1e-2, rowwise=True).step(Xg, sg)
+        assert rel(Xc, ref["X_new"]) < TOL
+    finally:
+        dist.destroy_process_group()
