@@ -473,24 +473,30 @@ template <int DPAD, int NW>
 int launch_variant(const GramProblem &p, FastArgs &a, bool grad, bool sym)
 {
     const int ntile = (p.A + NW - 1) / NW;
-    // column chunk: as long as possible (amortises the per-tile flush) while still >= ~2 waves of
-    // workgroups over the 256 CUs
-    int JC = sym ? 8 : 16; // measured at C4: 8 trims the last partial wave of workgroups (sym), 16 amortises flushes
-    auto nblocks = [&](int jc) {
-        long long nb = (long long)ntile * ((p.B + jc - 1) / jc);
-        return sym ? nb / 2 + ntile : nb;
-    };
-    while (JC > 1 && nblocks(JC) < 1024) JC >>= 1;
-    a.JC = JC;
     const int owned = (ntile - a.tile_offset + a.tile_stride - 1) / a.tile_stride;
     if (owned <= 0) return SIGSVGD_OK;
-    dim3 grid((p.B + JC - 1) / JC, owned);
-    if (sym) { // 1-D grid over the chunks on or right of the diagonal of each owned row tile
-        const int nJ = (p.B + JC - 1) / JC;
+    // Workgroups of this launch for a column chunk of jc columns (symmetric launches enumerate only the
+    // chunks on or right of the diagonal of each owned row tile).
+    auto nblocks = [&](int jc) {
+        const int nJ = (p.B + jc - 1) / jc;
         long long total = 0;
-        for (int k = 0; k < owned; ++k) total += nJ - ((k * a.tile_stride + a.tile_offset) * NW) / JC;
-        grid = dim3((unsigned)total, 1);
+        for (int k = 0; k < owned; ++k)
+            total += sym ? nJ - ((k * a.tile_stride + a.tile_offset) * NW) / jc : nJ;
+        return total;
+    };
+    // Column chunk: one workgroup per CU is resident (LDS), so the launch runs in ceil(nblocks/256)
+    // rounds and the last one is partly empty; longer chunks amortise the per-workgroup gradient flush
+    // (~3 % of a chunk of 8 at C4).  Pick the chunk with the best modelled efficiency.
+    int JC = 1;
+    double best = -1.0;
+    for (int jc = 16; jc >= 1; jc >>= 1) {
+        const double rounds = (double)nblocks(jc) / 256.0;
+        const double eff = rounds / __builtin_ceil(rounds) / (1.0 + 0.25 / jc);
+        if (eff > best + 1e-9) { best = eff; JC = jc; }
     }
+    a.JC = JC;
+    dim3 grid((p.B + JC - 1) / JC, owned);
+    if (sym) grid = dim3((unsigned)nblocks(JC), 1); // 1-D grid of real work only
     dim3 block(NW * 64);
     if (!grad)
         hipLaunchKernelGGL((gram_fast_kernel<DPAD, NW, false, false>), grid, block, 0, p.stream, a);
