@@ -64,6 +64,25 @@ __device__ __forceinline__ double dpp_shl1_one(double v)
     const int hi = dpp_shl1_i(__double2hiint(v), 0x3FF00000);
     return __hiloint2double(hi, lo);
 }
+// Same shifts with the 1.0 boundary kept in a PERSISTENT destination: the lane without a source
+// (0 for shr, 63 for shl) is never written, so once `dst` holds 1.0 there it stays -- no per-step
+// re-initialisation of the DPP `old` operand.  (asm: hipcc would re-materialise `old` every step.)
+// The DPP source is written by the previous step's stencil, tens of instructions earlier, so the
+// 2-wait-state VALU->DPP hazard cannot occur.
+__device__ __forceinline__ void dpp_shr1_keep(double &dst, double v)
+{
+    int dlo = __double2loint(dst), dhi = __double2hiint(dst);
+    asm("v_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(dlo) : "v"(__double2loint(v)));
+    asm("v_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(dhi) : "v"(__double2hiint(v)));
+    dst = __hiloint2double(dhi, dlo);
+}
+__device__ __forceinline__ void dpp_shl1_keep(double &dst, double v)
+{
+    int dlo = __double2loint(dst), dhi = __double2hiint(dst);
+    asm("v_mov_b32_dpp %0, %1 wave_shl:1 row_mask:0xf bank_mask:0xf" : "+v"(dlo) : "v"(__double2loint(v)));
+    asm("v_mov_b32_dpp %0, %1 wave_shl:1 row_mask:0xf bank_mask:0xf" : "+v"(dhi) : "v"(__double2hiint(v)));
+    dst = __hiloint2double(dhi, dlo);
+}
 __device__ __forceinline__ double dpp_shl1_zero(double v)
 {
     return __hiloint2double(dpp_shl1_z(__double2hiint(v)), dpp_shl1_z(__double2loint(v)));
@@ -157,7 +176,7 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
     const int j1 = min(a.B, j0 + a.JC);
     const int i = itile * NW + wave;
     const bool row_ok = i < a.A;
-    const bool rowD = lane < P;
+    const int lane_q = (lane < P) ? lane : 0x40000000; // rows without PDE cells never pass the range test below
     float *Gs = Gs_all + (GRAD ? wave * GS_WAVE : 0);
     const double inv_h = a.inv_h;
     const float m2h = (float)(-2.0 * inv_h);
@@ -271,19 +290,20 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
 
             // ---- phase 2: forward sweep, anti-diagonal sigma = 0 .. 2P-2 ---------------------------
             {
-                double cur = 1.0, diag = 1.0;
+                double cur = 1.0, diag = 1.0, up = 1.0; // `up` persists: lane 0 keeps the boundary K[0][.] = 1
                 const int smax = 2 * P - 2;
                 for (int rnd = 0; rnd < 2; ++rnd) {
                     if (rnd * 64 > smax) break;
+                    float c12 = 1.0f / 12.0f, chalf = 0.5f;
+                    asm volatile("" : "+s"(c12), "+s"(chalf)); // opaque per round: keeps the stencil coefficients in the loop
 #pragma unroll
                     for (int k = 0; k < 64; ++k) {
                         const int sigma = rnd * 64 + k;
-                        const bool act = rowD && (unsigned)(sigma - lane) < (unsigned)P;
-                        const double up = dpp_shr1_one(cur);
-                        float g = Dsl[k];
-                        asm volatile("" : "+v"(g)); // keep the coefficient math inside the round loop (no LICM)
-                        const float b = g * g * (1.0f / 12.0f);
-                        const float aa = __builtin_fmaf(g, 0.5f, b);
+                        const bool act = (unsigned)(sigma - lane_q) < (unsigned)P;
+                        dpp_shr1_keep(up, cur);
+                        const float g = Dsl[k];
+                        const float b = g * (g * c12); // c12, chalf: per-round opaque constants; (g*c12) first so nothing here is round-invariant
+                        const float aa = __builtin_fmaf(g, chalf, b);
                         const double t = cur + up;
                         double u = t - diag;
                         u = __builtin_fma(t, (double)aa, u);
@@ -304,7 +324,7 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
 
             if (GRAD) {
                 // ---- phase 3: reverse sweep + lagged R -> row-side contraction ----------------------
-                double cur = 1.0, ddiag = 1.0;
+                double cur = 1.0, ddiag = 1.0, down = 1.0; // `down` persists: lane 63 keeps U[P][.] = 1
                 float Sb = 0.f, Sc = 0.f, Nb = 0.f, s0 = 0.f;
                 f32x2 acc[DPAD / 2]; // packed pairs: the contraction runs on v_pk_fma_f32
 #pragma unroll
@@ -333,7 +353,9 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
                 auto grad_part = [&](int sigma, float Snew) {
                     const int k2 = (sigma + 2) & 63;
                     const float Na = dpp_shr1_zero(Snew); // S[l-1, q+1]
-                    const float R = (Na + Sc) - (Nb + Sb);
+                    float dN = Na - Nb;
+                    asm volatile("" : "+v"(dN)); // keeps hipcc from SLP-packing the two differences (costs 2 moves)
+                    const float R = (Sc - Sb) + dN;
                     Sc = Sb;
                     Sb = Snew;
                     Nb = Na;
@@ -349,7 +371,6 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
                     for (int c = 0; c < DPAD / 2; ++c) asm volatile("" : "+v"(acc[c]));
                     asm volatile("" : "+v"(s0));
                     if (SYM) {
-                        asm volatile("s_nop 1" ::: "memory");
                         t0 = add_rol1(t0, rg);
 #pragma unroll
                         for (int c = 0; c < DPAD / 2; ++c) {
@@ -366,16 +387,17 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
                 for (int rnd = 1; rnd >= 0; --rnd) {
                     if (rnd * 64 > smax) continue;
                     asm volatile("" : "+v"(yfrow), "+v"(gsoff)); // loads below are not round-invariant
+                    float c12 = 1.0f / 12.0f, chalf = 0.5f;
+                    asm volatile("" : "+s"(c12), "+s"(chalf));
 #pragma unroll
                     for (int kk = 0; kk < 64; ++kk) {
                         const int k = 63 - kk;
                         const int sigma = rnd * 64 + k;
-                        const bool act = rowD && (unsigned)(sigma - lane) < (unsigned)P;
-                        const double down = dpp_shl1_one(cur);
-                        float g = Dsl[k];
-                        asm volatile("" : "+v"(g));
-                        const float b = g * g * (1.0f / 12.0f);
-                        const float aa = __builtin_fmaf(g, 0.5f, b);
+                        const bool act = (unsigned)(sigma - lane_q) < (unsigned)P;
+                        dpp_shl1_keep(down, cur);
+                        const float g = Dsl[k];
+                        const float b = g * (g * c12);
+                        const float aa = __builtin_fmaf(g, chalf, b);
                         const double t = cur + down;
                         double u = t - ddiag;
                         u = __builtin_fma(t, (double)aa, u);

@@ -5,7 +5,7 @@ The reference has no distributed code; this is new desig
 natural sharding: N^2/2 independent pair solves followed by one reduction over partners.
 
     rank r owns particle rows [r*N/G, (r+1)*N/G)
-    1. all-gather   X shards, score shards            (N*T*d*4 B each; 1.8 MB at N=1024,T=64,d=7)
+    1. all-gather   X and score shards, packed into ONE collective   (2*N*T*d*4 B; 3.7 MB at N=1024,T=64,d=7)
     2. compute      the unordered pairs whose 8-row tile index is r mod G (cyclic over the upper
                     triangle => balanced), on the gathered X:  K_partial [N,N], grad_partial [N,T,d]
                     v_partial = -((K_partial @ score - grad_partial)/N)   (linear in the partials)
@@ -80,8 +80,10 @@ class ShardedSigSVGD:
     def step(self, X_shard: torch.Tensor, score_shard: torch.Tensor) -> torch.Tensor:
         """Returns the updated shard X_shard - lr * v_rows."""
         rank, world = _world(self.group)
-        X_full = all_gather_rows(X_shard, self.group)
-        s_full = all_gather_rows(score_shard, self.group)
+        # one collective for both operands: [n, 2, T, d] shards -> [N, 2, T, d]
+        both = all_gather_rows(torch.stack((X_shard, score_shard.to(X_shard.dtype)), dim=1), self.group)
+        X_full = both[:, 0].contiguous()
+        s_full = both[:, 1].contiguous()
         if self.rowwise or not self._partial_supported(X_full):
             return self._step_rowwise(X_shard, X_full, s_full)
         Kp, gp = self.partial_fn(X_full, self.inv_h, rank, world)
