@@ -261,14 +261,28 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
                 double g0 = 0.0, g1 = 0.0, gprev = 0.0, rdprev = 0.0;
                 const double *ybase = yd + (64 - lane) * YDS; // row (t - lane) & 63 == ybase + t*YDS
                 const double *nbase = ynd + (64 - lane);
+                // the y~ row of column t+1 is fetched while column t is computed (one s_waitcnt per
+                // column instead of one per ds_read, and the LDS latency is off the exp chain)
+                double ynx[DPAD], nnx;
+#pragma unroll
+                for (int c = 0; c < DPAD; ++c) ynx[c] = ybase[c];
+                nnx = nbase[0];
 #pragma unroll
                 for (int t = 0; t < 66; ++t) {
                     double g;
                     if (t < 64) {
-                        const double *yr = ybase + t * YDS;
-                        double e2 = xn + nbase[t];
+                        double ycu[DPAD];
 #pragma unroll
-                        for (int c = 0; c < DPAD; ++c) e2 = __builtin_fma(xs[c], yr[c], e2);
+                        for (int c = 0; c < DPAD; ++c) ycu[c] = ynx[c];
+                        double e2 = xn + nnx;
+                        if (t < 63) {
+                            const double *yr = ybase + (t + 1) * YDS;
+#pragma unroll
+                            for (int c = 0; c < DPAD; ++c) ynx[c] = yr[c];
+                            nnx = nbase[t + 1];
+                        }
+#pragma unroll
+                        for (int c = 0; c < DPAD; ++c) e2 = __builtin_fma(xs[c], ycu[c], e2);
                         g = exp2_p8(e2);
                         if (GRAD) Gs[gs_index(t, lane)] = (float)g;
                         if (t == 0) g0 = g;
