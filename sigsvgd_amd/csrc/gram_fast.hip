@@ -572,7 +572,11 @@ int fast_launch(const GramProblem &p)
         if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(gacc)");
     }
     int rc;
-    if (p.d <= 4)
+    if (!grad && p.d <= 4) // forward only: no G image, <=168 VGPRs -> 4-wave workgroups pack 3 waves per SIMD
+        rc = launch_variant<4, 4>(p, a, false, false);
+    else if (!grad && p.d <= 8)
+        rc = launch_variant<8, 4>(p, a, false, false);
+    else if (p.d <= 4)
         rc = launch_variant<4, 8>(p, a, grad, sym);
     else if (p.d <= 8)
         rc = launch_variant<8, 8>(p, a, grad, sym);
