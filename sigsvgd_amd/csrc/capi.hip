@@ -61,6 +61,8 @@ static int dispatch(const GramProblem &p)
     (void)want_grad;
     if (!(p.flags & SIGSVGD_FLAG_FORCE_GENERIC) && fast_supported(p.A, p.B, p.T, p.d, p.n, p.kind, p.flags))
         return fast_launch(p);
+    if (!(p.flags & SIGSVGD_FLAG_FORCE_GENERIC) && stream_supported(p.A, p.B, p.T, p.d, p.n, p.kind, p.flags))
+        return stream_launch(p);
     return generic_launch(p);
 }
 
@@ -84,6 +86,8 @@ int sigsvgd_gram_workspace_bytes(int A, int B, int T, int d, int dyadic_order, i
     // size for whichever kernel dispatch() would pick; the static kind does not change the size
     if (!(flags & SIGSVGD_FLAG_FORCE_GENERIC) && fast_supported(A, B, T, d, dyadic_order, SIGSVGD_STATIC_RBF, flags))
         return fast_workspace_bytes(A, B, T, d, want_grad, flags, bytes);
+    if (!(flags & SIGSVGD_FLAG_FORCE_GENERIC) && stream_supported(A, B, T, d, dyadic_order, SIGSVGD_STATIC_RBF, flags))
+        return stream_workspace_bytes(A, T, d, want_grad, bytes);
     return generic_workspace_bytes(A, B, T, d, dyadic_order, want_grad, bytes);
 }
 

@@ -1,0 +1,425 @@
+// Signature-kernel Gram forward/backward for LONG paths: dyadic order 0, 65 <= T <= 128, d <= 16, RBF,
+// second-order stencil (BASELINE.json config C5: T = 128, d = 14).
+//
+// For these shapes the per-pair arrays the register-resident kernel keeps (increments D, forward
+// solution K_fwd, static kernel G: 3 x 64 KB at T = 128) no longer fit a CU more than twice, so this
+// kernel stores NONE of them:
+//   * the static kernel is evaluated on the fly, two columns ahead of the PDE column, and the 4-corner
+//     increment is formed from row differences exactly as in phase 1 of gram_fast.hip (own difference
+//     of the previous step, neighbour row's difference through one wave_shl DPP);
+//   * the forward solution is not stored for the backward pass but REGENERATED: the stencil is
+//     reversible, K[p,q] = ((K[p+1,q] + K[p,q+1])*A - K[p+1,q+1]) / B, so the reverse sweep runs this
+//     recurrence next to the U recurrence, seeded by the last row / last column / band-boundary rows
+//     the forward sweep leaves in LDS and registers (error growth is that of the forward sweep,
+//     ~1e-12 in fp64);
+//   * the P x P grid is swept in two bands of <= 64 rows, one row per lane, anti-diagonal by
+//     anti-diagonal, neighbours through wave shifts, band boundary rows in LDS.
+// One wavefront per ORDERED pair (i, j); a workgroup is 4 wavefronts = 4 consecutive rows i sharing
+// the staged column trajectory y_j.  Row-side gradient only (the symmetric trick of gram_fast.hip is
+// not applied here).  Per-wave LDS: four T-length fp64 row buffers.
+//
+// Reference semantics: sigkernel _SigKernelGram.forward/backward [RECALLED, SURVEY.md App. A];
+// static kernel src/kernels/_traj_kernels.py:176-195.
+#include "sig_common.h"
+
+namespace sigsvgd {
+
+struct StreamArgs {
+    const void *X, *Y, *go;
+    void *K;
+    double *gacc; // [A][T][d] fp64, zeroed by the launcher
+    int io64, A, B, T, d, JC, symw;
+    double inv_h;
+};
+
+namespace {
+constexpr int SNW = 4;     // wavefronts (rows i) per workgroup
+constexpr int TMAX = 128;  // longest supported path
+constexpr int RB = TMAX + 4; // row-buffer length
+
+using sf32x2 = __attribute__((ext_vector_type(2))) float;
+
+__device__ __forceinline__ double s_shl(double v) // lane l <- lane l+1 (lane 63 gets 0)
+{
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x130, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x130, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double s_shr(double v) // lane l <- lane l-1 (lane 0 gets 0)
+{
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x138, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x138, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float s_shr(float v)
+{
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x138, 0xF, 0xF, true));
+}
+__device__ __forceinline__ double ldany(const void *b, size_t i, int io64)
+{
+    return io64 ? static_cast<const double *>(b)[i] : (double)static_cast<const float *>(b)[i];
+}
+} // namespace
+
+template <int DPAD, bool GRAD>
+__global__ __launch_bounds__(SNW * 64) void gram_stream_kernel(StreamArgs a)
+{
+    constexpr int NT = SNW * 64;
+    constexpr int YDS = DPAD + 2; // fp64 row stride (doubles): column DPAD holds -log2(e)/h * |y~|^2
+    constexpr int YFS = (DPAD == 4) ? 12 : DPAD + 4;
+    __shared__ __align__(16) double yd[TMAX * YDS];
+    __shared__ __align__(16) float yf[GRAD ? TMAX * YFS : 4];
+    __shared__ double yref[DPAD];
+    __shared__ double rows_all[SNW * 5 * RB];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int T = a.T, d = a.d, P = T - 1, io64 = a.io64;
+    const int i = blockIdx.y * SNW + wave;
+    const int j0 = blockIdx.x * a.JC, j1 = min(a.B, j0 + a.JC);
+    const bool row_ok = i < a.A;
+    const double inv_h = a.inv_h;
+    const double nscale = -inv_h * 1.4426950408889634074;
+    const float m2h = (float)(-2.0 * inv_h);
+    double *Kbnd = rows_all + (size_t)wave * 5 * RB; // K[64][.]   forward band boundary (kept for the K regeneration)
+    double *Klast = Kbnd + RB;                       // K[P][.]    last forward row
+    double *Ubnd = Klast + RB;                       // U[64][.]   reverse band boundary
+    double *Gbd = Ubnd + RB;                         // G[64][q+1] - G[64][q]: row beyond band 0
+    float *Gb32 = reinterpret_cast<float *>(Gbd + RB); // G[64][n] (fp32) and, behind it,
+    float *Srow = Gb32 + RB;                           // S[63][q]: last row of band 0 for the hand-over to row 64
+    const int nbands = (P + 63) / 64;                // 2 for 65 <= T <= 128
+
+    float gacc[2][DPAD]; // row-side gradient of (band, channel), summed over the j chunk in fp32
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int c = 0; c < DPAD; ++c) gacc[b][c] = 0.f;
+
+    for (int j = j0; j < j1; ++j) {
+        // ---- stage y_j (centred on its first point): fp64 rows + scaled norms, fp32 copy ------------------
+        __syncthreads();
+        for (int e = tid; e < TMAX * DPAD; e += NT) {
+            const int t = e / DPAD, c = e % DPAD;
+            const bool ok = t < T && c < d;
+            const double r0 = ok ? ldany(a.Y, (size_t)j * T * d + c, io64) : 0.0;
+            const double v = ok ? ldany(a.Y, ((size_t)j * T + t) * d + c, io64) - r0 : 0.0;
+            yd[t * YDS + c] = v;
+            if (GRAD) yf[t * YFS + c] = (float)v;
+            if (t == 0) yref[c] = r0;
+            double s = v * v * nscale;
+#pragma unroll
+            for (int off = 1; off < DPAD; off <<= 1) s += __shfl_xor(s, off, 64);
+            if (c == 0) yd[t * YDS + DPAD] = s;
+        }
+        __syncthreads();
+        if (!row_ok) continue;
+
+        double kfin[2] = {1.0, 1.0}; // K[p+1][P] per band: last-column seeds of the K regeneration
+        float w_ij = 1.f;
+        if (GRAD) {
+            if (a.go) {
+                w_ij = (float)ldany(a.go, (size_t)i * a.B + j, io64);
+                if (a.symw) w_ij += (float)ldany(a.go, (size_t)j * a.B + i, io64);
+            } else if (a.symw) {
+                w_ij = 2.f;
+            }
+        }
+
+        // per-band lane state: row p = rb + lane; xs = scaled x~ (fp64), xf = x~ (fp32)
+        double xs[DPAD], xn;
+        float xf[DPAD];
+        auto load_x = [&](int p) {
+            xn = 0.0;
+#pragma unroll
+            for (int c = 0; c < DPAD; ++c) {
+                const double xc = (p <= P && c < d) ? ldany(a.X, ((size_t)i * T + min(p, P)) * d + c, io64) - yref[c] : 0.0;
+                xn = __builtin_fma(xc, xc, xn);
+                xs[c] = xc * (-2.0 * nscale);
+                xf[c] = (float)xc;
+            }
+            xn *= nscale;
+        };
+        auto Geval = [&](int col) { // G[p, col] for this lane's row (col clamped; caller masks)
+            const double *yr = yd + min(max(col, 0), P) * YDS;
+            double e2 = xn + yr[DPAD];
+#pragma unroll
+            for (int c = 0; c < DPAD; ++c) e2 = __builtin_fma(xs[c], yr[c], e2);
+            return exp2_p8(e2);
+        };
+
+        // =============================== forward sweep ===================================================
+        for (int kb = 0; kb < nbands; ++kb) {
+            const int rb = kb * 64, p = rb + lane;
+            const bool pde_row = p < P;
+            const bool has_next = rb + 64 <= P; // G row rb+64 exists and belongs to the next band
+            load_x(p);
+            if (has_next) { // boundary G row (rb+64) differences for lane 63
+                double xs2[DPAD], xn2 = 0.0;
+#pragma unroll
+                for (int c = 0; c < DPAD; ++c) {
+                    const double xc = (c < d) ? ldany(a.X, ((size_t)i * T + rb + 64) * d + c, io64) - yref[c] : 0.0;
+                    xn2 = __builtin_fma(xc, xc, xn2);
+                    xs2[c] = xc * (-2.0 * nscale);
+                }
+                xn2 *= nscale;
+                for (int c0 = lane; c0 <= P; c0 += 64) {
+                    const double *yr = yd + c0 * YDS;
+                    double e2 = xn2 + yr[DPAD];
+#pragma unroll
+                    for (int c = 0; c < DPAD; ++c) e2 = __builtin_fma(xs2[c], yr[c], e2);
+                    const double gv = exp2_p8(e2);
+                    Ubnd[c0] = gv; // scratch use of Ubnd (free during the forward sweep)
+                    if (GRAD) Gb32[c0] = (float)gv;
+                }
+                for (int c0 = lane; c0 < P; c0 += 64) Gbd[c0] = Ubnd[c0 + 1] - Ubnd[c0];
+            }
+            double cur = 1.0, diag = 1.0, gprev = 0.0, rdprev = 0.0;
+            const int nsteps = P + 1 + 64 + 2;
+            for (int s = 0; s < nsteps; ++s) {
+                const int c = s - lane;     // column of the static kernel evaluated now
+                const int q = c - 2;        // PDE column
+                const double g = Geval(c);
+                const double rd = g - gprev; // G[p,c] - G[p,c-1]
+                gprev = g;
+                double nb = s_shl(rd);       // lane l+1: G[p+1,c-1] - G[p+1,c-2]
+                if (lane == 63 && has_next && q >= 0 && q < P) nb = Gbd[q];
+                const double gq = nb - rdprev; // D[p, q]
+                rdprev = rd;
+                double up = s_shr(cur);
+                const bool act = pde_row && q >= 0 && q < P;
+                if (lane == 0) up = (kb == 0 || !act) ? 1.0 : Kbnd[q + 1];
+                if (act) {
+                    const double b = gq * gq * (1.0 / 12.0);
+                    const double aa = __builtin_fma(gq, 0.5, b);
+                    const double t = cur + up;
+                    double u = t - diag;
+                    u = __builtin_fma(t, aa, u);
+                    const double nw = __builtin_fma(diag, b, u);
+                    cur = nw;
+                    diag = up;
+                    if (lane == 63 && has_next) Kbnd[q + 1] = nw; // K[rb+64][q+1]
+                    if (p == P - 1) Klast[q + 1] = nw;            // K[P][q+1]
+                }
+            }
+            kfin[kb] = cur;
+            if (p == P - 1) {
+                Klast[0] = 1.0;
+                if (io64)
+                    static_cast<double *>(a.K)[(size_t)i * a.B + j] = cur;
+                else
+                    static_cast<float *>(a.K)[(size_t)i * a.B + j] = (float)cur;
+            }
+            if (lane == 63 && has_next) Kbnd[0] = 1.0;
+        }
+        if (!GRAD) continue;
+
+        // =============================== reverse sweep ===================================================
+        for (int kb = nbands - 1; kb >= 0; --kb) {
+            const int rb = kb * 64, p = rb + lane;
+            const bool pde_row = p < P;
+            const bool has_next = rb + 64 <= P;
+            load_x(p);
+            // (Gbd / Gb32 of the row beyond this band were filled by the forward sweep and are still valid)
+            // seeds: K[p][P] (row p, last column) = forward final value of the row above
+            double kcur = s_shr(kfin[kb]);
+            if (lane == 0) kcur = (kb == 0) ? 1.0 : __shfl(kfin[kb - 1], 63, 64);
+            {
+                const double kf_prev_band = (kb == 0) ? 1.0 : __shfl(kfin[kb - 1], 63, 64);
+                if (lane == 0) kcur = kf_prev_band;
+            }
+            double kddiag = kfin[kb];              // K[p+1][P]
+            double cur = 1.0, ddiag = 1.0;         // U[p][P], U[p+1][P]
+            double gprev = 0.0, rdprev = 0.0;      // G[p][c+1], previous row difference
+            float Sb = 0.f, Sc = 0.f, Nb = 0.f, s0 = 0.f;
+            float gh1 = 0.f, gh2 = 0.f;            // G[p][q+1], G[p][q+2] (fp32, for the contraction)
+            sf32x2 acc[DPAD / 2];
+#pragma unroll
+            for (int c = 0; c < DPAD / 2; ++c) acc[c] = sf32x2{0.f, 0.f};
+            const int sig_hi = P + 63; // first anti-diagonal on which some lane has a column <= P
+            for (int sigma = sig_hi; sigma >= -2; --sigma) {
+                const int q = sigma - lane; // static-kernel column evaluated now == PDE column
+                const double g = Geval(q);
+                const double rd = gprev - g; // G[p,q+1] - G[p,q]   (valid for 0 <= q < P)
+                gprev = g;
+                double nb = s_shl(rdprev);   // lane l+1 one step ago: G[p+1,q+1] - G[p+1,q]
+                const bool act = pde_row && q >= 0 && q < P;
+                if (lane == 63 && has_next && act) nb = Gbd[q];
+                rdprev = rd;
+                const double gq = nb - rd;   // D[p, q]
+                double down = s_shl(cur);    // U[p+1][q]
+                double kdown = s_shl(kcur);  // K[p+1][q]
+                if (act && (lane == 63 || p == P - 1)) {
+                    down = (p == P - 1) ? 1.0 : Ubnd[q];
+                    kdown = (p == P - 1) ? Klast[q] : Kbnd[q];
+                }
+                float Snew = 0.f;
+                if (act) {
+                    const double b = gq * gq * (1.0 / 12.0);
+                    const double aa = __builtin_fma(gq, 0.5, b);
+                    // U[p][q]
+                    const double t = cur + down;
+                    double u = t - ddiag;
+                    u = __builtin_fma(t, aa, u);
+                    const double nw = __builtin_fma(ddiag, b, u);
+                    // K[p][q] regenerated: ((K10 + K01)(1+a) - K11) / (1-b),  1/(1-b) = 1 + b + b^2 + O(b^3)
+                    const double kt = kdown + kcur;
+                    double ku = kt - kddiag;
+                    ku = __builtin_fma(kt, aa, ku);
+                    const double ib = __builtin_fma(b, b, b);
+                    double k00 = __builtin_fma(ku, ib, ku);
+                    if (p == 0) k00 = 1.0; // boundary row K[0][.] = 1 exactly
+                    Snew = (float)(k00 * ddiag); // K[p][q] * U[p+1][q+1]
+                    cur = nw;
+                    ddiag = down;
+                    kcur = k00;
+                    kddiag = kdown;
+                    if (lane == 0 && kb > 0) Ubnd[q] = nw; // U[rb][q] for the band above
+                    if (lane == 63 && has_next) Srow[q] = Snew;  // S[rb+63][q] for the row beyond the band
+                }
+                // lagged 4-corner scatter and row-side contraction (column n = q + 2)
+                const float Na = s_shr(Snew);
+                float dN = Na - Nb;
+                const float R = (Sc - Sb) + dN;
+                Sc = Sb;
+                Sb = Snew;
+                Nb = Na;
+                const float rg = R * gh2;
+                gh2 = gh1;
+                gh1 = (float)g;
+                const int n = min(max(q + 2, 0), P);
+                const sf32x2 *yr = reinterpret_cast<const sf32x2 *>(yf + n * YFS);
+                const sf32x2 rg2 = {rg, rg};
+                s0 += rg;
+#pragma unroll
+                for (int c = 0; c < DPAD / 2; ++c) acc[c] = __builtin_elementwise_fma(rg2, yr[c], acc[c]);
+            }
+#pragma unroll
+            for (int c = 0; c < DPAD; ++c) gacc[kb][c] += w_ij * m2h * (xf[c] * s0 - acc[c / 2][c % 2]);
+
+            if (has_next) {
+                // Row m' = rb+64 belongs to the band below but its 4-corner scatter also takes the last S row
+                // of THIS band: R'[m',n] = S[rb+63][n-1] - S[rb+63][n].  One dense pass over n (lanes = n).
+                const int mp = rb + 64;
+                float ps0 = 0.f, part[DPAD], xm[DPAD];
+#pragma unroll
+                for (int c = 0; c < DPAD; ++c) {
+                    part[c] = 0.f;
+                    xm[c] = (c < d) ? (float)(ldany(a.X, ((size_t)i * T + mp) * d + c, io64) - yref[c]) : 0.f;
+                }
+                for (int n = lane; n <= P; n += 64) {
+                    const float Sa = (n >= 1) ? Srow[n - 1] : 0.f;
+                    const float Sz = (n <= P - 1) ? Srow[n] : 0.f;
+                    const float rgn = (Sa - Sz) * Gb32[n];
+                    ps0 += rgn;
+#pragma unroll
+                    for (int c = 0; c < DPAD; ++c) part[c] = __builtin_fmaf(rgn, yf[n * YFS + c], part[c]);
+                }
+#pragma unroll
+                for (int c = 0; c < DPAD; ++c) {
+                    float v = w_ij * m2h * (xm[c] * ps0 - part[c]);
+#pragma unroll
+                    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+                    if (lane == 0 && c < d) unsafeAtomicAdd(&a.gacc[((size_t)i * T + mp) * d + c], (double)v);
+                }
+            }
+        }
+    }
+
+    if (GRAD && row_ok) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const int p = kb * 64 + lane;
+            if (p < T)
+#pragma unroll
+                for (int c = 0; c < DPAD; ++c)
+                    if (c < d) unsafeAtomicAdd(&a.gacc[((size_t)i * T + p) * d + c], (double)gacc[kb][c]);
+        }
+    }
+}
+
+template <typename IO>
+__global__ void stream_finalize_kernel(const double *gacc, IO *gradX, size_t n)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < n) gradX[idx] = (IO)gacc[idx];
+}
+
+bool stream_supported(int A, int B, int T, int d, int n, int kind, unsigned flags)
+{
+    (void)A; (void)B;
+    if (n != 0 || T < 65 || T > TMAX || d > 16) return false;
+    if (kind != SIGSVGD_STATIC_RBF) return false;
+    if (flags & SIGSVGD_FLAG_NAIVE_SOLVER) return false;
+    return true;
+}
+
+int stream_workspace_bytes(int A, int T, int d, int want_grad, size_t *bytes)
+{
+    *bytes = want_grad ? (size_t)A * T * d * sizeof(double) + 256 : 0;
+    return SIGSVGD_OK;
+}
+
+namespace {
+template <int DPAD>
+int stream_launch_variant(const GramProblem &p, StreamArgs &a, bool grad)
+{
+    const int ntile = (p.A + SNW - 1) / SNW;
+    int JC = 8;
+    while (JC > 1 && (long long)ntile * ((p.B + JC - 1) / JC) < 2048) JC >>= 1;
+    a.JC = JC;
+    dim3 grid((p.B + JC - 1) / JC, ntile), block(SNW * 64);
+    if (grad)
+        hipLaunchKernelGGL((gram_stream_kernel<DPAD, true>), grid, block, 0, p.stream, a);
+    else
+        hipLaunchKernelGGL((gram_stream_kernel<DPAD, false>), grid, block, 0, p.stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "launch gram_stream_kernel");
+    return SIGSVGD_OK;
+}
+} // namespace
+
+int stream_launch(const GramProblem &p)
+{
+    const bool grad = p.gradX_out != nullptr;
+    StreamArgs a;
+    a.X = p.X; a.Y = p.Y; a.go = p.grad_out; a.K = p.K_out; a.gacc = nullptr;
+    a.io64 = p.dtype == SIGSVGD_F64; a.A = p.A; a.B = p.B; a.T = p.T; a.d = p.d; a.JC = 1;
+    a.symw = (p.flags & SIGSVGD_FLAG_SYM) ? 1 : 0; a.inv_h = p.inv_h;
+    if (a.symw && p.A != p.B) {
+        set_error("sym backward needs A == B");
+        return SIGSVGD_E_BADARG;
+    }
+    const size_t nacc = (size_t)p.A * p.T * p.d;
+    if (grad) {
+        const size_t need = nacc * sizeof(double) + 256;
+        if (!p.ws || p.ws_bytes < need) {
+            set_error("stream: workspace %zu B < required %zu B", p.ws_bytes, need);
+            return SIGSVGD_E_WORKSPACE;
+        }
+        a.gacc = reinterpret_cast<double *>((reinterpret_cast<uintptr_t>(p.ws) + 255) & ~(uintptr_t)255);
+        hipError_t e = hipMemsetAsync(a.gacc, 0, nacc * sizeof(double), p.stream);
+        if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(gacc)");
+    }
+    int rc;
+    if (p.d <= 4)
+        rc = stream_launch_variant<4>(p, a, grad);
+    else if (p.d <= 8)
+        rc = stream_launch_variant<8>(p, a, grad);
+    else
+        rc = stream_launch_variant<16>(p, a, grad);
+    if (rc) return rc;
+    if (grad) {
+        const int bs = 256;
+        const unsigned gs = (unsigned)((nacc + bs - 1) / bs);
+        if (p.dtype == SIGSVGD_F64)
+            hipLaunchKernelGGL(stream_finalize_kernel<double>, dim3(gs), dim3(bs), 0, p.stream, a.gacc,
+                               static_cast<double *>(p.gradX_out), nacc);
+        else
+            hipLaunchKernelGGL(stream_finalize_kernel<float>, dim3(gs), dim3(bs), 0, p.stream, a.gacc,
+                               static_cast<float *>(p.gradX_out), nacc);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return hip_fail(e, "launch stream_finalize_kernel");
+    }
+    return SIGSVGD_OK;
+}
+
+} // namespace sigsvgd
