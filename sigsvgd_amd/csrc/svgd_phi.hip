@@ -4,75 +4,141 @@
 //
 // The N x N x D product is the only GEMM-shaped piece of the hot path and runs on the fp32 MFMA
 // (v_mfma_f32_16x16x4_f32: exact fp32 FMA chain, same numerics as the reference's fp32 matmul).
-// Tile: one workgroup of 4 wavefronts computes 64 rows x 32 columns; each wavefront owns a
-// 16 x 32 strip (two 16x16 accumulators).  K and score tiles are staged through LDS with 16-byte
-// global loads; k-step 32 per stage.
+// It is small (0.94 GFLOP at N=1024, D=448) and latency-bound, so the kernel is organised for
+// overlap rather than tile size: a workgroup of 4 wavefronts owns a 32 x 64 output tile (224
+// workgroups at C4: one per CU), every wavefront computes the whole tile over ITS quarter of each
+// 64-deep k stage (split-K inside the workgroup, combined through LDS at the end), global loads are
+// 16 B per lane and the next stage is fetched into registers while the current one is multiplied.
 #include "sig_common.h"
 
 namespace sigsvgd {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-constexpr int PM = 64;  // rows per workgroup
-constexpr int PN = 32;  // cols per workgroup
-constexpr int PK = 32;  // k per stage
-constexpr int KS = PK + 1; // padded LDS strides (floats)
-constexpr int SS = PN + 1;
+constexpr int PM = 32;  // rows per workgroup
+constexpr int PN = 64;  // cols per workgroup
+constexpr int PK = 64;  // k per stage (16 per wavefront)
+constexpr int KS = PK + 4; // LDS row strides (floats), padded: 16-B aligned, conflict-light
+constexpr int SS = PN + 16; // = 16 mod 32: the two k rows a 32-lane read touches land on disjoint banks
 
 __global__ __launch_bounds__(256) void svgd_phi_kernel(const float *__restrict__ K, const float *__restrict__ S,
                                                        const float *__restrict__ gk, const float *__restrict__ mask,
                                                        int N, int D, float *__restrict__ v_out,
                                                        const float *__restrict__ X_in, float *__restrict__ X_out, float lr)
 {
-    __shared__ float kt[PM * KS]; // K tile   [row][k]
-    __shared__ float st[PK * SS]; // score tile [k][col]
+    __shared__ __align__(16) float kt[PM * KS];     // K tile      [row][k]
+    __shared__ __align__(16) float st[PK * SS];     // score tile  [k][col]
+    __shared__ __align__(16) float red[3 * PM * PN]; // partial tiles of wavefronts 1..3
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row0 = blockIdx.y * PM, col0 = blockIdx.x * PN;
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    const bool vecK = (N % 4) == 0 && (reinterpret_cast<uintptr_t>(K) & 15) == 0;
+    const bool vecS = (D % 4) == 0 && (reinterpret_cast<uintptr_t>(S) & 15) == 0;
 
+    // this thread's share of a stage: K tile 32x64 = 512 float4 (2 per thread), score tile 64x64 = 1024 float4 (4)
+    f32x4 ka[2], sa[4];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = tid + u * 256, r = e / (PK / 4), c4 = (e % (PK / 4)) * 4;
+            const int gr = row0 + r, gc = k0 + c4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (gr < N) {
+                if (vecK && gc + 3 < N)
+                    v = *reinterpret_cast<const f32x4 *>(K + (size_t)gr * N + gc);
+                else
+#pragma unroll
+                    for (int x = 0; x < 4; ++x)
+                        if (gc + x < N) v[x] = K[(size_t)gr * N + gc + x];
+            }
+            ka[u] = v;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = tid + u * 256, r = e / (PN / 4), c4 = (e % (PN / 4)) * 4;
+            const int gr = k0 + r, gc = col0 + c4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (gr < N) {
+                if (vecS && gc + 3 < D)
+                    v = *reinterpret_cast<const f32x4 *>(S + (size_t)gr * D + gc);
+                else
+#pragma unroll
+                    for (int x = 0; x < 4; ++x)
+                        if (gc + x < D) v[x] = S[(size_t)gr * D + gc + x];
+            }
+            sa[u] = v;
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = tid + u * 256, r = e / (PK / 4), c4 = (e % (PK / 4)) * 4;
+            *reinterpret_cast<f32x4 *>(&kt[r * KS + c4]) = ka[u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = tid + u * 256, r = e / (PN / 4), c4 = (e % (PN / 4)) * 4;
+            *reinterpret_cast<f32x4 *>(&st[r * SS + c4]) = sa[u];
+        }
+    };
+
+    f32x4 acc[2][4]; // [row half][col quarter] 16x16 accumulators of this wavefront's k quarter
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    fetch(0);
     for (int k0 = 0; k0 < N; k0 += PK) {
-        // stage K[row0:row0+64, k0:k0+32]: 2048 floats, 8 per thread
-        for (int e = tid; e < PM * PK; e += 256) {
-            const int r = e / PK, c = e % PK;
-            const int gr = row0 + r, gc = k0 + c;
-            kt[r * KS + c] = (gr < N && gc < N) ? K[(size_t)gr * N + gc] : 0.f;
-        }
-        // stage score[k0:k0+32, col0:col0+32]: 1024 floats, 4 per thread
-        for (int e = tid; e < PK * PN; e += 256) {
-            const int r = e / PN, c = e % PN;
-            const int gr = k0 + r, gc = col0 + c;
-            st[r * SS + c] = (gr < N && gc < D) ? S[(size_t)gr * D + gc] : 0.f;
-        }
+        __syncthreads(); // previous stage fully consumed
+        stash();
         __syncthreads();
-        // A operand lane map (16x16x4): A[i = lane&15][k = lane>>4]; B[k = lane>>4][j = lane&15]
-        const int ai = wave * 16 + (lane & 15), kk = lane >> 4, bj = lane & 15;
+        if (k0 + PK < N) fetch(k0 + PK); // in flight during the MFMAs below
+        // A operand (16x16x4): A[i = lane&15][k = lane>>4]; B[k = lane>>4][j = lane&15]
+        const int kk = lane >> 4, ij = lane & 15, kw = wave * 16;
 #pragma unroll
-        for (int ks = 0; ks < PK; ks += 4) {
-            const float av = kt[ai * KS + ks + kk];
-            const float b0 = st[(ks + kk) * SS + bj];
-            const float b1 = st[(ks + kk) * SS + 16 + bj];
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1, acc1, 0, 0, 0);
-        }
-        __syncthreads();
-    }
-    // C/D map (16x16): col = lane&15, row = (lane>>4)*4 + reg
-    const float invN = 1.0f / (float)N;
+        for (int ks = 0; ks < 16; ks += 4) {
+            const float a0 = kt[ij * KS + kw + ks + kk];
+            const float a1 = kt[(16 + ij) * KS + kw + ks + kk];
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        const f32x4 a = half ? acc1 : acc0;
-#pragma unroll
-        for (int rgi = 0; rgi < 4; ++rgi) {
-            const int gr = row0 + wave * 16 + (lane >> 4) * 4 + rgi;
-            const int gc = col0 + half * 16 + (lane & 15);
-            if (gr < N && gc < D) {
-                const size_t idx = (size_t)gr * D + gc;
-                float v = -((a[rgi] - gk[idx]) * invN);
-                if (mask) v *= mask[idx];
-                v_out[idx] = v;
-                if (X_out) X_out[idx] = X_in[idx] - lr * v;
+            for (int b = 0; b < 4; ++b) {
+                const float bv = st[(kw + ks + kk) * SS + b * 16 + ij];
+                acc[0][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bv, acc[0][b], 0, 0, 0);
+                acc[1][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bv, acc[1][b], 0, 0, 0);
             }
         }
+    }
+    // combine the four k-quarters: C/D map (16x16): col = lane&15, row = (lane>>4)*4 + reg
+    __syncthreads();
+    if (wave > 0) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    red[(wave - 1) * PM * PN + (a * 16 + (lane >> 4) * 4 + r) * PN + b * 16 + (lane & 15)] = acc[a][b][r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const float invN = 1.0f / (float)N;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int lr_ = a * 16 + (lane >> 4) * 4 + r, lc = b * 16 + (lane & 15);
+                    const int gr = row0 + lr_, gc = col0 + lc;
+                    if (gr < N && gc < D) {
+                        const float s = ((acc[a][b][r] + red[lr_ * PN + lc]) + red[PM * PN + lr_ * PN + lc]) +
+                                        red[2 * PM * PN + lr_ * PN + lc];
+                        const size_t idx = (size_t)gr * D + gc;
+                        float v = -((s - gk[idx]) * invN);
+                        if (mask) v *= mask[idx];
+                        v_out[idx] = v;
+                        if (X_out) X_out[idx] = X_in[idx] - lr * v;
+                    }
+                }
     }
 }
 
