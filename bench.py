@@ -184,9 +184,10 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             # HBM-side bytes per launch from rocprofv3 PMC passes (profiles/r01_pmc_hbm_traffic.csv):
-            # FETCH_SIZE 8.5 MB + WRITE_SIZE 1167 MB; the write side is the ~60 M fp64 atomics of the
-            # cross-workgroup gradient reduction (counted ~19.5 B each), not re-reads; 1.3 % of kernel time
-            "traffic": 8.5e6 + 1.167e9,
+            # FETCH_SIZE 162 MB + WRITE_SIZE 1260 MB.  Both are the ~29 M fp64 atomics of the column-side
+            # gradient reduction (448 per row tile and column, executed at the memory side and counted
+            # ~43 B written / ~5 B fetched each), not re-reads of inputs; they cost ~1.3 % of kernel time
+            "traffic": 162e6 + 1.26e9,
             "algorithmic_bytes_per_launch": by,
             "avg_launch_ms": k_ms,
             "median_launch_ms": ms[len(ms) // 2],

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SIGSVGD_ABI_VERSION 1
+#define SIGSVGD_ABI_VERSION 2
 
 /* dtype */
 #define SIGSVGD_F32 0
@@ -88,11 +88,12 @@ int sigsvgd_gram_fwd_bwd(const void *X, const void *Y, int A, int B, int T, int 
  *   K_partial[N,N]      (dtype)  both orientations K[i,j], K[j,i] of every owned pair, 0 elsewhere
  *   grad_partial[N,T,d] (fp64)   this rank's share of d sum(grad_out*K)/dX (row- and column-side)
  * Summing the buffers over tile_offset = 0..tile_stride-1 gives exactly sigsvgd_gram_fwd_bwd's
- * outputs.  Only the register-resident shapes (dyadic_order 0, 3 <= T <= 64, d <= 16, RBF). */
+ * outputs.  Only the register-resident shapes (dyadic_order 0, 3 <= T <= 64, d <= 16, RBF).
+ * `workspace` as sized by sigsvgd_gram_workspace_bytes(N, N, T, d, 0, 1, SIGSVGD_FLAG_Y_IS_X) (work queue). */
 int sigsvgd_gram_sym_partial(const void *X, int N, int T, int d, int dtype, double inv_h,
                              int static_kind, unsigned flags, int tile_offset, int tile_stride,
                              const void *grad_out, void *K_partial, double *grad_partial,
-                             void *stream);
+                             void *workspace, size_t workspace_bytes, void *stream);
 
 /* v_out[N,D] = -((K[N,N] @ score[N,D] - grad_k[N,D]) / N) * (mask ? mask[N,D] : 1)   (fp32)
  * If X_in and X_out are non-NULL additionally X_out = X_in - lr * v_out (optimizer=None update).

@@ -21,7 +21,7 @@ HEADERS = [os.path.join(_CSRC, "sig_common.h"), os.path.join(_PKG, "..", "includ
 F32, F64 = 0, 1
 STATIC_RBF, STATIC_LINEAR = 0, 1
 FLAG_NAIVE_SOLVER, FLAG_SYM, FLAG_Y_IS_X, FLAG_FORCE_GENERIC = 1, 2, 4, 8
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 EXPORTS = [
     "sigsvgd_abi_version",
@@ -91,7 +91,7 @@ def load():
     L.sigsvgd_gram_fwd_bwd.restype = ci
     L.sigsvgd_gram_fwd_bwd.argtypes = [vp, vp, ci, ci, ci, ci, ci, cd, ci, ci, cu, vp, vp, vp, vp, ctypes.c_size_t, vp]
     L.sigsvgd_gram_sym_partial.restype = ci
-    L.sigsvgd_gram_sym_partial.argtypes = [vp, ci, ci, ci, ci, cd, ci, cu, ci, ci, vp, vp, vp, vp]
+    L.sigsvgd_gram_sym_partial.argtypes = [vp, ci, ci, ci, ci, cd, ci, cu, ci, ci, vp, vp, vp, vp, ctypes.c_size_t, vp]
     L.sigsvgd_svgd_phi.restype = ci
     L.sigsvgd_svgd_phi.argtypes = [vp, vp, vp, vp, ci, ci, vp, vp, vp, cf, vp]
     if L.sigsvgd_abi_version() != ABI_VERSION:

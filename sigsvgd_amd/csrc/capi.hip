@@ -123,7 +123,8 @@ int sigsvgd_gram_fwd_bwd(const void *X, const void *Y, int A, int B, int T, int 
 
 int sigsvgd_gram_sym_partial(const void *X, int N, int T, int d, int dtype, double inv_h, int static_kind,
                              unsigned flags, int tile_offset, int tile_stride, const void *grad_out,
-                             void *K_partial, double *grad_partial, void *stream)
+                             void *K_partial, double *grad_partial, void *workspace, size_t workspace_bytes,
+                             void *stream)
 {
     int rc = check_common(X, X, N, N, T, d, dtype, inv_h, 0, static_kind, K_partial);
     if (rc) return rc;
@@ -132,7 +133,7 @@ int sigsvgd_gram_sym_partial(const void *X, int N, int T, int d, int dtype, doub
         return SIGSVGD_E_BADARG;
     }
     GramProblem p{X, X, N, N, T, d, dtype, inv_h, 0, static_kind, flags | SIGSVGD_FLAG_Y_IS_X, grad_out,
-                  K_partial, grad_partial, nullptr, 0, static_cast<hipStream_t>(stream)};
+                  K_partial, grad_partial, workspace, workspace_bytes, static_cast<hipStream_t>(stream)};
     return fast_sym_partial(p, tile_offset, tile_stride, grad_partial);
 }
 

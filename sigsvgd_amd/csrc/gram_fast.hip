@@ -34,6 +34,8 @@ struct FastArgs {
     double *gacc; // [A][T][d] fp64 accumulation buffer (zeroed by the launcher)
     int io64, A, B, T, d, JC, symw;
     int tile_offset, tile_stride; // row tiles owned by this launch: offset + k*stride (multi-GPU sharding)
+    int owned;                    // number of owned row tiles
+    int *queue;                   // [owned] next-chunk counters (zeroed by the launcher)
     double inv_h;
 };
 
@@ -151,46 +153,23 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int T = a.T, d = a.d, P = T - 1, io64 = a.io64;
-    // Block -> (row tile, column chunk).  Symmetric launches enumerate only the chunks that reach the
-    // diagonal of their row tile (a 1-D grid of real work: no early-exit workgroups, which would each
-    // have to wait for a CU with all 160 KB of LDS free just to return).
-    int itile, jchunk;
-    if (SYM) {
-        const int nJ = (a.B + a.JC - 1) / a.JC;
-        int rem = blockIdx.x, k = 0;
-        for (;; ++k) {
-            const int t = k * a.tile_stride + a.tile_offset;
-            const int cnt = nJ - (t * NW) / a.JC; // chunks c >= floor(t*NW/JC) touch or cross the diagonal
-            if (rem < cnt) {
-                itile = t;
-                jchunk = (t * NW) / a.JC + rem;
-                break;
-            }
-            rem -= cnt;
-        }
-    } else {
-        itile = blockIdx.y * a.tile_stride + a.tile_offset;
-        jchunk = blockIdx.x;
-    }
-    const int j0 = jchunk * a.JC;
-    const int j1 = min(a.B, j0 + a.JC);
-    const int i = itile * NW + wave;
-    const bool row_ok = i < a.A;
+    // Work distribution: a persistent grid (one workgroup per CU) pulls column chunks from per-row-tile
+    // counters.  A workgroup STAYS on a row tile while chunks remain there, so the per-lane row-side
+    // gradient accumulators live in registers across all of them and are flushed (one fp64 atomic per
+    // element) only when the workgroup leaves the tile -- ~10x fewer reduction atomics than one flush per
+    // chunk, and chunks can be short (fine-grained balance; the 1/G launches of the sharded step stay
+    // full).  Symmetric launches enumerate only the chunks that reach the diagonal of the row tile.
+    __shared__ int s_item;
+    const int nJ = (a.B + a.JC - 1) / a.JC;
+    int i = 0, j0 = 0, j1 = 0;
+    bool row_ok = false;
     const int lane_q = (lane < P) ? lane : 0x40000000; // rows without PDE cells never pass the range test below
     float *Gs = Gs_all + (GRAD ? wave * GS_WAVE : 0);
     const double inv_h = a.inv_h;
     const float m2h = (float)(-2.0 * inv_h);
 
-    // per-lane fp64 accumulators of d sum_j w_ij k(x_i, y_j) / d x_i[lane, c]
-    double gacc[DPAD];
-#pragma unroll
-    for (int c = 0; c < DPAD; ++c) gacc[c] = 0.0;
-
-    // raw row of x_i owned by this lane (fp64 copy of the fp32/fp64 input; exact)
-    double xraw[DPAD];
-#pragma unroll
-    for (int c = 0; c < DPAD; ++c)
-        xraw[c] = (row_ok && lane < T && c < d) ? load_any(a.X, ((size_t)i * T + lane) * d + c, io64) : 0.0;
+    double gacc[DPAD]; // per-lane fp64 accumulators of d sum_j w_ij k(x_i, y_j) / d x_i[lane, c]
+    double xraw[DPAD]; // raw row of x_i owned by this lane (fp64 copy of the fp32/fp64 input; exact)
 
     // ---- staging of column trajectory y_j: element e -> (t = e / DPAD, c = e % DPAD) -------------
     constexpr int EPT = (64 * DPAD + NT - 1) / NT; // elements per thread
@@ -231,6 +210,54 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
         }
     };
 
+    // Tile search: wave 0 looks at 64 tile counters at a time (one coalesced load + ballot) for a tile that
+    // still has chunks; a full lap without a hit means the launch is drained.
+    int kq = blockIdx.x % a.owned;
+    for (int scanned = 0; scanned < a.owned;) {
+    __syncthreads();
+    if (wave == 0) {
+        int kk = kq + lane;
+        if (kk >= a.owned) kk -= a.owned;
+        bool has = false;
+        if (lane < a.owned - scanned && kk < a.owned) {
+            const int tt = kk * a.tile_stride + a.tile_offset;
+            const int cn = nJ - (SYM ? (tt * NW) / a.JC : 0);
+            has = __hip_atomic_load(&a.queue[kk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < cn;
+        }
+        const unsigned long long m = __ballot(has);
+        if (lane == 0) s_item = m ? (int)__builtin_ctzll(m) : -1;
+    }
+    __syncthreads();
+    const int hit = s_item;
+    if (hit < 0) { // none of the next 64 tiles has work
+        scanned += 64;
+        kq += 64;
+        if (kq >= a.owned) kq %= a.owned;
+        continue;
+    }
+    kq += hit;
+    if (kq >= a.owned) kq -= a.owned;
+    scanned = 0;
+    const int itile = kq * a.tile_stride + a.tile_offset;
+    const int cfirst = SYM ? (itile * NW) / a.JC : 0; // first chunk that touches or crosses the diagonal
+    const int cnt = nJ - cfirst;
+    i = itile * NW + wave;
+    row_ok = i < a.A;
+#pragma unroll
+    for (int c = 0; c < DPAD; ++c) {
+        gacc[c] = 0.0;
+        xraw[c] = (row_ok && lane < T && c < d) ? load_any(a.X, ((size_t)i * T + lane) * d + c, io64) : 0.0;
+    }
+    bool worked = false;
+    for (;;) {
+    __syncthreads(); // s_item (and the staging buffers) are free again
+    if (tid == 0) s_item = atomicAdd(&a.queue[kq], 1);
+    __syncthreads();
+    const int cidx = s_item;
+    if (cidx >= cnt) break;
+    worked = true;
+    j0 = (cfirst + cidx) * a.JC;
+    j1 = min(a.B, j0 + a.JC);
     stage_load(j0);
     stage_store();
     __syncthreads();
@@ -473,11 +500,15 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
         __syncthreads();
     }
 
-    if (GRAD && row_ok && lane < T) {
+    } // chunks of this row tile
+
+    if (GRAD && worked && row_ok && lane < T) {
 #pragma unroll
         for (int c = 0; c < DPAD; ++c)
             if (c < d) unsafeAtomicAdd(&a.gacc[((size_t)i * T + lane) * d + c], gacc[c]);
     }
+    kq = (kq + 1 == a.owned) ? 0 : kq + 1; // this tile is drained: search on from the next one
+    } // row tiles
 }
 
 template <typename IO>
@@ -497,10 +528,14 @@ bool fast_supported(int A, int B, int T, int d, int n, int kind, unsigned flags)
     return true;
 }
 
+namespace {
+inline size_t queue_bytes(int A) { return ((size_t)(A + 3) / 4 + 1) * sizeof(int) + 256; } // >= one int per row tile
+}
+
 int fast_workspace_bytes(int A, int B, int T, int d, int want_grad, unsigned flags, size_t *bytes)
 {
     (void)B; (void)flags;
-    *bytes = want_grad ? (size_t)A * T * d * sizeof(double) + 256 : 0;
+    *bytes = (want_grad ? (size_t)A * T * d * sizeof(double) + 256 : 0) + queue_bytes(A);
     return SIGSVGD_OK;
 }
 
@@ -520,19 +555,18 @@ int launch_variant(const GramProblem &p, FastArgs &a, bool grad, bool sym)
             total += sym ? nJ - ((k * a.tile_stride + a.tile_offset) * NW) / jc : nJ;
         return total;
     };
-    // Column chunk: one workgroup per CU is resident (LDS), so the launch runs in ceil(nblocks/256)
-    // rounds and the last one is partly empty; longer chunks amortise the per-workgroup gradient flush
-    // (~3 % of a chunk of 8 at C4).  Pick the chunk with the best modelled efficiency.
-    int JC = 1;
-    double best = -1.0;
-    for (int jc = 16; jc >= 1; jc >>= 1) {
-        const double rounds = (double)nblocks(jc) / 256.0;
-        const double eff = rounds / __builtin_ceil(rounds) / (1.0 + 0.25 / jc);
-        if (eff > best + 1e-9) { best = eff; JC = jc; }
-    }
+    // Column chunk: chunks are pulled from a queue, so short ones cost only their staging prologue
+    // (~1 % at 4 columns) and buy fine-grained balance; tiny problems go down to single columns.
+    int JC = 4;
+    while (JC > 1 && nblocks(JC) < 256 * 8) JC >>= 1;
     a.JC = JC;
-    dim3 grid((p.B + JC - 1) / JC, owned);
-    if (sym) grid = dim3((unsigned)nblocks(JC), 1); // 1-D grid of real work only
+    a.owned = owned;
+    // the queue lives behind the fp64 accumulation buffer in the caller's workspace
+    hipError_t qe = hipMemsetAsync(a.queue, 0, (size_t)owned * sizeof(int), p.stream);
+    if (qe != hipSuccess) return hip_fail(qe, "hipMemsetAsync(queue)");
+    const long long total = nblocks(JC);
+    const long long resident = 256LL * (grad ? 1 : 3); // workgroups the chip holds at once (LDS / VGPR bound)
+    dim3 grid((unsigned)(total < resident ? total : resident), 1);
     dim3 block(NW * 64);
     if (!grad)
         hipLaunchKernelGGL((gram_fast_kernel<DPAD, NW, false, false>), grid, block, 0, p.stream, a);
@@ -554,22 +588,27 @@ int fast_launch(const GramProblem &p)
     a.X = p.X; a.Y = p.Y; a.go = p.grad_out; a.K = p.K_out;
     a.io64 = p.dtype == SIGSVGD_F64; a.A = p.A; a.B = p.B; a.T = p.T; a.d = p.d;
     a.symw = (p.flags & SIGSVGD_FLAG_SYM) ? 1 : 0; a.inv_h = p.inv_h; a.JC = 1;
-    a.tile_offset = 0; a.tile_stride = 1;
+    a.tile_offset = 0; a.tile_stride = 1; a.owned = 1; a.queue = nullptr;
     a.gacc = nullptr;
     if (a.symw && p.A != p.B) {
         set_error("sym backward needs A == B");
         return SIGSVGD_E_BADARG;
     }
     const size_t nacc = (size_t)p.A * p.T * p.d;
-    if (grad) {
-        const size_t need = nacc * sizeof(double) + 256;
+    {
+        const size_t need = (grad ? nacc * sizeof(double) + 256 : 0) + queue_bytes(p.A);
         if (!p.ws || p.ws_bytes < need) {
             set_error("fast: workspace %zu B < required %zu B", p.ws_bytes, need);
             return SIGSVGD_E_WORKSPACE;
         }
-        a.gacc = reinterpret_cast<double *>((reinterpret_cast<uintptr_t>(p.ws) + 255) & ~(uintptr_t)255);
-        hipError_t e = hipMemsetAsync(a.gacc, 0, nacc * sizeof(double), p.stream);
-        if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(gacc)");
+        unsigned char *base = reinterpret_cast<unsigned char *>((reinterpret_cast<uintptr_t>(p.ws) + 255) & ~(uintptr_t)255);
+        if (grad) {
+            a.gacc = reinterpret_cast<double *>(base);
+            hipError_t e = hipMemsetAsync(a.gacc, 0, nacc * sizeof(double), p.stream);
+            if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(gacc)");
+            base += nacc * sizeof(double);
+        }
+        a.queue = reinterpret_cast<int *>(base);
     }
     int rc;
     if (!grad && p.d <= 4) // forward only: no G image, <=168 VGPRs -> 4-wave workgroups pack 3 waves per SIMD
@@ -615,8 +654,13 @@ int fast_sym_partial(const GramProblem &p, int tile_offset, int tile_stride, dou
     a.X = p.X; a.Y = p.X; a.go = p.grad_out; a.K = p.K_out;
     a.io64 = p.dtype == SIGSVGD_F64; a.A = p.A; a.B = p.B; a.T = p.T; a.d = p.d;
     a.symw = (p.flags & SIGSVGD_FLAG_SYM) ? 1 : 0; a.inv_h = p.inv_h; a.JC = 1;
-    a.tile_offset = tile_offset; a.tile_stride = tile_stride;
+    a.tile_offset = tile_offset; a.tile_stride = tile_stride; a.owned = 1;
     a.gacc = grad_partial;
+    if (!p.ws || p.ws_bytes < queue_bytes(p.A)) {
+        set_error("sym_partial: workspace %zu B < required %zu B", p.ws_bytes, queue_bytes(p.A));
+        return SIGSVGD_E_WORKSPACE;
+    }
+    a.queue = reinterpret_cast<int *>((reinterpret_cast<uintptr_t>(p.ws) + 255) & ~(uintptr_t)255);
     if (p.d <= 4) return launch_variant<4, 8>(p, a, true, true);
     if (p.d <= 8) return launch_variant<8, 8>(p, a, true, true);
     return launch_variant<16, 4>(p, a, true, true);

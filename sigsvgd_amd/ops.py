@@ -191,10 +191,14 @@ def gram_sym_partial(X, inv_h: float, tile_offset: int, tile_stride: int, static
         go = grad_out.detach().to(Xc.dtype).contiguous()
     Kp = torch.zeros((N, N), dtype=Xc.dtype, device=dev)
     gp = torch.zeros((N, T, d), dtype=torch.float64, device=dev)
+    flags = _flags(False, sym, True, False)
+    nbytes = ctypes.c_size_t(0)
+    _lib.check(L.sigsvgd_gram_workspace_bytes(N, N, T, d, 0, 1, flags, ctypes.byref(nbytes)), "gram_workspace_bytes")
+    ws, wsn = _workspace(dev, nbytes.value)
     with torch.cuda.device(dev):
         rc = L.sigsvgd_gram_sym_partial(Xc.data_ptr(), N, T, d, _io_dtype(Xc), float(inv_h), int(static_kind),
-                                        _flags(False, sym, True, False), int(tile_offset), int(tile_stride),
+                                        flags, int(tile_offset), int(tile_stride),
                                         go.data_ptr() if go is not None else None, Kp.data_ptr(), gp.data_ptr(),
-                                        _stream_ptr(dev))
+                                        ws.data_ptr() if ws is not None else None, wsn, _stream_ptr(dev))
     _lib.check(rc, "gram_sym_partial")
     return Kp, gp
