@@ -107,3 +107,53 @@ def test_fast_c4_rows(gpu):
         Kref, gref = C.gram_fwd_bwd(X.numpy(), X.numpy(), 1.0, 0, rows=rows)
         assert _rel(Kn[rows[0]:rows[1]], Kref) < TOL
         assert np.abs(gn[rows[0]:rows[1]] - gref).max() / np.abs(gref).max() < TOL
+
+
+@pytest.mark.parametrize("A,B,T,d", [(1, 1, 64, 7), (1, 9, 17, 2), (9, 1, 64, 8), (11, 11, 3, 16), (23, 23, 64, 5)])
+def test_fast_edge_shapes(gpu, A, B, T, d):
+    """single rows/columns, ragged row tiles, exact-fit channel padding (d = 8, 16)"""
+    from sigsvgd_amd import ops
+
+    X, Y = _paths(A, T, d, 21), _paths(B, T, d, 22)
+    Kref, gref = C.gram_fwd_bwd(X, Y, 0.8, 0)
+    Xg, Yg = torch.as_tensor(X, device=gpu), torch.as_tensor(Y, device=gpu)
+    K, g = ops.gram_fwd_bwd(Xg, Yg, 1 / 0.8)
+    assert _rel(K.cpu().numpy(), Kref) < TOL and _rel(g.cpu().numpy(), gref) < TOL
+    if A == B:
+        Kr, gr = C.gram_fwd_bwd(X, X, 0.8, 0)
+        K2, g2 = ops.gram_fwd_bwd(Xg, Xg, 1 / 0.8, y_is_x=True)
+        assert _rel(K2.cpu().numpy(), Kr) < TOL and _rel(g2.cpu().numpy(), gr) < TOL
+
+
+def test_fast_fp64_io_symmetric_and_noncontiguous(gpu):
+    """fp64 particles (what the reference's callers hand to compute_Gram) through the symmetric path,
+    and a non-contiguous view as input"""
+    from sigsvgd_amd import ops
+
+    Xbig = torch.as_tensor(_paths(20, 64, 14, 31), device=gpu).double()
+    Xv = Xbig[:, :, ::2]  # [20, 64, 7] strided view
+    assert not Xv.is_contiguous()
+    Kref, gref = O.gram_backward(Xv.cpu().numpy(), Xv.cpu().numpy(), None, O.RBF, 1.0, 0)
+    K, g = ops.gram_fwd_bwd(Xv, Xv, 1.0, y_is_x=True)
+    assert K.dtype == torch.float64 and g.dtype == torch.float64
+    assert _rel(K.cpu().numpy(), Kref) < 1e-6 and _rel(g.cpu().numpy(), gref) < TOL
+
+
+def test_argument_errors(gpu):
+    from sigsvgd_amd import ops
+
+    x = torch.zeros(4, 10, 3, device=gpu)
+    with pytest.raises(ValueError):
+        ops.gram_fwd(x, torch.zeros(4, 9, 3, device=gpu), 1.0)      # ragged path lengths
+    with pytest.raises(ValueError):
+        ops.gram_fwd(x, torch.zeros(4, 10, 2, device=gpu), 1.0)     # channel mismatch
+    with pytest.raises(ValueError):
+        ops.gram_fwd(x[:0], x, 1.0)                                  # empty batch
+    with pytest.raises(ValueError):
+        ops.gram_fwd(x[:, :1], x[:, :1], 1.0)                        # single-point paths
+    with pytest.raises(ValueError):
+        ops.gram_fwd_bwd(x, x, 1.0, grad_out=torch.zeros(3, 4, device=gpu))
+    with pytest.raises(TypeError):
+        ops.gram_fwd(x.half(), x.half(), 1.0)
+    with pytest.raises(RuntimeError, match="inv_h"):
+        ops.gram_fwd(x, x, -1.0)
