@@ -14,6 +14,11 @@
  *   sigsvgd_svgd_phi       SVGD._velocity dense part: v = -((K @ score - grad_k)/N) [* mask]
  *                          src/inference/svgd.py:82-83, src/inference/trajectory_svgd.py:84
  *                          optionally fused with the optimizer=None update X - lr*v (svgd.py:115)
+ *   sigsvgd_vec_sqdist     src/utils/math.py:69-86 pw_dist_sq, :116-144 scaled_pw_dist_sq
+ *   sigsvgd_vec_kernel     src/kernels/_kernels.py:64-299 GaussianKernel / ScaledGaussianKernel /
+ *                          IMQKernel / ScaledIMQKernel: K and d_K.sum(1) without the [A,B,D] tensor
+ *   sigsvgd_signature      signatory.signature(path, depth, basepoint) [third-party, absent] as
+ *                          called by PathSigKernel, src/kernels/_traj_kernels.py:124-125
  *
  * Conventions
  *   - all pointers are DEVICE pointers (HIP), row-major contiguous; the caller owns every buffer
@@ -36,7 +41,7 @@
 extern "C" {
 #endif
 
-#define SIGSVGD_ABI_VERSION 2
+#define SIGSVGD_ABI_VERSION 3
 
 /* dtype */
 #define SIGSVGD_F32 0
@@ -45,6 +50,12 @@ extern "C" {
 /* static kernel kinds */
 #define SIGSVGD_STATIC_RBF 0    /* k(x,y) = exp(-|x-y|^2 * inv_h)   (reference: exp(-dist/h)) */
 #define SIGSVGD_STATIC_LINEAR 1 /* k(x,y) = <x,y>                                              */
+
+/* vector kernels (sigsvgd_vec_kernel) */
+#define SIGSVGD_VEC_GAUSSIAN 0 /* k = exp(-sq / (2 h^2))          src/kernels/_kernels.py:106 */
+#define SIGSVGD_VEC_IMQ 1      /* k = (1 + sq / (2 h^2))^(-1/2)     src/kernels/_kernels.py:229-230 */
+#define SIGSVGD_VEC_UNIT 2     /* k = sq, w = 1: dK = grad_scale * sum_j grad_out_ij (XM_i - YM_j),
+                                  the adjoint of sigsvgd_vec_sqdist (autograd through the distance) */
 
 /* flags */
 #define SIGSVGD_FLAG_NAIVE_SOLVER 1u /* first-order stencil (sigkernel _naive_solver=True)      */
@@ -101,6 +112,32 @@ int sigsvgd_gram_sym_partial(const void *X, int N, int T, int d, int dtype, doub
 int sigsvgd_svgd_phi(const float *K, const float *score, const float *grad_k, const float *mask,
                      int N, int D, float *v_out, const float *X_in, float *X_out, float lr,
                      void *stream);
+
+/* ---- vector kernels on particles X[A,D], Y[B,D] ---------------------------------
+ * sq[i,j] = max(0, sum_c (XM[i,c] - YM[j,c]) * (X[i,c] - Y[j,c])).  XM = X @ M, YM = Y @ M for a metric
+ * M[D,D] (scaled_pw_dist_sq); XM = YM = NULL means M = I, i.e. |x_i - y_j|^2 (pw_dist_sq).  Arithmetic
+ * in `dtype`.  Differences are formed directly, so sq >= 0 up to rounding and the clamp is a no-op. */
+int sigsvgd_vec_sqdist(const void *X, const void *Y, const void *XM, const void *YM, int A, int B, int D,
+                       int dtype, void *sq_out, void *stream);
+
+/* From sq[A,B]:  K_out[i,j] = f(sq[i,j])  (kind: SIGSVGD_VEC_GAUSSIAN / SIGSVGD_VEC_IMQ, inv_h2 = 1/h^2)
+ * and, if dK_out != NULL,
+ *   dK_out[i,c] = grad_scale * sum_j (grad_out ? grad_out[i,j] : 1) * w(sq[i,j]) * (XM[i,c] - YM[j,c]),
+ * w = f for the Gaussian, f^3 = (1 + sq/(2h^2))^(-3/2) for the IMQ: the reference's `d_K.sum(1)`
+ * with grad_scale = -1/h^2 (Gaussian kernels), +1/(2h^2) (IMQKernel: its (Y - X) sign convention,
+ * _kernels.py:232) or -1/(2h^2) (ScaledIMQKernel, _kernels.py:297).  For M = I pass XM = X, YM = Y.
+ * K_out may be NULL when only the gradient is wanted (it must be with SIGSVGD_VEC_UNIT). */
+int sigsvgd_vec_kernel(const void *sq, const void *XM, const void *YM, const void *grad_out, int A, int B,
+                       int D, int dtype, int kind, double inv_h2, double grad_scale, void *K_out,
+                       void *dK_out, void *stream);
+
+/* ---- truncated path signature ----------------------------------------------------
+ * out[N, C + C^2 + ... + C^depth] = signature of the piecewise-linear path X[N,L,C] (levels
+ * concatenated, each level row-major), with a zero point prepended when basepoint != 0.  Chen's
+ * identity, fp64 accumulation, I/O in `dtype`.  *channels (if non-NULL) receives the output width;
+ * with out == NULL only that query is performed. */
+int sigsvgd_signature(const void *X, int N, int L, int C, int depth, int basepoint, int dtype, void *out,
+                      long long *channels, void *stream);
 
 #ifdef __cplusplus
 }

@@ -14,14 +14,15 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_PKG, "csrc")
 # SIGSVGD_LIB_PATH: A/B benchmarking of two builds on the same GPU box (scripts/ab.py); never set in tests
 LIB_PATH = os.environ.get("SIGSVGD_LIB_PATH") or os.path.join(_PKG, "libsigsvgd_hip.so")
-SOURCES = ["capi.hip", "gram_generic.hip", "gram_fast.hip", "gram_stream.hip", "svgd_phi.hip"]
+SOURCES = ["capi.hip", "gram_generic.hip", "gram_fast.hip", "gram_stream.hip", "svgd_phi.hip", "vec_kernels.hip"]
 HEADERS = [os.path.join(_CSRC, "sig_common.h"), os.path.join(_PKG, "..", "include", "sigsvgd_hip.h")]
 
 # mirror of include/sigsvgd_hip.h
 F32, F64 = 0, 1
 STATIC_RBF, STATIC_LINEAR = 0, 1
 FLAG_NAIVE_SOLVER, FLAG_SYM, FLAG_Y_IS_X, FLAG_FORCE_GENERIC = 1, 2, 4, 8
-ABI_VERSION = 2
+VEC_GAUSSIAN, VEC_IMQ, VEC_UNIT = 0, 1, 2
+ABI_VERSION = 3
 
 EXPORTS = [
     "sigsvgd_abi_version",
@@ -31,6 +32,9 @@ EXPORTS = [
     "sigsvgd_gram_fwd_bwd",
     "sigsvgd_gram_sym_partial",
     "sigsvgd_svgd_phi",
+    "sigsvgd_vec_sqdist",
+    "sigsvgd_vec_kernel",
+    "sigsvgd_signature",
 ]
 
 _lib = None
@@ -94,6 +98,12 @@ def load():
     L.sigsvgd_gram_sym_partial.argtypes = [vp, ci, ci, ci, ci, cd, ci, cu, ci, ci, vp, vp, vp, vp, ctypes.c_size_t, vp]
     L.sigsvgd_svgd_phi.restype = ci
     L.sigsvgd_svgd_phi.argtypes = [vp, vp, vp, vp, ci, ci, vp, vp, vp, cf, vp]
+    L.sigsvgd_vec_sqdist.restype = ci
+    L.sigsvgd_vec_sqdist.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp, vp]
+    L.sigsvgd_vec_kernel.restype = ci
+    L.sigsvgd_vec_kernel.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, cd, cd, vp, vp, vp]
+    L.sigsvgd_signature.restype = ci
+    L.sigsvgd_signature.argtypes = [vp, ci, ci, ci, ci, ci, ci, vp, ctypes.POINTER(ctypes.c_longlong), vp]
     if L.sigsvgd_abi_version() != ABI_VERSION:
         raise RuntimeError("sigsvgd_amd: libsigsvgd_hip.so ABI version mismatch; rebuild it")
     _lib = L

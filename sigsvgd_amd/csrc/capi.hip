@@ -25,6 +25,14 @@ int hip_fail(hipError_t e, const char *what)
 int phi_launch(const float *K, const float *score, const float *grad_k, const float *mask, int N, int D,
                float *v_out, const float *X_in, float *X_out, float lr, hipStream_t stream);
 
+int vec_sqdist_launch(const void *X, const void *Y, const void *XM, const void *YM, int A, int B, int D, int dtype,
+                      void *sq, hipStream_t stream);
+int vec_kgrad_launch(const void *sq, const void *XM, const void *YM, const void *go, int A, int B, int D, int dtype,
+                     int kind, double inv_h2, double grad_scale, void *K, void *dK, hipStream_t stream);
+long long signature_channels(int C, int depth);
+int signature_launch(const void *X, int N, int L, int C, int depth, int basepoint, int dtype, void *out,
+                     hipStream_t stream);
+
 static int check_common(const void *X, const void *Y, int A, int B, int T, int d, int dtype, double inv_h,
                         int n, int kind, const void *K_out)
 {
@@ -141,6 +149,72 @@ int sigsvgd_svgd_phi(const float *K, const float *score, const float *grad_k, co
                      float *v_out, const float *X_in, float *X_out, float lr, void *stream)
 {
     return phi_launch(K, score, grad_k, mask, N, D, v_out, X_in, X_out, lr, static_cast<hipStream_t>(stream));
+}
+
+int sigsvgd_vec_sqdist(const void *X, const void *Y, const void *XM, const void *YM, int A, int B, int D, int dtype,
+                       void *sq_out, void *stream)
+{
+    if (!X || !Y || !sq_out || (XM == nullptr) != (YM == nullptr)) {
+        set_error("vec_sqdist: null pointer argument (XM and YM must both be given or both be NULL)");
+        return SIGSVGD_E_BADARG;
+    }
+    if (A < 1 || B < 1 || D < 1 || (dtype != SIGSVGD_F32 && dtype != SIGSVGD_F64)) {
+        set_error("vec_sqdist: bad arguments A=%d B=%d D=%d dtype=%d", A, B, D, dtype);
+        return SIGSVGD_E_BADARG;
+    }
+    return vec_sqdist_launch(X, Y, XM, YM, A, B, D, dtype, sq_out, static_cast<hipStream_t>(stream));
+}
+
+int sigsvgd_vec_kernel(const void *sq, const void *XM, const void *YM, const void *grad_out, int A, int B, int D,
+                       int dtype, int kind, double inv_h2, double grad_scale, void *K_out, void *dK_out, void *stream)
+{
+    if (!sq || (!K_out && !dK_out) || (dK_out && (!XM || !YM))) {
+        set_error("vec_kernel: null pointer argument");
+        return SIGSVGD_E_BADARG;
+    }
+    if (A < 1 || B < 1 || D < 1 || (dtype != SIGSVGD_F32 && dtype != SIGSVGD_F64)) {
+        set_error("vec_kernel: bad arguments A=%d B=%d D=%d dtype=%d", A, B, D, dtype);
+        return SIGSVGD_E_BADARG;
+    }
+    if (kind != SIGSVGD_VEC_GAUSSIAN && kind != SIGSVGD_VEC_IMQ && kind != SIGSVGD_VEC_UNIT) {
+        set_error("vec_kernel: bad kind %d", kind);
+        return SIGSVGD_E_BADARG;
+    }
+    if (kind == SIGSVGD_VEC_UNIT && (K_out || !dK_out)) {
+        set_error("vec_kernel: SIGSVGD_VEC_UNIT computes only dK_out (K_out must be NULL)");
+        return SIGSVGD_E_BADARG;
+    }
+    if (kind != SIGSVGD_VEC_UNIT && !(inv_h2 > 0.0)) {
+        set_error("vec_kernel: needs 1/h^2 > 0 (got %g)", inv_h2);
+        return SIGSVGD_E_BADARG;
+    }
+    return vec_kgrad_launch(sq, XM, YM, grad_out, A, B, D, dtype, kind, inv_h2, grad_scale, K_out, dK_out,
+                            static_cast<hipStream_t>(stream));
+}
+
+int sigsvgd_signature(const void *X, int N, int L, int C, int depth, int basepoint, int dtype, void *out,
+                      long long *channels, void *stream)
+{
+    if (N < 1 || L < 1 || C < 1 || depth < 1 || (dtype != SIGSVGD_F32 && dtype != SIGSVGD_F64)) {
+        set_error("signature: bad arguments N=%d L=%d C=%d depth=%d dtype=%d", N, L, C, depth, dtype);
+        return SIGSVGD_E_BADARG;
+    }
+    const long long ch = signature_channels(C, depth);
+    if (ch < 0) {
+        set_error("signature: C=%d depth=%d overflows", C, depth);
+        return SIGSVGD_E_UNSUPPORTED;
+    }
+    if (channels) *channels = ch;
+    if (!out) {
+        if (channels) return SIGSVGD_OK;
+        set_error("signature: out == NULL and channels == NULL");
+        return SIGSVGD_E_BADARG;
+    }
+    if (!X) {
+        set_error("signature: X == NULL");
+        return SIGSVGD_E_BADARG;
+    }
+    return signature_launch(X, N, L, C, depth, basepoint, dtype, out, static_cast<hipStream_t>(stream));
 }
 
 } // extern "C"

@@ -38,10 +38,9 @@ class SVGD:
         **opt_args,
     ):
         if kernel is None:
-            raise ValueError(
-                "sigsvgd_amd.SVGD needs a kernel (the reference's GaussianKernel default is outside this "
-                "build's scope); pass a SignatureKernel / SigKernel or inject k_xx and grad_k in step()."
-            )
+            from ..kernels import GaussianKernel
+
+            kernel = GaussianKernel()  # reference default (svgd.py:24-25)
         self.kernel = kernel
         self.log_p = log_p
         self.log_prior = log_prior

@@ -8,6 +8,7 @@ import torch
 import torch.autograd as autograd
 import torch.optim as optim
 
+from ..kernels import PathSigKernel, TrajectoryKernel
 from ..sigkernel import SigKernel
 from .svgd import SVGD
 
@@ -27,6 +28,25 @@ class TrajectorySVGD(SVGD):
         self.gradient_mask = gradient_mask
 
     def _compute_kernel(self, X, **kwargs):
+        if isinstance(self.kernel, TrajectoryKernel):
+            tau = kwargs["trajectories"][..., 1:, :2]
+            if kwargs["sample_shape"]:
+                tau = tau.mean(0)
+            k_xx, grad_k = (0, 0)
+            for i in range(tau.shape[-1]):
+                # gradients w.r.t. the policies = sum of the gradients w.r.t. the sampled actions
+                k_xx_i, grad_k_i = self.kernel(tau[..., i], tau[..., i].detach(), X, compute_grad=True)
+                k_xx = k_xx + k_xx_i
+                grad_k = grad_k + grad_k_i
+            k_xx = k_xx / tau.shape[-1]
+            grad_k = grad_k.flatten(1) / tau.shape[-1]
+            return k_xx.detach(), grad_k.detach()
+        if isinstance(self.kernel, PathSigKernel):
+            tau = kwargs["trajectories"][..., 1:, :2]
+            if kwargs["sample_shape"]:
+                tau = tau.mean(0)
+            k_xx, grad_k = self.kernel(tau, tau, X, compute_grad=True)
+            return k_xx.detach(), grad_k.detach().flatten(1)
         if isinstance(self.kernel, SigKernel):
             # x, y positions from time t+1 on; mean over action samples if present
             tau = kwargs["trajectories"][..., 1:, :2]

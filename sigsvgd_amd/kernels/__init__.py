@@ -1,4 +1,14 @@
-from ._kernels import BaseKernel
-from ._traj_kernels import BatchGaussianKernel, SignatureKernel
+from ._kernels import BaseKernel, GaussianKernel, IMQKernel, ScaledGaussianKernel, ScaledIMQKernel
+from ._traj_kernels import BatchGaussianKernel, PathSigKernel, SignatureKernel, TrajectoryKernel
 
-__all__ = ["BaseKernel", "BatchGaussianKernel", "SignatureKernel"]
+__all__ = [
+    "BaseKernel",
+    "GaussianKernel",
+    "ScaledGaussianKernel",
+    "IMQKernel",
+    "ScaledIMQKernel",
+    "TrajectoryKernel",
+    "PathSigKernel",
+    "BatchGaussianKernel",
+    "SignatureKernel",
+]

@@ -1,5 +1,5 @@
-"""Kernel base class: bandwidth-function handling shared by the kernels of the path
-(reference src/kernels/_kernels.py:12-61)."""
+"""Kernel base class (bandwidth-function handling, reference src/kernels/_kernels.py:12-61) and the
+vector kernels with analytic gradients (reference src/kernels/_kernels.py:64-299) on the HIP library."""
 from __future__ import annotations
 
 from abc import ABC, abstractmethod
@@ -7,6 +7,7 @@ from typing import Callable, Tuple, Union
 
 import torch
 
+from .. import _lib
 from ..utils.math import bw_median
 
 scalar_function = Callable[[torch.Tensor], float]
@@ -31,3 +32,133 @@ class BaseKernel(ABC, torch.nn.Module):
     @abstractmethod
     def __call__(self, X: torch.Tensor, Y: torch.Tensor, compute_grad=True, **kwargs) -> kernel_output:
         pass
+
+
+# ---- vector kernels with analytic gradients (reference src/kernels/_kernels.py:64-299) -------------------
+# K and `d_K.sum(1)` come from the HIP library (ops.vec_sqdist + ops.vec_kernel): the [batch, batch, dim]
+# difference tensor of the reference is never formed.
+class _SqDist(torch.autograd.Function):
+    """sq[i,j] = (x_i - y_j) M (x_i - y_j)^T as an autograd node (used when the caller differentiates K
+    itself, `compute_grad=False`); backward = weighted differences, also on the HIP library."""
+
+    @staticmethod
+    def forward(ctx, X, Y, M):
+        from .. import ops
+
+        if M is None:
+            sq = ops.vec_sqdist(X, Y)
+        else:
+            sq = ops.vec_sqdist(X, Y, X.detach() @ M, Y.detach() @ M)
+        ctx.save_for_backward(X.detach(), Y.detach(), M)
+        return sq
+
+    @staticmethod
+    def backward(ctx, g):
+        from .. import _lib, ops
+
+        X, Y, M = ctx.saved_tensors
+        if M is None:
+            XMs, YMs, scale = X, Y, 2.0
+        else:
+            Ms = M + M.T
+            XMs, YMs, scale = X @ Ms, Y @ Ms, 1.0
+        g = g.contiguous()
+        gX = gY = None
+        if ctx.needs_input_grad[0]:
+            gX = ops.vec_kernel(g, XMs, YMs, _lib.VEC_UNIT, 1.0, scale, grad_out=g, want_K=False)[1]
+        if ctx.needs_input_grad[1]:
+            gT = g.T.contiguous()
+            gY = ops.vec_kernel(gT, YMs, XMs, _lib.VEC_UNIT, 1.0, scale, grad_out=gT, want_K=False)[1]
+        return gX, gY, None
+
+
+class _VectorKernel(BaseKernel):
+    """Shared driver: flatten to [batch, dim], distances, bandwidth, K and summed gradient."""
+
+    _kind = None       # _lib.VEC_GAUSSIAN / _lib.VEC_IMQ
+    _scaled = False    # takes a metric M
+    _sym_metric = False  # symmetrise M (ScaledGaussianKernel does, ScaledIMQKernel does not)
+
+    def __init__(self, bandwidth_fn: scalar_function = None, **kwargs):
+        super().__init__(bandwidth_fn, analytic_grad=True, **kwargs)
+
+    def _grad_scale(self, h2: float) -> float:
+        raise NotImplementedError
+
+    def _evaluate(self, X, Y, M=None, h=None, compute_grad=True):
+        from .. import ops
+
+        assert X.shape == Y.shape, "X and Y must have the same dimensions."
+        X, Y = torch.atleast_2d(X), torch.atleast_2d(Y)
+        X, Y = X.flatten(1), Y.flatten(1)  # enforces 2-D tensors
+        if M is not None:
+            assert M.shape == M.T.shape, "M must be a square matrix."
+            assert M.shape[-1] == X.shape[-1], "Matrix M must match last dim of inputs."
+            M = M.to(device=X.device, dtype=X.dtype)
+            if self._sym_metric:
+                M = 0.5 * (M + M.T)  # PSD stabilization
+        if not compute_grad and (X.requires_grad or Y.requires_grad):
+            # the caller will differentiate K: keep the distance (and a data-dependent bandwidth) on the tape
+            sq = _SqDist.apply(X, Y, M)
+            h = self.get_bandwidth(sq) if h is None else float(h)
+            if self._kind == _lib.VEC_GAUSSIAN:
+                return (-0.5 / h**2 * sq).exp()
+            return (1 + 0.5 * sq / h**2) ** -0.5
+        Xd, Yd = X.detach(), Y.detach()
+        XM, YM = (Xd, Yd) if M is None else (Xd @ M, Yd @ M)
+        sq = ops.vec_sqdist(Xd, Yd) if M is None else ops.vec_sqdist(Xd, Yd, XM, YM)
+        h = float(self.get_bandwidth(sq)) if h is None else float(h)
+        K, dK = ops.vec_kernel(sq, XM, YM, self._kind, 1.0 / h**2, self._grad_scale(h**2), want_grad=compute_grad)
+        return (K, dK) if compute_grad else K
+
+
+class GaussianKernel(_VectorKernel):
+    """k(X, Y) = exp(-|X - Y|^2 / (2 h^2)); returns (K, d_K.sum(1)) (reference _kernels.py:64-111)."""
+
+    _kind = _lib.VEC_GAUSSIAN
+
+    def _grad_scale(self, h2):
+        return -1.0 / h2
+
+    def __call__(self, X, Y, h: float = None, compute_grad=True, **kwargs) -> kernel_output:
+        return self._evaluate(X, Y, None, h, compute_grad)
+
+
+class ScaledGaussianKernel(_VectorKernel):
+    """k = exp(-(X - Y) M (X - Y)^T / (2 h^2)), M symmetrised (reference _kernels.py:114-186)."""
+
+    _kind = _lib.VEC_GAUSSIAN
+    _scaled = True
+    _sym_metric = True
+
+    def _grad_scale(self, h2):
+        return -1.0 / h2
+
+    def __call__(self, X, Y, M: torch.Tensor = None, h: float = None, compute_grad=True, **kwargs) -> kernel_output:
+        return self._evaluate(X, Y, M, h, compute_grad)
+
+
+class IMQKernel(_VectorKernel):
+    """k = (1 + |X - Y|^2 / (2 h^2))^(-1/2).  The summed gradient keeps the reference's (Y - X)
+    orientation (_kernels.py:232), i.e. it is MINUS the derivative w.r.t. X."""
+
+    _kind = _lib.VEC_IMQ
+
+    def _grad_scale(self, h2):
+        return +0.5 / h2
+
+    def __call__(self, X, Y, h: float = None, compute_grad: bool = True, **kwargs) -> kernel_output:
+        return self._evaluate(X, Y, None, h, compute_grad)
+
+
+class ScaledIMQKernel(_VectorKernel):
+    """k = (1 + (X - Y) M (X - Y)^T / (2 h^2))^(-1/2), M used as given (reference _kernels.py:238-299)."""
+
+    _kind = _lib.VEC_IMQ
+    _scaled = True
+
+    def _grad_scale(self, h2):
+        return -0.5 / h2
+
+    def __call__(self, X, Y, M: torch.Tensor = None, h: float = None, compute_grad: bool = True, **kwargs):
+        return self._evaluate(X, Y, M, h, compute_grad)

@@ -1,13 +1,58 @@
-"""Trajectory kernels of the hot path: `BatchGaussianKernel` (static RBF on path points) and
-`SignatureKernel` (signature kernel via the Goursat PDE) -- reference
-src/kernels/_traj_kernels.py:147-206 -- backed by the HIP library instead of `sigkernel`."""
+"""Trajectory kernels: `BatchGaussianKernel` (static RBF on path points) and `SignatureKernel` (signature
+kernel via the Goursat PDE) -- reference src/kernels/_traj_kernels.py:147-206 -- backed by the HIP library
+instead of `sigkernel`; `PathSigKernel` (static kernel on truncated signatures, :72-144) backed by the HIP
+signature kernel instead of `signatory`; `TrajectoryKernel` (:14-69)."""
 from __future__ import annotations
 
 import torch
 
 from .. import _lib
 from ..sigkernel import SigKernel, gram_sqdist, inv_bandwidth_from_fn
-from ._kernels import BaseKernel, kernel_output, scalar_function
+from ._kernels import BaseKernel, GaussianKernel, _SqDist, kernel_output, scalar_function
+
+class TrajectoryKernel(BaseKernel):
+    """RBF kernel between state-space projections phi(actions) of the inputs; the gradient w.r.t. the
+    actions comes from autograd through the caller's rollout graph (reference _traj_kernels.py:14-69).
+    The pairwise distance is a HIP autograd node (`_SqDist`)."""
+
+    def __init__(self, bandwidth_fn: scalar_function = None, **kwargs):
+        super().__init__(bandwidth_fn, analytic_grad=False, **kwargs)
+
+    def __call__(self, X, Y, X_actions, h: float = None, compute_grad=True, **kwargs) -> kernel_output:
+        assert X.shape == Y.shape, "X and Y must have the same dimensions."
+        sq_dists = _SqDist.apply(torch.atleast_2d(X), torch.atleast_2d(Y), None)
+        h = self.get_bandwidth(sq_dists) if h is None else float(h)
+        gamma = -0.5 / h**2
+        K = (gamma * sq_dists).exp()
+        if compute_grad:
+            d_K = torch.autograd.grad(K.sum(), X_actions, retain_graph=True)[0]
+            return K, d_K
+        return K
+
+
+class PathSigKernel(BaseKernel):
+    """Static kernel on truncated path signatures S(X, depth) with a zero base point (reference
+    _traj_kernels.py:72-144).  As in the reference, `h` and `ref_vector` are accepted but NOT forwarded:
+    the static kernel uses its own bandwidth function, and the returned gradient is the static kernel's
+    `d_K.sum(1)` with respect to the SIGNATURE features ([batch, C + ... + C^depth])."""
+
+    def __init__(self, bandwidth_fn: scalar_function = None, static_kernel: BaseKernel = None, **kwargs):
+        super().__init__(bandwidth_fn, analytic_grad=False, **kwargs)
+        self.static_kernel = GaussianKernel() if static_kernel is None else static_kernel
+
+    def __call__(self, X, Y, ref_vector=None, depth: int = 3, h: float = None, compute_grad=True,
+                 **kwargs) -> kernel_output:
+        from .. import ops
+
+        assert X.shape == Y.shape, "X and Y must have the same dimensions."
+        X, Y = torch.atleast_3d(X), torch.atleast_3d(Y)
+        X_sig = ops.signature(X, depth, basepoint=True)
+        Y_sig = ops.signature(Y, depth, basepoint=True)
+        if compute_grad:
+            K, d_K = self.static_kernel(X_sig, Y_sig, compute_grad=True)
+            return K, d_K
+        return self.static_kernel(X_sig, Y_sig, compute_grad=False)
+
 
 class BatchGaussianKernel(BaseKernel):
     """RBF kernel on path points, k(x, y) = exp(-|x-y|^2 / h), h = bandwidth_fn(dist)."""

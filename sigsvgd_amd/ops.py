@@ -202,3 +202,104 @@ def gram_sym_partial(X, inv_h: float, tile_offset: int, tile_stride: int, static
                                         ws.data_ptr() if ws is not None else None, wsn, _stream_ptr(dev))
     _lib.check(rc, "gram_sym_partial")
     return Kp, gp
+
+
+# ---- vector kernels / truncated signature ---------------------------------------
+def _prep_vec(t: torch.Tensor, dtype=None) -> torch.Tensor:
+    t = t.detach()
+    if t.dim() < 2:
+        t = torch.atleast_2d(t)
+    t = t.flatten(1)
+    if dtype is not None and t.dtype != dtype:
+        t = t.to(dtype)
+    return t.contiguous()
+
+
+def vec_sqdist(X, Y, XM=None, YM=None) -> torch.Tensor:
+    """sq[A,B] = clamp(sum_c (XM - YM)_c (X - Y)_c, 0); XM = YM = None: |x_i - y_j|^2.  X [A,D], Y [B,D]."""
+    L = _lib.load()
+    dev = _require_gpu(X, Y, XM, YM)
+    Xc = _prep_vec(X)
+    dt = _io_dtype(Xc)
+    Yc = _prep_vec(Y, Xc.dtype)
+    if Xc.shape[1] != Yc.shape[1]:
+        raise ValueError(f"X and Y must share the feature size, got {tuple(Xc.shape)} vs {tuple(Yc.shape)}")
+    if (XM is None) != (YM is None):
+        raise ValueError("XM and YM must both be given or both be None")
+    XMc = YMc = None
+    if XM is not None:
+        XMc, YMc = _prep_vec(XM, Xc.dtype), _prep_vec(YM, Xc.dtype)
+        if XMc.shape != Xc.shape or YMc.shape != Yc.shape:
+            raise ValueError("XM / YM must have the shapes of X / Y")
+    A, D = Xc.shape
+    B = Yc.shape[0]
+    if A == 0 or B == 0 or D == 0:
+        raise ValueError("empty batch")
+    sq = torch.empty((A, B), dtype=Xc.dtype, device=dev)
+    with torch.cuda.device(dev):
+        rc = L.sigsvgd_vec_sqdist(Xc.data_ptr(), Yc.data_ptr(), XMc.data_ptr() if XMc is not None else None,
+                                  YMc.data_ptr() if YMc is not None else None, A, B, D, dt, sq.data_ptr(),
+                                  _stream_ptr(dev))
+    _lib.check(rc, "vec_sqdist")
+    return sq
+
+
+def vec_kernel(sq, XM, YM, kind: int, inv_h2: float, grad_scale: float, grad_out=None, want_K: bool = True,
+               want_grad: bool = True):
+    """(K[A,B] or None, dK[A,D] or None): K = f(sq), dK = grad_scale * sum_j grad_out_ij w(sq_ij) (XM_i - YM_j)."""
+    L = _lib.load()
+    dev = _require_gpu(sq, XM, YM, grad_out)
+    sqc = sq.detach().contiguous()
+    dt = _io_dtype(sqc)
+    A, B = sqc.shape
+    XMc = YMc = go = None
+    D = 1
+    if want_grad:
+        XMc, YMc = _prep_vec(XM, sqc.dtype), _prep_vec(YM, sqc.dtype)
+        D = XMc.shape[1]
+        if XMc.shape[0] != A or YMc.shape != (B, D):
+            raise ValueError(f"XM {tuple(XMc.shape)} / YM {tuple(YMc.shape)} do not match sq {tuple(sqc.shape)}")
+    if grad_out is not None:
+        if tuple(grad_out.shape) != (A, B):
+            raise ValueError(f"grad_out must be [{A},{B}], got {tuple(grad_out.shape)}")
+        go = grad_out.detach().to(sqc.dtype).contiguous()
+    K = torch.empty((A, B), dtype=sqc.dtype, device=dev) if want_K else None
+    dK = torch.empty((A, D), dtype=sqc.dtype, device=dev) if want_grad else None
+    with torch.cuda.device(dev):
+        rc = L.sigsvgd_vec_kernel(sqc.data_ptr(), XMc.data_ptr() if XMc is not None else None,
+                                  YMc.data_ptr() if YMc is not None else None,
+                                  go.data_ptr() if go is not None else None, A, B, D, dt, int(kind), float(inv_h2),
+                                  float(grad_scale), K.data_ptr() if K is not None else None,
+                                  dK.data_ptr() if dK is not None else None, _stream_ptr(dev))
+    _lib.check(rc, "vec_kernel")
+    return K, dK
+
+
+def signature_channels(channels: int, depth: int) -> int:
+    L = _lib.load()
+    n = ctypes.c_longlong(0)
+    _lib.check(L.sigsvgd_signature(None, 1, 1, int(channels), int(depth), 0, _lib.F32, None, ctypes.byref(n), None),
+               "signature (channel query)")
+    return int(n.value)
+
+
+def signature(X, depth: int, basepoint: bool = False) -> torch.Tensor:
+    """Truncated signature of paths X [N, L, C] -> [N, C + ... + C^depth] (signatory's layout)."""
+    L = _lib.load()
+    dev = _require_gpu(X)
+    if X.dim() != 3:
+        raise ValueError(f"paths must be [batch, length, channels]; got {tuple(X.shape)}")
+    Xc = X.detach().contiguous()
+    dt = _io_dtype(Xc)
+    N, Ln, C = Xc.shape
+    if N == 0:
+        raise ValueError("empty batch")
+    n = ctypes.c_longlong(0)
+    _lib.check(L.sigsvgd_signature(None, N, Ln, C, int(depth), int(bool(basepoint)), dt, None, ctypes.byref(n), None),
+               "signature (channel query)")
+    out = torch.empty((N, int(n.value)), dtype=Xc.dtype, device=dev)
+    with torch.cuda.device(dev):
+        rc = L.sigsvgd_signature(Xc.data_ptr(), N, Ln, C, int(depth), int(bool(basepoint)), dt, out.data_ptr(), None,
+                                 _stream_ptr(dev))
+    _lib.check(rc, "signature")
+    return out

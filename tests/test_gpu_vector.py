@@ -1,0 +1,251 @@
+"""GPU parity of the vector kernels (Gaussian / scaled Gaussian / IMQ / scaled IMQ), the truncated
+signature and PathSigKernel against the fp64 oracle and the reference-generated fixtures
+(tests/golden/ref_vector_kernels.npz).  Tolerance: fp32 I/O -> 1e-5 relative to max-abs; fp64 I/O -> 1e-11."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vector_oracle as VO
+
+pytestmark = pytest.mark.gpu
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_vector_kernels.npz"))
+
+
+def rel(a, b):
+    a = a.detach().double().cpu().numpy() if hasattr(a, "detach") else np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+def t64(a, gpu):
+    return torch.as_tensor(np.asarray(a), dtype=torch.float64, device=gpu)
+
+
+# ---- reference fixtures replayed through the drop-in classes (fp64 in, like the fixtures) ---------------
+@pytest.mark.parametrize("name", ["gauss", "imq"])
+def test_plain_kernels_reference_fixtures(gpu, name):
+    from sigsvgd_amd.kernels import GaussianKernel, IMQKernel
+
+    ker = {"gauss": GaussianKernel, "imq": IMQKernel}[name]()
+    X, Y = t64(G["X"], gpu), t64(G["Y"], gpu)
+    K, dK = ker(X, Y, h=0.8)
+    assert K.dtype == torch.float64 and K.shape == (7, 7) and dK.shape == (7, 5)
+    assert rel(K, G[f"{name}_h0.8_K"]) < 1e-11 and rel(dK, G[f"{name}_h0.8_dK"]) < 1e-11
+    assert rel(ker(X, Y, h=0.8, compute_grad=False), G[f"{name}_h0.8_Konly"]) < 1e-11
+    K, dK = ker(X, Y)  # median heuristic (float32 log inside, as in the reference)
+    assert rel(K, G[f"{name}_med_K"]) < 1e-6 and rel(dK, G[f"{name}_med_dK"]) < 1e-6
+    K, dK = ker(X, X, h=1.1)
+    assert rel(K, G[f"{name}_xx_K"]) < 1e-11 and rel(dK, G[f"{name}_xx_dK"]) < 1e-11
+
+
+@pytest.mark.parametrize("name", ["sgauss", "simq"])
+def test_scaled_kernels_reference_fixtures(gpu, name):
+    from sigsvgd_amd.kernels import ScaledGaussianKernel, ScaledIMQKernel
+
+    ker = {"sgauss": ScaledGaussianKernel, "simq": ScaledIMQKernel}[name]()
+    X, Y, M, Mns = (t64(G[k], gpu) for k in ("X", "Y", "M", "Mns"))
+    for key, kw in [("I_h0.8", dict(h=0.8)), ("M_h0.8", dict(M=M, h=0.8)), ("Mns_h1.3", dict(M=Mns, h=1.3))]:
+        K, dK = ker(X, Y, **kw)
+        assert rel(K, G[f"{name}_{key}_K"]) < 1e-11, key
+        assert rel(dK, G[f"{name}_{key}_dK"]) < 1e-11, key
+    K, dK = ker(X, Y, M=M)
+    assert rel(K, G[f"{name}_M_med_K"]) < 1e-6 and rel(dK, G[f"{name}_M_med_dK"]) < 1e-6
+
+
+def test_three_dimensional_particles_fixture(gpu):
+    from sigsvgd_amd.kernels import GaussianKernel
+
+    X3 = t64(G["X3"], gpu)
+    K, dK = GaussianKernel()(X3, X3, h=1.7)
+    assert dK.shape == (6, 12)
+    assert rel(K, G["gauss_X3_K"]) < 1e-11 and rel(dK, G["gauss_X3_dK"]) < 1e-11
+
+
+# ---- fp32 against the fp64 oracle at awkward and larger sizes -----------------------------------------
+@pytest.mark.parametrize("A,B,D", [(1, 1, 1), (3, 70, 5), (65, 17, 67), (130, 130, 129), (257, 300, 448)])
+@pytest.mark.parametrize("kind", ["gaussian", "imq"])
+def test_vec_ops_fp32_vs_oracle(gpu, A, B, D, kind):
+    from sigsvgd_amd import _lib, ops
+
+    rng = np.random.default_rng(A * 1000 + B + D)
+    X = rng.normal(size=(A, D)).astype(np.float32)
+    Y = (rng.normal(size=(B, D)) * 0.9 + 0.1).astype(np.float32)
+    go = rng.uniform(0.5, 1.5, size=(A, B)).astype(np.float32)
+    h = float(np.sqrt(D))
+    sq = ops.vec_sqdist(torch.as_tensor(X, device=gpu), torch.as_tensor(Y, device=gpu))
+    want_sq = VO.pw_dist_sq(X, Y)
+    assert rel(sq, want_sq) < 1e-5
+    k = _lib.VEC_GAUSSIAN if kind == "gaussian" else _lib.VEC_IMQ
+    K, dK = ops.vec_kernel(sq, torch.as_tensor(X, device=gpu), torch.as_tensor(Y, device=gpu), k, 1 / h**2, -1 / h**2,
+                           grad_out=torch.as_tensor(go, device=gpu))
+    wantK = np.exp(-0.5 / h**2 * want_sq) if kind == "gaussian" else (1 + 0.5 * want_sq / h**2) ** -0.5
+    assert rel(K, wantK) < 1e-5
+    want = VO.vec_kernel_weighted_grad(want_sq, X, Y, go, kind, h, -1 / h**2)
+    assert rel(dK, want) < 1e-5
+    # gradient only / kernel only
+    assert ops.vec_kernel(sq, None, None, k, 1 / h**2, 0.0, want_grad=False)[1] is None
+    K2, dK2 = ops.vec_kernel(sq, torch.as_tensor(X, device=gpu), torch.as_tensor(Y, device=gpu), k, 1 / h**2, -1 / h**2,
+                             grad_out=torch.as_tensor(go, device=gpu), want_K=False)
+    assert K2 is None and torch.equal(dK2, dK)
+
+
+def test_metric_sqdist_fp32_vs_oracle(gpu):
+    from sigsvgd_amd import ops
+
+    rng = np.random.default_rng(3)
+    X, Y = rng.normal(size=(90, 33)).astype(np.float32), rng.normal(size=(75, 33)).astype(np.float32)
+    R = rng.normal(size=(33, 33))
+    M = (R @ R.T / 33 + np.eye(33)).astype(np.float32)
+    Xg, Yg, Mg = (torch.as_tensor(a, device=gpu) for a in (X, Y, M))
+    sq = ops.vec_sqdist(Xg, Yg, Xg @ Mg, Yg @ Mg)
+    want, _ = VO.scaled_pw_dist_sq(X, Y, M)
+    assert rel(sq, want) < 1e-5
+    assert float(sq.min()) >= 0.0
+
+
+def test_autograd_through_K_matches_torch(gpu):
+    """compute_grad=False returns a differentiable K (reference ScoreEstimator._svgd_ag_score pattern),
+    including the dependence of a median bandwidth on the inputs."""
+    from sigsvgd_amd.kernels import GaussianKernel, ScaledIMQKernel
+
+    g = torch.Generator().manual_seed(4)
+    X0 = torch.randn(20, 6, generator=g, dtype=torch.float64)
+    M = torch.randn(6, 6, generator=g, dtype=torch.float64)
+    M = (M @ M.T / 6 + torch.eye(6, dtype=torch.float64))
+    for ker, kw, f in [
+        (GaussianKernel(), {}, lambda sq, h: (-0.5 / h**2 * sq).exp()),
+        (GaussianKernel(bandwidth_fn=lambda _: 1.3), {}, lambda sq, h: (-0.5 / h**2 * sq).exp()),
+        (ScaledIMQKernel(bandwidth_fn=lambda _: 0.9), {"M": M}, lambda sq, h: (1 + 0.5 * sq / h**2) ** -0.5),
+    ]:
+        x = X0.clone().to(gpu).requires_grad_(True)
+        K = ker(x, x.detach(), compute_grad=False, **{k: v.to(gpu) for k, v in kw.items()})
+        (gx,) = torch.autograd.grad(K.sum(), x)
+        xc = X0.clone().requires_grad_(True)
+        diff = xc[:, None, :] - xc.detach()[None, :, :]
+        sq = ((diff @ kw["M"]) * diff).sum(-1) if kw else (diff * diff).sum(-1)
+        Kc = f(sq, ker.get_bandwidth(sq))
+        (gc,) = torch.autograd.grad(Kc.sum(), xc)
+        assert rel(K, Kc.detach().numpy()) < 1e-6
+        assert rel(gx, gc.numpy()) < 1e-6
+
+
+def test_sqdist_autograd_second_slot(gpu):
+    from sigsvgd_amd.kernels._kernels import _SqDist
+
+    g = torch.Generator().manual_seed(9)
+    X = torch.randn(9, 4, generator=g, dtype=torch.float64)
+    Y = torch.randn(11, 4, generator=g, dtype=torch.float64)
+    W = torch.randn(9, 11, generator=g, dtype=torch.float64)
+    xg, yg = X.to(gpu).requires_grad_(True), Y.to(gpu).requires_grad_(True)
+    sq = _SqDist.apply(xg, yg, None)
+    gx, gy = torch.autograd.grad((sq * W.to(gpu)).sum(), (xg, yg))
+    xc, yc = X.clone().requires_grad_(True), Y.clone().requires_grad_(True)
+    sqc = ((xc[:, None] - yc[None]) ** 2).sum(-1)
+    gxc, gyc = torch.autograd.grad((sqc * W).sum(), (xc, yc))
+    assert rel(gx, gxc.numpy()) < 1e-12 and rel(gy, gyc.numpy()) < 1e-12
+
+
+# ---- truncated signature ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,L,C,depth,bp", [(1, 2, 1, 1, False), (5, 8, 2, 3, True), (3, 25, 2, 3, True), (4, 6, 3, 4, False),
+                                            (2, 64, 7, 3, True), (2, 5, 2, 6, True), (70, 3, 4, 2, True)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_signature_vs_oracle(gpu, N, L, C, depth, bp, dtype):
+    from sigsvgd_amd import ops
+
+    rng = np.random.default_rng(N + L * 7 + C * 31 + depth)
+    X = np.cumsum(0.4 * rng.normal(size=(N, L, C)), axis=1)
+    S = ops.signature(torch.as_tensor(X, dtype=dtype, device=gpu), depth, basepoint=bp)
+    assert S.dtype == dtype and tuple(S.shape) == (N, VO.signature_channels(C, depth))
+    assert ops.signature_channels(C, depth) == S.shape[1]
+    want = VO.signature(X.astype(np.float32) if dtype == torch.float32 else X, depth, bp)
+    assert rel(S, want) < (1e-6 if dtype == torch.float32 else 1e-13)
+
+
+def test_signature_straight_line_and_single_point(gpu):
+    from sigsvgd_amd import ops
+
+    a = np.array([0.7, -0.3, 0.2])
+    x = np.linspace(0, 1, 6)[:, None] * a
+    S = ops.signature(torch.as_tensor(x[None], device=gpu), 3, basepoint=True)[0].cpu().numpy()
+    want = np.concatenate([a, np.multiply.outer(a, a).ravel() / 2, np.multiply.outer(np.multiply.outer(a, a), a).ravel() / 6])
+    np.testing.assert_allclose(S, want, rtol=1e-13, atol=1e-15)
+    one = ops.signature(torch.ones(2, 1, 3, dtype=torch.float64, device=gpu), 2, basepoint=False)
+    assert float(one.abs().max()) == 0.0  # a single point has no increments
+
+
+def test_signature_too_large_for_lds_is_an_error(gpu):
+    from sigsvgd_amd import ops
+
+    with pytest.raises(RuntimeError, match="LDS"):
+        ops.signature(torch.zeros(1, 4, 16, device=gpu), 4)  # 69,904 channels
+
+
+def test_path_sig_kernel_fixture_and_oracle(gpu):
+    from sigsvgd_amd.kernels import PathSigKernel
+
+    P1, P2 = t64(G["P1"], gpu), t64(G["P2"], gpu)
+    psk = PathSigKernel()
+    K, dK = psk(P1, P2, depth=3, h=0.9)  # h is ignored, as in the reference
+    assert K.shape == (6, 6) and dK.shape == (6, 14)
+    assert rel(K, G["psk_d3_h0.9_K"]) < 1e-6 and rel(dK, G["psk_d3_h0.9_dK"]) < 1e-6
+    K, dK = psk(P1, P2, depth=2)
+    assert rel(K, G["psk_d2_med_K"]) < 1e-6 and rel(dK, G["psk_d2_med_dK"]) < 1e-6
+    assert rel(psk(P1, P1, depth=3, compute_grad=False), G["psk_d3_Konly"]) < 1e-6
+    # the reference's test shape (tests/test_traj_kernels.py: batch 128, 25 points, (cos, sin) channels), fp32
+    g = torch.Generator().manual_seed(0)
+    X = torch.randn(128, 25, 1, generator=g)
+    Y = torch.randn(128, 25, 1, generator=g)
+    phi = lambda t: torch.cat((t.cos(), t.sin()), -1)
+    K, dK = psk(phi(X).to(gpu), phi(Y).to(gpu), X.to(gpu), depth=3, h=2.0**0.5)
+    wK, wdK, _ = VO.path_sig_kernel(phi(X).numpy(), phi(Y).numpy(), depth=3)
+    assert rel(K, wK) < 1e-5 and rel(dK, wdK) < 1e-5
+
+
+def test_svgd_with_default_gaussian_kernel_matches_closed_form(gpu):
+    """SVGD(kernel=None) uses GaussianKernel (reference svgd.py:24-25): one manual step == oracle."""
+    from sigsvgd_amd.inference import SVGD
+
+    rng = np.random.default_rng(12)
+    X = rng.normal(size=(40, 6)).astype(np.float32)
+    score = rng.normal(size=(40, 6)).astype(np.float32)
+    s = SVGD(optimizer_class=None, lr=0.1)
+    Xn, it = s.step(torch.as_tensor(X, device=gpu), torch.as_tensor(score, device=gpu), None)
+    K, dK, _ = VO.gaussian(X, X)
+    v = -((K @ score.astype(np.float64) - dK) / 40)
+    assert rel(it["k_xx"], K) < 1e-5
+    assert rel(Xn, X - 0.1 * v) < 1e-5
+
+
+def test_trajectory_kernel_autograd_to_actions(gpu):
+    from sigsvgd_amd.kernels import TrajectoryKernel
+
+    g = torch.Generator().manual_seed(2)
+    a0 = torch.randn(12, 5, generator=g, dtype=torch.float64)
+    act = a0.clone().to(gpu).requires_grad_(True)
+    tau = torch.cumsum(act, 1)  # a toy differentiable rollout
+    K, dK = TrajectoryKernel()(tau, tau.detach(), act, h=1.4)
+    ac = a0.clone().requires_grad_(True)
+    tc = torch.cumsum(ac, 1)
+    sq = ((tc[:, None] - tc.detach()[None]) ** 2).sum(-1)
+    Kc = (-0.5 / 1.4**2 * sq).exp()
+    (dc,) = torch.autograd.grad(Kc.sum(), ac)
+    assert rel(K, Kc.detach().numpy()) < 1e-12 and rel(dK, dc.numpy()) < 1e-12
+
+
+def test_vector_kernel_argument_errors(gpu):
+    from sigsvgd_amd import _lib, ops
+    from sigsvgd_amd.kernels import GaussianKernel
+
+    x = torch.zeros(4, 3, device=gpu)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.vec_sqdist(torch.zeros(4, 3), torch.zeros(4, 3))
+    with pytest.raises(ValueError):
+        ops.vec_sqdist(x, torch.zeros(4, 2, device=gpu))
+    with pytest.raises(RuntimeError, match="1/h"):
+        ops.vec_kernel(torch.zeros(4, 4, device=gpu), x, x, _lib.VEC_GAUSSIAN, 0.0, 1.0)
+    with pytest.raises(AssertionError):
+        GaussianKernel()(x, torch.zeros(5, 3, device=gpu))
+    with pytest.raises(ValueError):
+        GaussianKernel(bandwidth_fn=3.0)

@@ -136,8 +136,9 @@ def test_svgd_step_injected_kernel_fixture(monkeypatch):
 def test_svgd_errors():
     from sigsvgd_amd.inference import SVGD
 
-    with pytest.raises(ValueError):
-        SVGD(None)
+    from sigsvgd_amd.kernels import GaussianKernel
+
+    assert isinstance(SVGD(None).kernel, GaussianKernel)  # reference default, svgd.py:24-25
     with pytest.raises(ValueError):
         SVGD(_Dummy(), optimizer_class=None, lr=0.1)._velocity(torch.zeros(2, 3, 1), None)
 
