@@ -62,7 +62,7 @@ __device__ __forceinline__ double ldany(const void *b, size_t i, int io64)
 } // namespace
 
 template <int DPAD, bool GRAD>
-__global__ __launch_bounds__(SNW * 64) void gram_stream_kernel(StreamArgs a)
+__global__ __launch_bounds__(SNW * 64, (DPAD == 16 && GRAD) ? 2 : 3) void gram_stream_kernel(StreamArgs a)
 {
     constexpr int NT = SNW * 64;
     constexpr int YDS = DPAD + 2; // fp64 row stride (doubles): column DPAD holds -log2(e)/h * |y~|^2
