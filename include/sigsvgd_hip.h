@@ -94,12 +94,12 @@ int sigsvgd_gram_fwd_bwd(const void *X, const void *Y, int A, int B, int T, int 
 
 /* Multi-GPU building block (particles sharded over ranks; new design, the reference has no
  * distributed code -- SURVEY.md §8e).  Solves the unordered pairs {i <= j} whose row tile
- * (8 consecutive rows i for d <= 8, 4 for d <= 16) has index tile_offset + k*tile_stride, on the
+ * (8 consecutive rows i for T <= 64 and d <= 8, otherwise 4) has index tile_offset + k*tile_stride, on the
  * full gathered particle tensor X[N,T,d], and ACCUMULATES into caller-zeroed buffers:
  *   K_partial[N,N]      (dtype)  both orientations K[i,j], K[j,i] of every owned pair, 0 elsewhere
  *   grad_partial[N,T,d] (fp64)   this rank's share of d sum(grad_out*K)/dX (row- and column-side)
  * Summing the buffers over tile_offset = 0..tile_stride-1 gives exactly sigsvgd_gram_fwd_bwd's
- * outputs.  Only the register-resident shapes (dyadic_order 0, 3 <= T <= 64, d <= 16, RBF).
+ * outputs.  Shapes of the register-resident and streaming kernels (dyadic_order 0, 3 <= T <= 128, d <= 16, RBF).
  * `workspace` as sized by sigsvgd_gram_workspace_bytes(N, N, T, d, 0, 1, SIGSVGD_FLAG_Y_IS_X) (work queue). */
 int sigsvgd_gram_sym_partial(const void *X, int N, int T, int d, int dtype, double inv_h,
                              int static_kind, unsigned flags, int tile_offset, int tile_stride,

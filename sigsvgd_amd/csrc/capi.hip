@@ -142,6 +142,8 @@ int sigsvgd_gram_sym_partial(const void *X, int N, int T, int d, int dtype, doub
     }
     GramProblem p{X, X, N, N, T, d, dtype, inv_h, 0, static_kind, flags | SIGSVGD_FLAG_Y_IS_X, grad_out,
                   K_partial, grad_partial, workspace, workspace_bytes, static_cast<hipStream_t>(stream)};
+    if (!fast_supported(N, N, T, d, 0, static_kind, flags) && stream_supported(N, N, T, d, 0, static_kind, flags))
+        return stream_sym_partial(p, tile_offset, tile_stride, grad_partial);
     return fast_sym_partial(p, tile_offset, tile_stride, grad_partial);
 }
 

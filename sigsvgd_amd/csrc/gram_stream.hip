@@ -14,9 +14,14 @@
 //     ~1e-12 in fp64);
 //   * the P x P grid is swept in two bands of <= 64 rows, one row per lane, anti-diagonal by
 //     anti-diagonal, neighbours through wave shifts, band boundary rows in LDS.
-// One wavefront per ORDERED pair (i, j); a workgroup is 4 wavefronts = 4 consecutive rows i sharing
-// the staged column trajectory y_j.  Row-side gradient only (the symmetric trick of gram_fast.hip is
-// not applied here).  Per-wave LDS: four T-length fp64 row buffers.
+// One wavefront per pair (i, j); a workgroup is 4 wavefronts = 4 consecutive rows i sharing the staged
+// column trajectory y_j.  Per-wave LDS: four T-length fp64 row buffers and three fp32 ones.
+// SYM (Y is X): only pairs j >= i are solved; K is mirrored and the column-side gradient
+// sum_m R G[m,n] x~_m (= d k(x_j, x_i)/d x_j) rides travelling accumulators as in gram_fast.hip (one
+// v_add_f32_dpp wave_shl:1 per running sum and step; lane 63 starts every column from the DPP zero fill).
+// With 128 columns and 64 lanes a column is finished when it leaves lane 0, so lane 0 adds it to a
+// [T][DPAD+1] fp32 image in LDS shared by the four wavefronts (ds_add_f32), which is closed
+// (y~_n * sum - sums) and sent to the fp64 accumulation buffer once per column trajectory.
 //
 // Reference semantics: sigkernel _SigKernelGram.forward/backward [RECALLED, SURVEY.md App. A];
 // static kernel src/kernels/_traj_kernels.py:176-195.
@@ -29,6 +34,7 @@ struct StreamArgs {
     void *K;
     double *gacc; // [A][T][d] fp64, zeroed by the launcher
     int io64, A, B, T, d, JC, symw;
+    int tile_offset, tile_stride; // row tiles tile_offset + k * tile_stride are solved (sharded partial solve)
     double inv_h;
 };
 
@@ -55,37 +61,51 @@ __device__ __forceinline__ float s_shr(float v)
 {
     return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x138, 0xF, 0xF, true));
 }
+// acc[lane + 1] + v in one VALU instruction; lane 63 reads the DPP zero fill (bound_ctrl), i.e. starts at v.
+// (2 wait states between a VALU write of `acc` and this DPP read are guaranteed by the >30 instructions of
+// a sweep step in between.)
+__device__ __forceinline__ float add_shl1z(float acc, float v)
+{
+    float out;
+    asm("v_add_f32_dpp %0, %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(out) : "v"(acc), "v"(v));
+    return out;
+}
 __device__ __forceinline__ double ldany(const void *b, size_t i, int io64)
 {
     return io64 ? static_cast<const double *>(b)[i] : (double)static_cast<const float *>(b)[i];
 }
 } // namespace
 
-template <int DPAD, bool GRAD>
+template <int DPAD, bool GRAD, bool SYM>
 __global__ __launch_bounds__(SNW * 64, (DPAD == 16 && GRAD) ? 2 : 3) void gram_stream_kernel(StreamArgs a)
 {
     constexpr int NT = SNW * 64;
+    constexpr int CS = DPAD + 1; // row stride of the column-side image (odd: conflict-free across n)
     constexpr int YDS = DPAD + 2; // fp64 row stride (doubles): column DPAD holds -log2(e)/h * |y~|^2
     constexpr int YFS = (DPAD == 4) ? 12 : DPAD + 4;
     __shared__ __align__(16) double yd[TMAX * YDS];
     __shared__ __align__(16) float yf[GRAD ? TMAX * YFS : 4];
     __shared__ double yref[DPAD];
-    __shared__ double rows_all[SNW * 5 * RB];
+    __shared__ double rows_all[SNW * 6 * RB];
+    __shared__ float colacc[(GRAD && SYM) ? TMAX * CS : 4]; // [n][c] sums of w R G x~_m, [n][DPAD] sums of w R G
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int T = a.T, d = a.d, P = T - 1, io64 = a.io64;
-    const int i = blockIdx.y * SNW + wave;
+    const int i0 = (a.tile_offset + (int)blockIdx.y * a.tile_stride) * SNW;
+    const int i = i0 + wave;
     const int j0 = blockIdx.x * a.JC, j1 = min(a.B, j0 + a.JC);
+    if (SYM && j1 <= i0) return; // chunk entirely left of the diagonal: solved from the other side
     const bool row_ok = i < a.A;
     const double inv_h = a.inv_h;
     const double nscale = -inv_h * 1.4426950408889634074;
     const float m2h = (float)(-2.0 * inv_h);
-    double *Kbnd = rows_all + (size_t)wave * 5 * RB; // K[64][.]   forward band boundary (kept for the K regeneration)
+    double *Kbnd = rows_all + (size_t)wave * 6 * RB; // K[64][.]   forward band boundary (kept for the K regeneration)
     double *Klast = Kbnd + RB;                       // K[P][.]    last forward row
     double *Ubnd = Klast + RB;                       // U[64][.]   reverse band boundary
     double *Gbd = Ubnd + RB;                         // G[64][q+1] - G[64][q]: row beyond band 0
     float *Gb32 = reinterpret_cast<float *>(Gbd + RB); // G[64][n] (fp32) and, behind it,
     float *Srow = Gb32 + RB;                           // S[63][q]: last row of band 0 for the hand-over to row 64
+    float *Srow2 = Srow + RB;                          // S[64][q]: first row of band 1, contracted in the hand-over pass
     const int nbands = (P + 63) / 64;                // 2 for 65 <= T <= 128
 
     float gacc[2][DPAD]; // row-side gradient of (band, channel), summed over the j chunk in fp32
@@ -110,18 +130,22 @@ __global__ __launch_bounds__(SNW * 64, (DPAD == 16 && GRAD) ? 2 : 3) void gram_s
             for (int off = 1; off < DPAD; off <<= 1) s += __shfl_xor(s, off, 64);
             if (c == 0) yd[t * YDS + DPAD] = s;
         }
+        if (GRAD && SYM)
+            for (int e = tid; e < TMAX * CS; e += NT) colacc[e] = 0.f;
         __syncthreads();
-        if (!row_ok) continue;
+        if (row_ok && (!SYM || j >= i)) {
 
         double kfin[2] = {1.0, 1.0}; // K[p+1][P] per band: last-column seeds of the K regeneration
-        float w_ij = 1.f;
+        float w_ij = 1.f, w_ji = 1.f; // row-side / column-side weights
         if (GRAD) {
             if (a.go) {
                 w_ij = (float)ldany(a.go, (size_t)i * a.B + j, io64);
-                if (a.symw) w_ij += (float)ldany(a.go, (size_t)j * a.B + i, io64);
+                if (SYM || a.symw) w_ji = (float)ldany(a.go, (size_t)j * a.B + i, io64);
+                if (a.symw) { w_ij += w_ji; w_ji = w_ij; }
             } else if (a.symw) {
-                w_ij = 2.f;
+                w_ij = 2.f; w_ji = 2.f;
             }
+            if (SYM && j == i) w_ji = 0.f; // diagonal pair: first-slot derivative only
         }
 
         // per-band lane state: row p = rb + lane; xs = scaled x~ (fp64), xf = x~ (fp32)
@@ -207,11 +231,16 @@ __global__ __launch_bounds__(SNW * 64, (DPAD == 16 && GRAD) ? 2 : 3) void gram_s
                     static_cast<double *>(a.K)[(size_t)i * a.B + j] = cur;
                 else
                     static_cast<float *>(a.K)[(size_t)i * a.B + j] = (float)cur;
+                if (SYM && j != i) {
+                    if (io64)
+                        static_cast<double *>(a.K)[(size_t)j * a.B + i] = cur;
+                    else
+                        static_cast<float *>(a.K)[(size_t)j * a.B + i] = (float)cur;
+                }
             }
             if (lane == 63 && has_next) Kbnd[0] = 1.0;
         }
-        if (!GRAD) continue;
-
+        if (GRAD) {
         // =============================== reverse sweep ===================================================
         for (int kb = nbands - 1; kb >= 0; --kb) {
             const int rb = kb * 64, p = rb + lane;
@@ -234,6 +263,9 @@ __global__ __launch_bounds__(SNW * 64, (DPAD == 16 && GRAD) ? 2 : 3) void gram_s
             sf32x2 acc[DPAD / 2];
 #pragma unroll
             for (int c = 0; c < DPAD / 2; ++c) acc[c] = sf32x2{0.f, 0.f};
+            float t0 = 0.f, tacc[DPAD]; // column-side travelling sums (SYM)
+#pragma unroll
+            for (int c = 0; c < DPAD; ++c) tacc[c] = 0.f;
             const int sig_hi = P + 63; // first anti-diagonal on which some lane has a column <= P
             for (int sigma = sig_hi; sigma >= -2; --sigma) {
                 const int q = sigma - lane; // static-kernel column evaluated now == PDE column
@@ -260,11 +292,17 @@ __global__ __launch_bounds__(SNW * 64, (DPAD == 16 && GRAD) ? 2 : 3) void gram_s
                     double u = t - ddiag;
                     u = __builtin_fma(t, aa, u);
                     const double nw = __builtin_fma(ddiag, b, u);
-                    // K[p][q] regenerated: ((K10 + K01)(1+a) - K11) / (1-b),  1/(1-b) = 1 + b + b^2 + O(b^3)
+                    // K[p][q] regenerated: ((K10 + K01)(1+a) - K11) / (1-b),  1/(1-b) = 1 + b + ... + b^6 + O(b^7).
+                    // The truncation error is injected at every cell and accumulates over the <= 63 rows between
+                    // a lane and its exact anchor row: with 1 + b + b^2 the regenerated K of a pair with
+                    // |g| <= 0.23 was off by 7e-5 (gradient 1.5e-5); six terms keep it below 1e-12.
                     const double kt = kdown + kcur;
                     double ku = kt - kddiag;
                     ku = __builtin_fma(kt, aa, ku);
-                    const double ib = __builtin_fma(b, b, b);
+                    const double b2 = b * b;
+                    const double ib0 = __builtin_fma(b, b, b);          // b + b^2
+                    const double sb = __builtin_fma(b2, b2, b2);        // b^2 + b^4
+                    const double ib = __builtin_fma(ib0, sb, ib0);      // (b + b^2)(1 + b^2 + b^4)
                     double k00 = __builtin_fma(ku, ib, ku);
                     if (p == 0) k00 = 1.0; // boundary row K[0][.] = 1 exactly
                     Snew = (float)(k00 * ddiag); // K[p][q] * U[p+1][q+1]
@@ -272,13 +310,20 @@ __global__ __launch_bounds__(SNW * 64, (DPAD == 16 && GRAD) ? 2 : 3) void gram_s
                     ddiag = down;
                     kcur = k00;
                     kddiag = kdown;
-                    if (lane == 0 && kb > 0) Ubnd[q] = nw; // U[rb][q] for the band above
+                    if (lane == 0 && kb > 0) {
+                        Ubnd[q] = nw;      // U[rb][q] for the band above
+                        Srow2[q] = Snew;   // S[rb][q]: this row's 4-corner scatter is completed in the hand-over pass
+                    }
                     if (lane == 63 && has_next) Srow[q] = Snew;  // S[rb+63][q] for the row beyond the band
                 }
                 // lagged 4-corner scatter and row-side contraction (column n = q + 2)
                 const float Na = s_shr(Snew);
                 float dN = Na - Nb;
-                const float R = (Sc - Sb) + dN;
+                float R = (Sc - Sb) + dN;
+                // The first row of a lower band sees only its own half of the scatter here; the other half
+                // (last S row of the band above) is not known yet.  Both halves are large and nearly cancel,
+                // so they are combined BEFORE the contraction, in the hand-over pass below.
+                if (kb > 0 && lane == 0) R = 0.f;
                 Sc = Sb;
                 Sb = Snew;
                 Nb = Na;
@@ -291,14 +336,30 @@ __global__ __launch_bounds__(SNW * 64, (DPAD == 16 && GRAD) ? 2 : 3) void gram_s
                 s0 += rg;
 #pragma unroll
                 for (int c = 0; c < DPAD / 2; ++c) acc[c] = __builtin_elementwise_fma(rg2, yr[c], acc[c]);
+                if (SYM) {
+                    // column n = q + 2 sits one lane lower on the next step: rotate-and-add; lane 0 holds the
+                    // finished band sum of column sigma + 2 and files it in the shared image
+                    const float rgc = rg * w_ji;
+                    t0 = add_shl1z(t0, rgc);
+#pragma unroll
+                    for (int c = 0; c < DPAD; ++c) tacc[c] = add_shl1z(tacc[c], rgc * xf[c]);
+                    const int n0 = sigma + 2;
+                    if (lane == 0 && n0 >= 0 && n0 <= P) {
+#pragma unroll
+                        for (int c = 0; c < DPAD; ++c) atomicAdd(&colacc[n0 * CS + c], tacc[c]);
+                        atomicAdd(&colacc[n0 * CS + DPAD], t0);
+                    }
+                }
             }
 #pragma unroll
             for (int c = 0; c < DPAD; ++c) gacc[kb][c] += w_ij * m2h * (xf[c] * s0 - acc[c / 2][c % 2]);
 
             if (has_next) {
-                // Row m' = rb+64 belongs to the band below but its 4-corner scatter also takes the last S row
-                // of THIS band: R'[m',n] = S[rb+63][n-1] - S[rb+63][n].  One dense pass over n (lanes = n).
+                // Row m' = rb+64 belongs to the band below; its 4-corner scatter takes the last S row of THIS band
+                // and its own S row (left in LDS by the band below):
+                // R[m',n] = (S[rb+63][n-1] - S[rb+63][n]) + (S[m'][n] - S[m'][n-1]).  One dense pass over n (lanes = n).
                 const int mp = rb + 64;
+                const bool own = mp < P; // row m' has PDE cells of its own
                 float ps0 = 0.f, part[DPAD], xm[DPAD];
 #pragma unroll
                 for (int c = 0; c < DPAD; ++c) {
@@ -308,10 +369,18 @@ __global__ __launch_bounds__(SNW * 64, (DPAD == 16 && GRAD) ? 2 : 3) void gram_s
                 for (int n = lane; n <= P; n += 64) {
                     const float Sa = (n >= 1) ? Srow[n - 1] : 0.f;
                     const float Sz = (n <= P - 1) ? Srow[n] : 0.f;
-                    const float rgn = (Sa - Sz) * Gb32[n];
+                    const float Ta = (own && n >= 1) ? Srow2[n - 1] : 0.f;
+                    const float Tz = (own && n <= P - 1) ? Srow2[n] : 0.f;
+                    const float rgn = ((Sa - Sz) + (Tz - Ta)) * Gb32[n];
                     ps0 += rgn;
 #pragma unroll
                     for (int c = 0; c < DPAD; ++c) part[c] = __builtin_fmaf(rgn, yf[n * YFS + c], part[c]);
+                    if (SYM) {
+                        const float rgc = rgn * w_ji;
+#pragma unroll
+                        for (int c = 0; c < DPAD; ++c) atomicAdd(&colacc[n * CS + c], rgc * xm[c]);
+                        atomicAdd(&colacc[n * CS + DPAD], rgc);
+                    }
                 }
 #pragma unroll
                 for (int c = 0; c < DPAD; ++c) {
@@ -320,6 +389,18 @@ __global__ __launch_bounds__(SNW * 64, (DPAD == 16 && GRAD) ? 2 : 3) void gram_s
                     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
                     if (lane == 0 && c < d) unsafeAtomicAdd(&a.gacc[((size_t)i * T + mp) * d + c], (double)v);
                 }
+            }
+        }
+        } // GRAD
+        } // this wavefront's pair
+        if (GRAD && SYM) {
+            // close the column-side sums of y_j over the four rows of the tile:
+            // d/dy_n = -(2/h) * (y~_n * sum_m w R G - sum_m w R G x~_m)
+            __syncthreads();
+            for (int e = tid; e < T * DPAD; e += NT) {
+                const int n = e / DPAD, c = e % DPAD;
+                const float v = m2h * (yf[n * YFS + c] * colacc[n * CS + DPAD] - colacc[n * CS + c]);
+                if (c < d && v != 0.f) unsafeAtomicAdd(&a.gacc[((size_t)j * T + n) * d + c], (double)v);
             }
         }
     }
@@ -360,30 +441,51 @@ int stream_workspace_bytes(int A, int T, int d, int want_grad, size_t *bytes)
 
 namespace {
 template <int DPAD>
-int stream_launch_variant(const GramProblem &p, StreamArgs &a, bool grad)
+int stream_launch_variant(const GramProblem &p, StreamArgs &a, bool grad, bool sym)
 {
     const int ntile = (p.A + SNW - 1) / SNW;
+    const int owned = (ntile - a.tile_offset + a.tile_stride - 1) / a.tile_stride;
+    if (owned <= 0) return SIGSVGD_OK;
     int JC = 8;
-    while (JC > 1 && (long long)ntile * ((p.B + JC - 1) / JC) < 2048) JC >>= 1;
+    while (JC > 1 && (long long)owned * ((p.B + JC - 1) / JC) < (sym ? 4096 : 2048)) JC >>= 1;
     a.JC = JC;
-    dim3 grid((p.B + JC - 1) / JC, ntile), block(SNW * 64);
-    if (grad)
-        hipLaunchKernelGGL((gram_stream_kernel<DPAD, true>), grid, block, 0, p.stream, a);
+    dim3 grid((p.B + JC - 1) / JC, owned), block(SNW * 64);
+    if (grad && sym)
+        hipLaunchKernelGGL((gram_stream_kernel<DPAD, true, true>), grid, block, 0, p.stream, a);
+    else if (grad)
+        hipLaunchKernelGGL((gram_stream_kernel<DPAD, true, false>), grid, block, 0, p.stream, a);
+    else if (sym)
+        hipLaunchKernelGGL((gram_stream_kernel<DPAD, false, true>), grid, block, 0, p.stream, a);
     else
-        hipLaunchKernelGGL((gram_stream_kernel<DPAD, false>), grid, block, 0, p.stream, a);
+        hipLaunchKernelGGL((gram_stream_kernel<DPAD, false, false>), grid, block, 0, p.stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "launch gram_stream_kernel");
     return SIGSVGD_OK;
+}
+
+int stream_dispatch(const GramProblem &p, StreamArgs &a, bool grad, bool sym)
+{
+    if (p.d <= 4) return stream_launch_variant<4>(p, a, grad, sym);
+    if (p.d <= 8) return stream_launch_variant<8>(p, a, grad, sym);
+    return stream_launch_variant<16>(p, a, grad, sym);
+}
+
+void stream_fill_args(const GramProblem &p, StreamArgs &a)
+{
+    a.X = p.X; a.Y = p.Y; a.go = p.grad_out; a.K = p.K_out; a.gacc = nullptr;
+    a.io64 = p.dtype == SIGSVGD_F64; a.A = p.A; a.B = p.B; a.T = p.T; a.d = p.d; a.JC = 1;
+    a.symw = (p.flags & SIGSVGD_FLAG_SYM) ? 1 : 0; a.inv_h = p.inv_h;
+    a.tile_offset = 0; a.tile_stride = 1;
 }
 } // namespace
 
 int stream_launch(const GramProblem &p)
 {
     const bool grad = p.gradX_out != nullptr;
+    // the caller states that Y is X: solve each unordered pair once
+    const bool sym = (p.flags & SIGSVGD_FLAG_Y_IS_X) && p.A == p.B;
     StreamArgs a;
-    a.X = p.X; a.Y = p.Y; a.go = p.grad_out; a.K = p.K_out; a.gacc = nullptr;
-    a.io64 = p.dtype == SIGSVGD_F64; a.A = p.A; a.B = p.B; a.T = p.T; a.d = p.d; a.JC = 1;
-    a.symw = (p.flags & SIGSVGD_FLAG_SYM) ? 1 : 0; a.inv_h = p.inv_h;
+    stream_fill_args(p, a);
     if (a.symw && p.A != p.B) {
         set_error("sym backward needs A == B");
         return SIGSVGD_E_BADARG;
@@ -399,13 +501,7 @@ int stream_launch(const GramProblem &p)
         hipError_t e = hipMemsetAsync(a.gacc, 0, nacc * sizeof(double), p.stream);
         if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(gacc)");
     }
-    int rc;
-    if (p.d <= 4)
-        rc = stream_launch_variant<4>(p, a, grad);
-    else if (p.d <= 8)
-        rc = stream_launch_variant<8>(p, a, grad);
-    else
-        rc = stream_launch_variant<16>(p, a, grad);
+    int rc = stream_dispatch(p, a, grad, sym);
     if (rc) return rc;
     if (grad) {
         const int bs = 256;
@@ -420,6 +516,23 @@ int stream_launch(const GramProblem &p)
         if (e != hipSuccess) return hip_fail(e, "launch stream_finalize_kernel");
     }
     return SIGSVGD_OK;
+}
+
+// Sharded partial solve (sigsvgd_gram_sym_partial) for the streaming shapes: row tiles of SNW = 4 rows,
+// tiles tile_offset + k * tile_stride, both orientations of K stored into the caller-zeroed K_partial,
+// gradient shares accumulated (fp64 atomics) straight into the caller-zeroed grad_partial.
+int stream_sym_partial(const GramProblem &p, int tile_offset, int tile_stride, double *grad_partial)
+{
+    if (tile_stride < 1 || tile_offset < 0 || tile_offset >= tile_stride) {
+        set_error("bad tile_offset/tile_stride %d/%d", tile_offset, tile_stride);
+        return SIGSVGD_E_BADARG;
+    }
+    StreamArgs a;
+    stream_fill_args(p, a);
+    a.gacc = grad_partial;
+    a.tile_offset = tile_offset;
+    a.tile_stride = tile_stride;
+    return stream_dispatch(p, a, true, true);
 }
 
 } // namespace sigsvgd

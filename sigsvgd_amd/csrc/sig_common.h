@@ -126,5 +126,6 @@ int fast_sym_partial(const GramProblem &p, int tile_offset, int tile_stride, dou
 bool stream_supported(int A, int B, int T, int d, int n, int kind, unsigned flags);
 int stream_workspace_bytes(int A, int T, int d, int want_grad, size_t *bytes);
 int stream_launch(const GramProblem &p);
+int stream_sym_partial(const GramProblem &p, int tile_offset, int tile_stride, double *grad_partial);
 
 } // namespace sigsvgd

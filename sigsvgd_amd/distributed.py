@@ -94,11 +94,11 @@ class ShardedSigSVGD:
 
     @staticmethod
     def _partial_supported(X_full) -> bool:
-        """shapes the register-resident symmetric kernel covers (include/sigsvgd_hip.h)"""
-        return 3 <= X_full.shape[1] <= 64 and X_full.shape[2] <= 16
+        """shapes the register-resident and streaming symmetric kernels cover (include/sigsvgd_hip.h)"""
+        return 3 <= X_full.shape[1] <= 128 and X_full.shape[2] <= 16
 
     def _step_rowwise(self, X_shard, X_full, s_full):
-        """Fallback for shapes outside the symmetric partial solve (e.g. T = 128): each rank solves
+        """Fallback for shapes outside the symmetric partial solve (e.g. T > 128): each rank solves
         the ordered pairs (own rows) x (all columns), so its rows of K, grad_k and v are complete
         locally and no reduce-scatter is needed -- at twice the pair solves."""
         K_rows, g_rows = self.rows_fn(X_shard, X_full, self.inv_h)

@@ -42,11 +42,11 @@ def svgd_phi(K, score, grad_k, mask=None, X=None, lr=None):
 
 
 def gram_sym_partial(X, inv_h, tile_offset, tile_stride, static_kind=0, grad_out=None, sym=False):
-    """Same ownership rule as the HIP kernel: unordered pairs {i<=j} whose 8-row (d<=8) / 4-row tile of
-    i has index tile_offset mod tile_stride."""
+    """Same ownership rule as the HIP kernels: unordered pairs {i<=j} whose 8-row (T<=64 and d<=8) / 4-row
+    tile of i has index tile_offset mod tile_stride."""
     Xn = _np(X)
     N, T, d = Xn.shape
-    nw = 8 if d <= 8 else 4
+    nw = 8 if (d <= 8 and T <= 64) else 4
     K_full, g, G = O.gram_forward_full(Xn, Xn, static_kind, 1.0 / inv_h, 0)
     Kp = np.zeros((N, N))
     gp = np.zeros((N, T, d))

@@ -53,3 +53,70 @@ def test_stream_self_gram_c5_shape(gpu):
     assert _rel(K.cpu().numpy(), Kref) < TOL and _rel(g.cpu().numpy(), gref) < TOL
     K2, g2 = ops.gram_fwd_bwd(Xg, Xg, 1.0, sym=True, y_is_x=True)
     assert _rel(g2.cpu().numpy(), 2 * gref) < TOL
+
+
+@pytest.mark.parametrize("N,T,d", [(9, 128, 14), (13, 65, 3), (6, 100, 7), (5, 127, 16), (1, 96, 2), (17, 128, 1)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_stream_symmetric_solve_equals_ordered_pairs(gpu, N, T, d, dtype):
+    """y_is_x=True solves every unordered pair once (mirrored K, column-side gradient through the
+    travelling accumulators); with asymmetric weights it must still equal the ordered-pair result."""
+    from sigsvgd_amd import ops
+
+    X = _paths(N, T, d, 5)
+    h = 0.9
+    go = np.random.default_rng(6).standard_normal((N, N)).astype(np.float32)
+    Kref, gref = C.gram_fwd_bwd(X, X, h, 0, grad_out=go.astype(np.float64))
+    Xg, gog = torch.as_tensor(X, device=gpu).to(dtype), torch.as_tensor(go, device=gpu).to(dtype)
+    K, g = ops.gram_fwd_bwd(Xg, Xg, 1.0 / h, grad_out=gog, y_is_x=True)
+    assert _rel(K.cpu().numpy(), Kref) < TOL and _rel(g.cpu().numpy(), gref) < TOL
+    assert torch.equal(K, K.T)  # mirrored stores
+    Ko, g_o = ops.gram_fwd_bwd(Xg, Xg, 1.0 / h, grad_out=gog)  # ordered pairs on the same kernel family
+    assert _rel(K.cpu().numpy(), Ko.double().cpu().numpy()) < 1e-6
+    assert _rel(g.cpu().numpy(), g_o.double().cpu().numpy()) < 1e-5
+    # ones weights, and the sym=True weighting (grad_out symmetrised)
+    K1, g1 = ops.gram_fwd_bwd(Xg, Xg, 1.0 / h, y_is_x=True)
+    _, gref1 = C.gram_fwd_bwd(X, X, h, 0)
+    assert _rel(g1.cpu().numpy(), gref1) < TOL
+    _, g2 = ops.gram_fwd_bwd(Xg, Xg, 1.0 / h, grad_out=gog, sym=True, y_is_x=True)
+    _, gref2 = C.gram_fwd_bwd(X, X, h, 0, grad_out=(go + go.T).astype(np.float64))
+    assert _rel(g2.cpu().numpy(), gref2) < TOL
+
+
+@pytest.mark.parametrize("N,T,d,world", [(22, 128, 14, 3), (10, 70, 5, 2), (9, 96, 3, 4)])
+def test_stream_partials_sum_to_full(gpu, N, T, d, world):
+    """sigsvgd_gram_sym_partial on the long-path shapes: the per-rank partials (4-row tiles, cyclic) add up
+    to the full symmetric solve, and each owned pair appears in exactly one partial."""
+    from sigsvgd_amd import ops
+
+    X = _paths(N, T, d, 8)
+    Xg = torch.as_tensor(X, device=gpu)
+    go = torch.as_tensor(np.random.default_rng(9).uniform(0.5, 1.5, (N, N)).astype(np.float32), device=gpu)
+    Kf, gf = ops.gram_fwd_bwd(Xg, Xg, 1.0, grad_out=go, y_is_x=True)
+    Ks = torch.zeros_like(Kf)
+    gs = torch.zeros(N, T, d, dtype=torch.float64, device=gpu)
+    cover = torch.zeros(N, N, device=gpu)
+    for r in range(world):
+        Kp, gp = ops.gram_sym_partial(Xg, 1.0, r, world, grad_out=go)
+        Ks += Kp
+        gs += gp
+        cover += (Kp != 0).float()
+    assert torch.equal(cover, torch.ones_like(cover))
+    assert torch.equal(Ks, Kf)
+    assert _rel(gs.cpu().numpy(), gf.double().cpu().numpy()) < 1e-6
+    Kref, gref = C.gram_fwd_bwd(X, X, 1.0, 0, grad_out=go.double().cpu().numpy())
+    assert _rel(gs.cpu().numpy(), gref) < TOL
+
+
+def test_stream_symmetric_large_property(gpu):
+    """C5 path shape at N=96: K symmetric with unit-free diagonal structure, and the symmetric solve equals
+    the ordered solve (no oracle at this size)."""
+    from sigsvgd_amd import ops
+
+    X, _ = O.synthetic_inputs(96, 128, 14)
+    Xg = X.to(gpu)
+    K, g = ops.gram_fwd_bwd(Xg, Xg, 1.0, y_is_x=True)
+    Ko, g_o = ops.gram_fwd_bwd(Xg, Xg.clone(), 1.0)
+    assert torch.equal(K, K.T)
+    assert _rel(K.cpu().numpy(), Ko.double().cpu().numpy()) < 1e-6
+    assert _rel(g.cpu().numpy(), g_o.double().cpu().numpy()) < 1e-5
+    assert torch.isfinite(g).all()
