@@ -19,9 +19,12 @@
 // SYM (Y is X): only pairs j >= i are solved; K is mirrored and the column-side gradient
 // sum_m R G[m,n] x~_m (= d k(x_j, x_i)/d x_j) rides travelling accumulators as in gram_fast.hip (one
 // v_add_f32_dpp wave_shl:1 per running sum and step; lane 63 starts every column from the DPP zero fill).
-// With 128 columns and 64 lanes a column is finished when it leaves lane 0, so lane 0 adds it to a
-// [T][DPAD+1] fp32 image in LDS shared by the four wavefronts (ds_add_f32), which is closed
-// (y~_n * sum - sums) and sent to the fp64 accumulation buffer once per column trajectory.
+// With 128 columns and 64 lanes a column is finished (for this band) when it leaves lane 0: lane 0 files
+// it in a per-wave [64][DPAD+1] staging block in LDS (plain stores); every 64 columns all lanes add one
+// staged column each to a [T][DPAD+1] image shared by the four wavefronts (ds_add_f32, distinct addresses),
+// which is closed (y~_n * sum - sums) and sent to the fp64 accumulation buffer once per column trajectory.
+// (Measured at N=1024, T=128, d=14: single-lane ds_add_f32 per step 136 ms, closing every wave's block
+// straight into global fp64 atomics 140 ms, this scheme: see DESIGN.md.)
 //
 // Reference semantics: sigkernel _SigKernelGram.forward/backward [RECALLED, SURVEY.md App. A];
 // static kernel src/kernels/_traj_kernels.py:176-195.
@@ -86,20 +89,38 @@ __global__ __launch_bounds__(SNW * 64, (DPAD == 16 && GRAD) ? 2 : 3) void gram_s
     __shared__ __align__(16) double yd[TMAX * YDS];
     __shared__ __align__(16) float yf[GRAD ? TMAX * YFS : 4];
     __shared__ double yref[DPAD];
-    __shared__ double rows_all[SNW * 6 * RB];
-    __shared__ float colacc[(GRAD && SYM) ? TMAX * CS : 4]; // [n][c] sums of w R G x~_m, [n][DPAD] sums of w R G
+    constexpr int WR = 5 * RB + RB / 2; // doubles per wave: five fp64/fp32-pair rows + one fp32 row
+    __shared__ double rows_all[SNW * WR];
+    __shared__ float colstage[(GRAD && SYM) ? SNW * 64 * CS : 4]; // per wave: [n & 63][c] = sum_m w R G x~_m, [..][DPAD] = sum_m w R G
+    __shared__ float colacc[(GRAD && SYM) ? TMAX * CS : 4];       // the same sums over both bands and the four rows of the tile
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int T = a.T, d = a.d, P = T - 1, io64 = a.io64;
-    const int i0 = (a.tile_offset + (int)blockIdx.y * a.tile_stride) * SNW;
+    // Ordered launches: 2-D grid (column chunk, owned row tile).  Symmetric launches: 1-D grid over the chunks
+    // that reach the diagonal of their row tile, decoded with a short scalar scan (workgroups that only
+    // exit early still cost a dispatch slot with 70 KB of LDS: 30 % of a symmetric launch at N = 1024).
+    int ty = blockIdx.y, cx = blockIdx.x;
+    if (SYM) {
+        const int nJ = (a.B + a.JC - 1) / a.JC;
+        int rem = blockIdx.x;
+        for (ty = 0;; ++ty) {
+            const int first = ((a.tile_offset + ty * a.tile_stride) * SNW) / a.JC; // first chunk with j1 > i0
+            const int cnt = nJ - first;
+            if (rem < cnt) {
+                cx = first + rem;
+                break;
+            }
+            rem -= cnt;
+        }
+    }
+    const int i0 = (a.tile_offset + ty * a.tile_stride) * SNW;
     const int i = i0 + wave;
-    const int j0 = blockIdx.x * a.JC, j1 = min(a.B, j0 + a.JC);
-    if (SYM && j1 <= i0) return; // chunk entirely left of the diagonal: solved from the other side
+    const int j0 = cx * a.JC, j1 = min(a.B, j0 + a.JC);
     const bool row_ok = i < a.A;
     const double inv_h = a.inv_h;
     const double nscale = -inv_h * 1.4426950408889634074;
     const float m2h = (float)(-2.0 * inv_h);
-    double *Kbnd = rows_all + (size_t)wave * 6 * RB; // K[64][.]   forward band boundary (kept for the K regeneration)
+    double *Kbnd = rows_all + (size_t)wave * WR; // K[64][.]   forward band boundary (kept for the K regeneration)
     double *Klast = Kbnd + RB;                       // K[P][.]    last forward row
     double *Ubnd = Klast + RB;                       // U[64][.]   reverse band boundary
     double *Gbd = Ubnd + RB;                         // G[64][q+1] - G[64][q]: row beyond band 0
@@ -241,6 +262,17 @@ __global__ __launch_bounds__(SNW * 64, (DPAD == 16 && GRAD) ? 2 : 3) void gram_s
             if (lane == 63 && has_next) Kbnd[0] = 1.0;
         }
         if (GRAD) {
+        float *stg = colstage + ((GRAD && SYM) ? wave * 64 * CS : 0);
+        // 64 staged columns (one per lane) join the tile's image: 17 ds_add_f32 with distinct addresses per lane
+        auto col_close = [&](int nbase) {
+            const int n = nbase + lane;
+            if (n <= P) {
+                const float *src = stg + lane * CS;
+                float *dst = colacc + n * CS;
+#pragma unroll
+                for (int c = 0; c <= DPAD; ++c) atomicAdd(dst + c, src[c]);
+            }
+        };
         // =============================== reverse sweep ===================================================
         for (int kb = nbands - 1; kb >= 0; --kb) {
             const int rb = kb * 64, p = rb + lane;
@@ -340,15 +372,22 @@ __global__ __launch_bounds__(SNW * 64, (DPAD == 16 && GRAD) ? 2 : 3) void gram_s
                     // column n = q + 2 sits one lane lower on the next step: rotate-and-add; lane 0 holds the
                     // finished band sum of column sigma + 2 and files it in the shared image
                     const float rgc = rg * w_ji;
+                    const sf32x2 rgc2 = {rgc, rgc};
                     t0 = add_shl1z(t0, rgc);
 #pragma unroll
-                    for (int c = 0; c < DPAD; ++c) tacc[c] = add_shl1z(tacc[c], rgc * xf[c]);
+                    for (int c = 0; c < DPAD / 2; ++c) {
+                        const sf32x2 pr = rgc2 * sf32x2{xf[2 * c], xf[2 * c + 1]};
+                        tacc[2 * c] = add_shl1z(tacc[2 * c], pr[0]);
+                        tacc[2 * c + 1] = add_shl1z(tacc[2 * c + 1], pr[1]);
+                    }
                     const int n0 = sigma + 2;
                     if (lane == 0 && n0 >= 0 && n0 <= P) {
+                        float *dst = stg + (n0 & 63) * CS;
 #pragma unroll
-                        for (int c = 0; c < DPAD; ++c) atomicAdd(&colacc[n0 * CS + c], tacc[c]);
-                        atomicAdd(&colacc[n0 * CS + DPAD], t0);
+                        for (int c = 0; c < DPAD; ++c) dst[c] = tacc[c];
+                        dst[DPAD] = t0;
                     }
+                    if (n0 == 64 || n0 == 0) col_close(n0); // columns n0 .. n0+63 of this band are staged
                 }
             }
 #pragma unroll
@@ -450,6 +489,16 @@ int stream_launch_variant(const GramProblem &p, StreamArgs &a, bool grad, bool s
     while (JC > 1 && (long long)owned * ((p.B + JC - 1) / JC) < (sym ? 4096 : 2048)) JC >>= 1;
     a.JC = JC;
     dim3 grid((p.B + JC - 1) / JC, owned), block(SNW * 64);
+    if (sym) { // count the chunks on or right of the diagonal of every owned tile
+        const int nJ = (p.B + JC - 1) / JC;
+        long long total = 0;
+        for (int k = 0; k < owned; ++k) {
+            const int first = ((a.tile_offset + k * a.tile_stride) * SNW) / JC;
+            if (first < nJ) total += nJ - first;
+        }
+        if (total <= 0) return SIGSVGD_OK;
+        grid = dim3((unsigned)total, 1);
+    }
     if (grad && sym)
         hipLaunchKernelGGL((gram_stream_kernel<DPAD, true, true>), grid, block, 0, p.stream, a);
     else if (grad)
