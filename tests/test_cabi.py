@@ -79,7 +79,7 @@ def test_argument_errors_are_status_codes(lib):
     assert rc == -3 and b"workspace" in lib.sigsvgd_last_error()  # workspace missing
     rc = lib.sigsvgd_gram_sym_partial(one, 4, 5, 2, 0, 1.0, 0, 0, 2, 2, None, one, one, None, 0, None)
     assert rc == -1  # tile_offset >= tile_stride
-    rc = lib.sigsvgd_gram_sym_partial(one, 4, 100, 2, 0, 1.0, 0, 0, 0, 1, None, one, one, None, 0, None)
-    assert rc == -2  # T > 64 is outside the register-resident path
+    rc = lib.sigsvgd_gram_sym_partial(one, 4, 200, 2, 0, 1.0, 0, 0, 0, 1, None, one, one, None, 0, None)
+    assert rc == -2  # T > 128 is outside the register-resident and streaming paths
     rc = lib.sigsvgd_svgd_phi(None, one, one, None, 4, 4, one, None, None, 0.1, None)
     assert rc == -1
