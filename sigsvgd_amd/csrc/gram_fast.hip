@@ -558,7 +558,7 @@ int launch_variant(const GramProblem &p, FastArgs &a, bool grad, bool sym)
     // Column chunk: chunks are pulled from a queue, so short ones cost only their staging prologue
     // (~1 % at 4 columns) and buy fine-grained balance; tiny problems go down to single columns.
     int JC = 4;
-    while (JC > 1 && nblocks(JC) < 256 * 8) JC >>= 1;
+    while (JC > 1 && nblocks(JC) < 256 * 16) JC >>= 1;
     a.JC = JC;
     a.owned = owned;
     // the queue lives behind the fp64 accumulation buffer in the caller's workspace
