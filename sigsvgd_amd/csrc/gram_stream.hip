@@ -183,12 +183,13 @@ __global__ __launch_bounds__(SNW * 64, (DPAD == 16 && GRAD) ? 2 : 3) void gram_s
             }
             xn *= nscale;
         };
+        Exp2Coef ek = exp2_coef();
         auto Geval = [&](int col) { // G[p, col] for this lane's row (col clamped; caller masks)
             const double *yr = yd + min(max(col, 0), P) * YDS;
             double e2 = xn + yr[DPAD];
 #pragma unroll
             for (int c = 0; c < DPAD; ++c) e2 = __builtin_fma(xs[c], yr[c], e2);
-            return exp2_p8(e2);
+            return exp2_p8(e2, ek);
         };
 
         // =============================== forward sweep ===================================================
@@ -220,6 +221,7 @@ __global__ __launch_bounds__(SNW * 64, (DPAD == 16 && GRAD) ? 2 : 3) void gram_s
             double cur = 1.0, diag = 1.0, gprev = 0.0, rdprev = 0.0;
             const int nsteps = P + 1 + 64 + 2;
             for (int s = 0; s < nsteps; ++s) {
+                exp2_coef_pin(ek);
                 const int c = s - lane;     // column of the static kernel evaluated now
                 const int q = c - 2;        // PDE column
                 const double g = Geval(c);
@@ -300,6 +302,7 @@ __global__ __launch_bounds__(SNW * 64, (DPAD == 16 && GRAD) ? 2 : 3) void gram_s
             for (int c = 0; c < DPAD; ++c) tacc[c] = 0.f;
             const int sig_hi = P + 63; // first anti-diagonal on which some lane has a column <= P
             for (int sigma = sig_hi; sigma >= -2; --sigma) {
+                exp2_coef_pin(ek);
                 const int q = sigma - lane; // static-kernel column evaluated now == PDE column
                 const double g = Geval(q);
                 const double rd = gprev - g; // G[p,q+1] - G[p,q]   (valid for 0 <= q < P)

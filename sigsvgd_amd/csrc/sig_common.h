@@ -58,6 +58,38 @@ __device__ __forceinline__ double exp2_p8(double t)
     return ldexp(p, (int)kf);
 }
 
+// Same polynomial with the coefficients handed in by the caller, who keeps them in scalar registers inside
+// a rolled loop (empty `asm volatile("" : "+s"(c))` per iteration): hipcc otherwise hoists them into
+// VGPRs and pays one v_mov_b64 per Horner step to feed v_fmac_f64.
+struct Exp2Coef {
+    double c8, c7, c6, c5, c4, c3, c2, c1, c0;
+};
+__device__ __forceinline__ Exp2Coef exp2_coef()
+{
+    return Exp2Coef{1.3255197199834888e-06, 1.5310079063632544e-05, 1.5403455940423864e-04,
+                    1.3333450569733936e-03, 9.618129159303683e-03,  5.550410941203932e-02,
+                    2.4022650695813685e-01, 6.931471805459342e-01,  0.9999999999999997};
+}
+__device__ __forceinline__ void exp2_coef_pin(Exp2Coef &k)
+{
+    asm volatile("" : "+s"(k.c8), "+s"(k.c7), "+s"(k.c6), "+s"(k.c5), "+s"(k.c4), "+s"(k.c3), "+s"(k.c2), "+s"(k.c1),
+                 "+s"(k.c0));
+}
+__device__ __forceinline__ double exp2_p8(double t, const Exp2Coef &k)
+{
+    const double kf = __builtin_rint(t);
+    const double f = t - kf;
+    double p = __builtin_fma(k.c8, f, k.c7);
+    p = __builtin_fma(p, f, k.c6);
+    p = __builtin_fma(p, f, k.c5);
+    p = __builtin_fma(p, f, k.c4);
+    p = __builtin_fma(p, f, k.c3);
+    p = __builtin_fma(p, f, k.c2);
+    p = __builtin_fma(p, f, k.c1);
+    p = __builtin_fma(p, f, k.c0);
+    return ldexp(p, (int)kf);
+}
+
 // ---- Goursat stencils -------------------------------------------------------------------------
 // default (second order):  K11 = (K10 + K01)*(1 + g/2 + g^2/12) - K00*(1 - g^2/12)
 // written in delta form so that the O(1) parts cancel exactly in fp64:
