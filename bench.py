@@ -201,6 +201,21 @@ def main():
             },
         }
 
+    # ---- second figure: the reference's eager per-iteration `.cpu()` of K, grad_k and v
+    # (svgd.py:85-90), PCIe-inclusive.  Reported beside `value`, never as `value`.
+    eager = None
+    if rank == 0 and not use_dist:
+        Xe2 = X0.to(dev)
+        n_e = 20
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_e):
+            K, gk = ops.gram_fwd_bwd(Xe2, Xe2, 1.0 / H, 0, y_is_x=True)
+            v, Xe2 = ops.svgd_phi(K, score, gk, X=Xe2, lr=LR)
+            _ = (K.cpu(), gk.cpu(), v.cpu())
+        torch.cuda.synchronize()
+        eager = n_e / (time.perf_counter() - t0)
+
     if rank == 0:
         out = {
             "metric": "SVGD iters/sec, sig-kernel N=1024 T=64 d=7",
@@ -223,6 +238,7 @@ def main():
                 "parallelism": f"particle-sharded x{world}" if world > 1 else "single GPU",
                 "host_copies": "none in the timed region (reference-style eager .cpu() of K is opt-in)",
             },
+            "eager_cpu_copies_iters_per_sec": eager,
             "roofline": roofline,
         }
         if not args.no_cpu_baseline and world == 1:

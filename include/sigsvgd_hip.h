@@ -62,7 +62,13 @@ extern "C" {
 #define SIGSVGD_FLAG_SYM 2u          /* sigkernel sym=True backward weighting: go + go^T (A==B) */
 #define SIGSVGD_FLAG_Y_IS_X 4u       /* caller guarantees Y aliases X (same values): lets the   */
                                      /* library solve each unordered pair once                  */
-#define SIGSVGD_FLAG_FORCE_GENERIC 8u /* testing: bypass the register-resident fast kernels     */
+#define SIGSVGD_FLAG_FORCE_GENERIC 8u /* use the coverage kernel (keeps the forward solution in  */
+                                      /* HBM): tests, and long paths (65 <= T <= 128) so rough    */
+                                      /* that a static-kernel increment exceeds SIGSVGD_STREAM_GMAX:*/
+                                      /* the streaming kernel regenerates the forward solution    */
+                                      /* backwards, trusts that only up to this increment size,   */
+                                      /* and returns NaN gradients for pairs beyond it            */
+#define SIGSVGD_STREAM_GMAX 0.4
 
 /* errors */
 #define SIGSVGD_OK 0

@@ -45,6 +45,7 @@ namespace {
 constexpr int SNW = 4;     // wavefronts (rows i) per workgroup
 constexpr int TMAX = 128;  // longest supported path
 constexpr int RB = TMAX + 4; // row-buffer length
+constexpr double STREAM_GMAX = SIGSVGD_STREAM_GMAX; // largest static-kernel increment the K regeneration is trusted with
 
 using sf32x2 = __attribute__((ext_vector_type(2))) float;
 
@@ -157,6 +158,7 @@ __global__ __launch_bounds__(SNW * 64, (DPAD == 16 && GRAD) ? 2 : 3) void gram_s
         if (row_ok && (!SYM || j >= i)) {
 
         double kfin[2] = {1.0, 1.0}; // K[p+1][P] per band: last-column seeds of the K regeneration
+        double gmax = 0.0;           // largest |increment| of this pair (regeneration guard below)
         float w_ij = 1.f, w_ji = 1.f; // row-side / column-side weights
         if (GRAD) {
             if (a.go) {
@@ -235,6 +237,7 @@ __global__ __launch_bounds__(SNW * 64, (DPAD == 16 && GRAD) ? 2 : 3) void gram_s
                 const bool act = pde_row && q >= 0 && q < P;
                 if (lane == 0) up = (kb == 0 || !act) ? 1.0 : Kbnd[q + 1];
                 if (act) {
+                    if (GRAD) gmax = fmax(gmax, fabs(gq));
                     const double b = gq * gq * (1.0 / 12.0);
                     const double aa = __builtin_fma(gq, 0.5, b);
                     const double t = cur + up;
@@ -264,6 +267,22 @@ __global__ __launch_bounds__(SNW * 64, (DPAD == 16 && GRAD) ? 2 : 3) void gram_s
             if (lane == 63 && has_next) Kbnd[0] = 1.0;
         }
         if (GRAD) {
+        // Guard: regenerating K_fwd backwards amplifies rounding errors by a factor that grows with the
+        // increments (oracle experiment, 63 rows from the anchor row: 5e-8 at max|g| = 0.37, 4e-6 at 0.45,
+        // 2e-3 at 0.54).  Pairs beyond STREAM_GMAX (in practice: a rough path against itself, K > 1e6) get
+        // NaN gradients -- loud, not silently wrong; callers route such inputs to the coverage kernel
+        // (SIGSVGD_FLAG_FORCE_GENERIC), which keeps the forward solution.
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) gmax = fmax(gmax, __shfl_xor(gmax, off, 64));
+        const bool risky = !(gmax <= STREAM_GMAX);
+        if (risky) {
+            const float qnan = __builtin_nanf("");
+#pragma unroll
+            for (int c = 0; c < DPAD; ++c) gacc[0][c] = gacc[1][c] = qnan;
+            if (SYM && j != i)
+                for (int e = lane; e < T * d; e += 64) unsafeAtomicAdd(&a.gacc[(size_t)j * T * d + e], (double)qnan);
+        }
+        if (!risky) {
         float *stg = colstage + ((GRAD && SYM) ? wave * 64 * CS : 0);
         // 64 staged columns (one per lane) join the tile's image: 17 ds_add_f32 with distinct addresses per lane
         auto col_close = [&](int nbase) {
@@ -433,6 +452,7 @@ __global__ __launch_bounds__(SNW * 64, (DPAD == 16 && GRAD) ? 2 : 3) void gram_s
                 }
             }
         }
+        } // !risky
         } // GRAD
         } // this wavefront's pair
         if (GRAD && SYM) {

@@ -108,15 +108,39 @@ def gram_fwd(X, Y, inv_h: float, dyadic_order: int = 0, static_kind: int = _lib.
     return K
 
 
+STREAM_GMAX = 0.4  # include/sigsvgd_hip.h SIGSVGD_STREAM_GMAX
+
+
+def _needs_coverage_kernel(Xc, Yc, inv_h: float, dyadic_order: int, static_kind: int) -> bool:
+    """Long paths (65 <= T <= 128, dyadic order 0, RBF) run on the streaming kernel, which regenerates the
+    forward solution backwards and is accurate only while the static-kernel increments stay below
+    STREAM_GMAX (it returns NaN gradients beyond).  The largest increment of a launch is that of a path
+    against itself, 2 (1 - exp(-max |dx|^2 / h)): one small device reduction + one scalar read-back."""
+    T = Xc.shape[1]
+    if dyadic_order != 0 or static_kind != _lib.STATIC_RBF or T < 65 or T > 128 or Xc.shape[2] > 16:
+        return False
+    m = (Xc[:, 1:] - Xc[:, :-1]).square().sum(-1).max()
+    if Yc is not Xc:
+        m = torch.maximum(m, (Yc[:, 1:] - Yc[:, :-1]).square().sum(-1).max())
+    gest = 2.0 * (1.0 - torch.exp(-float(inv_h) * m.double()))
+    return bool(gest > STREAM_GMAX)  # NaN increments fall through to the streaming kernel (NaN out either way)
+
+
 def gram_fwd_bwd(X, Y, inv_h: float, dyadic_order: int = 0, static_kind: int = _lib.STATIC_RBF,
                  grad_out: Optional[torch.Tensor] = None, naive: bool = False, sym: bool = False,
-                 y_is_x: bool = False, force_generic: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
-    """(K[A,B], gradX[A,T,d]) with gradX = d sum(grad_out*K)/dX (first slot); grad_out None = ones."""
+                 y_is_x: bool = False, force_generic: bool = False,
+                 check_regime: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(K[A,B], gradX[A,T,d]) with gradX = d sum(grad_out*K)/dX (first slot); grad_out None = ones.
+
+    check_regime: for long paths, pick the coverage kernel when the paths are too rough for the streaming
+    kernel (see _needs_coverage_kernel; costs one host sync, skipped for T <= 64)."""
     L = _lib.load()
     dev = _require_gpu(X, Y, grad_out)
     Xc, Yc = _prep_paths(X, Y)
     A, T, d = Xc.shape
     B = Yc.shape[0]
+    if check_regime and not force_generic and not naive and _needs_coverage_kernel(Xc, Yc, inv_h, dyadic_order, static_kind):
+        force_generic = True
     go = None
     if grad_out is not None:
         if tuple(grad_out.shape) != (A, B):

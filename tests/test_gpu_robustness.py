@@ -1,0 +1,111 @@
+"""GPU parity across regimes: rough / smooth paths, small / large bandwidths, degenerate paths, on all three
+solvers (register-resident T <= 64, streaming T <= 128, coverage).  Tolerance 1e-5 relative to max-abs
+(BASELINE.json north_star), fp32 I/O against the fp64 C oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle as C
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _paths(A, T, d, seed, scale):
+    rng = np.random.default_rng(seed)
+    return np.cumsum(scale * rng.standard_normal((A, T, d)), axis=1).astype(np.float32)
+
+
+def _rel(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+@pytest.mark.parametrize("T,d", [(64, 7), (33, 3), (128, 14), (96, 5)])
+@pytest.mark.parametrize("scale,h", [(0.01, 1.0), (0.05, 0.1), (0.05, 10.0), (0.15, 1.0), (0.3, 4.0), (0.02, 0.02)])
+def test_regimes_self_gram(gpu, T, d, scale, h):
+    """Y is X (the SVGD call): includes the diagonal pairs, whose K can reach 1e3 for rough paths"""
+    from sigsvgd_amd import ops
+
+    N = 10
+    X = _paths(N, T, d, 21, scale)
+    Kref, gref = C.gram_fwd_bwd(X, X, h, 0)
+    if not np.isfinite(Kref).all() or Kref.max() > 1e30:
+        pytest.skip("regime overflows the oracle")
+    Xg = torch.as_tensor(X, device=gpu)
+    K, g = ops.gram_fwd_bwd(Xg, Xg, 1.0 / h, y_is_x=True)
+    Ko, go_ = ops.gram_fwd_bwd(Xg, Xg.clone(), 1.0 / h)
+    assert torch.isfinite(K).all() and torch.isfinite(g).all()
+    assert _rel(K.cpu().numpy(), Kref) < TOL, ("K sym", Kref.max())
+    assert _rel(Ko.cpu().numpy(), Kref) < TOL, ("K ordered", Kref.max())
+    assert _rel(g.cpu().numpy(), gref) < TOL, ("grad sym", Kref.max(), np.abs(gref).max())
+    assert _rel(go_.cpu().numpy(), gref) < TOL, ("grad ordered", Kref.max(), np.abs(gref).max())
+
+
+@pytest.mark.parametrize("T,d,n", [(20, 2, 2), (10, 3, 4), (30, 2, 3)])
+@pytest.mark.parametrize("scale,h", [(0.05, 1.0), (0.3, 5.0), (0.1, 0.2)])
+def test_regimes_coverage_kernel(gpu, T, d, n, scale, h):
+    from sigsvgd_amd import ops
+
+    X, Y = _paths(6, T, d, 31, scale), _paths(7, T, d, 32, scale)
+    Kref, gref = C.gram_fwd_bwd(X, Y, h, n)
+    K, g = ops.gram_fwd_bwd(torch.as_tensor(X, device=gpu), torch.as_tensor(Y, device=gpu), 1.0 / h, n)
+    assert _rel(K.cpu().numpy(), Kref) < TOL and _rel(g.cpu().numpy(), gref) < TOL
+
+
+@pytest.mark.parametrize("T,d", [(64, 7), (128, 14), (40, 2)])
+def test_degenerate_paths(gpu, T, d):
+    """constant paths (all increments zero): K = 1 exactly and zero gradient; a path against itself
+    repeated: K symmetric with equal rows; duplicated consecutive points change nothing (g = 0 cells)."""
+    from sigsvgd_amd import ops
+
+    const = np.tile(np.random.default_rng(1).standard_normal((3, 1, d)).astype(np.float32), (1, T, 1))
+    mov = _paths(4, T, d, 2, 0.05)
+    K, g = ops.gram_fwd_bwd(torch.as_tensor(const, device=gpu), torch.as_tensor(mov, device=gpu), 1.0)
+    assert torch.equal(K, torch.ones_like(K))
+    K2, g2 = ops.gram_fwd_bwd(torch.as_tensor(mov, device=gpu), torch.as_tensor(const, device=gpu), 1.0)
+    assert torch.equal(K2, torch.ones_like(K2)) and float(g2.abs().max()) == 0.0
+    same = np.repeat(mov[:1], 5, axis=0)
+    K3, g3 = ops.gram_fwd_bwd(torch.as_tensor(same, device=gpu), torch.as_tensor(same, device=gpu), 1.0, y_is_x=True)
+    assert float((K3 - K3[0, 0]).abs().max()) <= 1e-6 * float(K3[0, 0])
+    assert _rel(g3[1:].cpu().numpy(), g3[:1].double().cpu().numpy().repeat(4, 0)) < 1e-6
+    # a repeated point: path of length T with x[t] == x[t+1] at one place vs the oracle
+    rep = mov.copy()
+    rep[:, T // 2] = rep[:, T // 2 - 1]
+    Kref, gref = C.gram_fwd_bwd(rep, mov, 1.0, 0)
+    K4, g4 = ops.gram_fwd_bwd(torch.as_tensor(rep, device=gpu), torch.as_tensor(mov, device=gpu), 1.0)
+    assert _rel(K4.cpu().numpy(), Kref) < TOL and _rel(g4.cpu().numpy(), gref) < TOL
+
+
+def test_non_finite_inputs_propagate_without_hanging(gpu):
+    """a NaN in one trajectory poisons its own row/column only; the launch completes"""
+    from sigsvgd_amd import ops
+
+    X = _paths(9, 64, 7, 5, 0.05)
+    X[3, 10, 2] = np.nan
+    Xg = torch.as_tensor(X, device=gpu)
+    K, g = ops.gram_fwd_bwd(Xg, Xg, 1.0, y_is_x=True)
+    torch.cuda.synchronize()
+    bad = torch.isnan(K)
+    assert bad[3].all() and bad[:, 3].all()
+    ok = [i for i in range(9) if i != 3]
+    assert torch.isfinite(K[ok][:, ok]).all()
+
+
+def test_streaming_kernel_guard_is_loud(gpu):
+    """Rough long paths: with the regime check off, the streaming kernel must flag the pairs whose forward
+    solution it cannot regenerate (NaN gradient rows) rather than return numbers that look plausible;
+    K itself (forward sweep only) stays exact.  With the check on, the coverage kernel takes over."""
+    from sigsvgd_amd import ops
+
+    X = _paths(6, 128, 14, 21, 0.15)
+    Kref, gref = C.gram_fwd_bwd(X, X, 1.0, 0)
+    Xg = torch.as_tensor(X, device=gpu)
+    K, g = ops.gram_fwd_bwd(Xg, Xg, 1.0, y_is_x=True, check_regime=False)
+    assert _rel(K.cpu().numpy(), Kref) < TOL
+    assert torch.isnan(g).flatten(1).all(1).all()  # every particle's own pair is beyond the guard
+    K2, g2 = ops.gram_fwd_bwd(Xg, Xg, 1.0, y_is_x=True)
+    assert _rel(K2.cpu().numpy(), Kref) < TOL and _rel(g2.cpu().numpy(), gref) < TOL
+    # smooth paths are untouched by the guard
+    Xs = torch.as_tensor(_paths(6, 128, 14, 22, 0.05), device=gpu)
+    _, gs = ops.gram_fwd_bwd(Xs, Xs, 1.0, y_is_x=True, check_regime=False)
+    assert torch.isfinite(gs).all()
