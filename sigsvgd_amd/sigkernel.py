@@ -200,6 +200,26 @@ class SigKernel:
         return _SigKernelGram.apply(X, Y, static_kind, inv_h, self.dyadic_order, self._naive_solver, bool(sym),
                                     y_is_x, self.speculate_ones)
 
+    # -- the rest of the upstream `sigkernel.SigKernel` surface [RECALLED from the public package; the
+    #    reference tree never calls these].  All go through compute_Gram, so gradients flow to the FIRST
+    #    argument only, with `sym=True` giving the symmetrised weighting for Gram(X, X).
+    def compute_kernel(self, X: torch.Tensor, Y: torch.Tensor) -> torch.Tensor:
+        """Paired kernel k_sig(X_i, Y_i) -> [batch] (taken from the Gram launch: batch^2 solves)."""
+        assert X.shape[0] == Y.shape[0], "compute_kernel pairs X_i with Y_i"
+        return self.compute_Gram(X, Y).diagonal()
+
+    def compute_distance(self, X: torch.Tensor, Y: torch.Tensor) -> torch.Tensor:
+        """mean_i k(X_i, X_i) + mean_i k(Y_i, Y_i) - 2 mean_i k(X_i, Y_i)."""
+        return (self.compute_kernel(X, X).mean() + self.compute_kernel(Y, Y).mean()
+                - 2.0 * self.compute_kernel(X, Y).mean())
+
+    def compute_mmd(self, X: torch.Tensor, Y: torch.Tensor) -> torch.Tensor:
+        """Biased squared MMD: mean K_XX + mean K_YY - 2 mean K_XY."""
+        K_XX = self.compute_Gram(X, X, sym=True)
+        K_YY = self.compute_Gram(Y, Y, sym=True)
+        K_XY = self.compute_Gram(X, Y, sym=False)
+        return K_XX.mean() + K_YY.mean() - 2.0 * K_XY.mean()
+
     def gram_and_grad(self, X: torch.Tensor, Y: Optional[torch.Tensor] = None, grad_out=None, sym: bool = False):
         """One fused launch: (K, d sum(grad_out*K)/dX) with detached tensors.  Equivalent to
         `K = compute_Gram(X, Y); g = autograd.grad((grad_out*K).sum(), X)` (score.py:68-69)."""

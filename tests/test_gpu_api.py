@@ -238,3 +238,31 @@ def test_sharded_step_on_rccl_single_rank(gpu):
         assert rel(Xc, ref["X_new"]) < TOL
     finally:
         dist.destroy_process_group()
+
+
+def test_sigkernel_paired_distance_mmd(gpu):
+    """compute_kernel / compute_distance / compute_mmd of the sigkernel surface vs oracle Gram matrices,
+    and the gradient of the MMD w.r.t. its first argument vs the oracle's weighted backward."""
+    from sigsvgd_amd.sigkernel import RBFKernel, SigKernel
+
+    rng = np.random.default_rng(17)
+    X = np.cumsum(0.2 * rng.standard_normal((6, 12, 3)), 1)
+    Y = np.cumsum(0.2 * rng.standard_normal((6, 12, 3)), 1)
+    sigma, n = 0.8, 1
+    h = sigma  # sigkernel's RBFKernel divides by sigma
+    Kxx, Kyy, Kxy = (O.gram(a, b, O.RBF, h, n) for a, b in ((X, X), (Y, Y), (X, Y)))
+    sk = SigKernel(RBFKernel(sigma), n)
+    Xg = torch.as_tensor(X, device=gpu, dtype=torch.float64)
+    Yg = torch.as_tensor(Y, device=gpu, dtype=torch.float64)
+    assert rel(sk.compute_kernel(Xg, Yg), np.diag(Kxy)) < 1e-6  # increments are kept in fp32 (DESIGN.md §3)
+    want_d = np.diag(Kxx).mean() + np.diag(Kyy).mean() - 2 * np.diag(Kxy).mean()
+    assert abs(float(sk.compute_distance(Xg, Yg)) - want_d) < 1e-5 * abs(want_d) + 1e-7
+    want_m = Kxx.mean() + Kyy.mean() - 2 * Kxy.mean()
+    xg = Xg.clone().requires_grad_(True)
+    mmd = sk.compute_mmd(xg, Yg)
+    assert abs(float(mmd) - want_m) < 1e-5 * abs(want_m) + 1e-7
+    (g,) = torch.autograd.grad(mmd, xg)
+    w = np.full((6, 6), 1.0 / 36)
+    _, g_xx = O.gram_backward(X, X, w, O.RBF, h, n, False, True)  # sym: both slots of Gram(X, X)
+    _, g_xy = O.gram_backward(X, Y, w, O.RBF, h, n)
+    assert rel(g, g_xx - 2 * g_xy) < 1e-5
