@@ -1,0 +1,30 @@
+"""Workload for rocprofv3 --kernel-trace --stats of the kernels bench.py does not touch: the streaming
+kernel at the C5 path shape (N=256 of 4096, T=128, d=14, symmetric), the coverage kernel at C1, the vector
+kernels and the truncated signature.  usage: rocprofv3 --kernel-trace --stats ... -- python3 scripts/profile_other_rows.py"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from oracle import sigkernel_oracle as O
+from sigsvgd_amd import _lib, ops
+
+dev = torch.device("cuda:0")
+X5, s5 = O.synthetic_inputs(256, 128, 14)
+X5, s5 = X5.to(dev), s5.to(dev)
+X1, s1 = O.synthetic_inputs(16, 20, 2)
+X1, s1 = X1.to(dev), s1.to(dev)
+g = torch.Generator().manual_seed(0)
+V = torch.randn(1024, 448, generator=g).to(dev)
+P = torch.cumsum(0.3 * torch.randn(1024, 64, 2, generator=g), 1).to(dev)
+for _ in range(10):
+    K, gk = ops.gram_fwd_bwd(X5, X5, 1.0, 0, y_is_x=True, check_regime=False)
+    ops.svgd_phi(K, s5, gk, X=X5, lr=1e-3)
+    K, gk = ops.gram_fwd_bwd(X1, X1, 1.0, 2, y_is_x=True)
+    ops.svgd_phi(K, s1, gk, X=X1, lr=1e-3)
+    sq = ops.vec_sqdist(V, V)
+    ops.vec_kernel(sq, V, V, _lib.VEC_GAUSSIAN, 1 / 448.0, -1 / 448.0)
+    S = ops.signature(P, 3, basepoint=True)
+torch.cuda.synchronize()
+print("ok", float(K.sum()), tuple(S.shape))

@@ -85,6 +85,10 @@ __global__ __launch_bounds__(256) void vec_sqdist_kernel(const T *__restrict__ X
         }
 }
 
+constexpr int SIG_MAX_DEPTH = 16;
+__device__ const double RECIP[SIG_MAX_DEPTH + 1] = {0.0, 1.0, 1.0 / 2, 1.0 / 3, 1.0 / 4, 1.0 / 5, 1.0 / 6, 1.0 / 7, 1.0 / 8,
+                                                    1.0 / 9, 1.0 / 10, 1.0 / 11, 1.0 / 12, 1.0 / 13, 1.0 / 14, 1.0 / 15, 1.0 / 16};
+
 constexpr int GR = 16; // rows per workgroup of vec_kgrad_kernel
 constexpr int GJ = 64; // partners staged per step
 constexpr int GC = 64; // channels per workgroup (4 per thread)
@@ -169,39 +173,91 @@ __global__ __launch_bounds__(256) void vec_kgrad_kernel(const T *__restrict__ sq
 // Truncated signature by Chen's identity, one workgroup per path.  Level k of the signature after
 // appending the increment D is  S_k + sum_{m=1..k} S_{k-m} (x) D^{(x)m} / m!,  evaluated per element
 // (a_1 .. a_k) in Horner form:  h_0 = 1,  h_r = S_r[a_1..a_r] + h_{r-1} * D[a_r] / (k - r + 1).
-// Accumulated in fp64 in LDS (ping-pong buffers, one barrier per point).
+// Accumulated in fp64 in LDS (ping-pong buffers, one barrier per point).  The prefix positions and letters
+// of every element do not depend on the point, so they are tabulated once ((position << 8) | letter, one
+// int per element and Horner step): the integer divisions that produce them cost more than the rest.
 template <typename T>
 __global__ __launch_bounds__(256) void signature_kernel(const T *__restrict__ X, int L, int C, int depth,
-                                                        int basepoint, int sigdim, T *__restrict__ out)
+                                                        int basepoint, int sigdim, int staged, T *__restrict__ out)
 {
-    extern __shared__ double sig_lds[]; // 2 * sigdim + C
-    double *buf0 = sig_lds, *buf1 = sig_lds + sigdim, *inc = sig_lds + 2 * sigdim;
+    extern __shared__ double sig_lds[]; // 2 * sigdim doubles, increments ([L][C] if staged, else [C]), table
+    double *buf0 = sig_lds, *buf1 = sig_lds + sigdim, *incs = sig_lds + 2 * sigdim;
+    int *tab = reinterpret_cast<int *>(incs + (staged ? (size_t)L * C : (size_t)C)); // [sigdim][depth]
     const int tid = threadIdx.x, nt = blockDim.x;
     const T *x = X + (size_t)blockIdx.x * L * C;
     for (int e = tid; e < sigdim; e += nt) buf0[e] = 0.0;
-    double *cur = buf0, *nxt = buf1;
-    for (int t = basepoint ? 0 : 1; t < L; ++t) {
-        __syncthreads();
-        if (tid < C) inc[tid] = (double)x[(size_t)t * C + tid] - (t > 0 ? (double)x[(size_t)(t - 1) * C + tid] : 0.0);
-        __syncthreads();
+    if (staged) // the whole path in one coalesced pass instead of a global load (and its latency) per point
+        for (int e = tid; e < L * C; e += nt) incs[e] = (double)x[e] - (e >= C ? (double)x[e - C] : 0.0);
+    {
         int off = 0, len = C; // level k occupies [off, off + C^k)
         for (int k = 1; k <= depth; ++k) {
             for (int e = tid; e < len; e += nt) {
-                // prefixes of the multi-index: level r index = e / C^(k-r)
-                double h = 1.0;
-                int div = len / C, loff = 0, llen = C; // C^(k-1); offset/length of level r
+                int div = len / C, loff = 0, llen = C; // C^(k-1); offset / length of level r
                 for (int r = 1; r <= k; ++r) {
                     const int pr = e / div; // a_1..a_r as a level-r flat index
-                    const int ar = pr % C;
-                    h = cur[loff + pr] + h * inc[ar] / (double)(k - r + 1);
+                    tab[(off + e) * depth + (r - 1)] = ((loff + pr) << 8) | (pr % C);
                     loff += llen;
                     llen *= C;
                     div = div > 1 ? div / C : 1;
                 }
-                nxt[off + e] = h;
             }
             off += len;
             len *= C;
+        }
+    }
+    __syncthreads();
+    // this thread's first element (all of them when sigdim <= blockDim): level and Horner table in registers
+    const bool small = depth <= 4 && sigdim <= nt;
+    int myk = 0, pk[4] = {0, 0, 0, 0};
+    double rc[4] = {0.0, 0.0, 0.0, 0.0};
+    if (small && tid < sigdim) {
+        int off = 0, len = C;
+        for (int k = 1; k <= depth; ++k) {
+            if (tid >= off && tid < off + len) myk = k;
+            off += len;
+            len *= C;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (r < myk) {
+                pk[r] = tab[tid * depth + r];
+                rc[r] = RECIP[myk - r];
+            }
+    }
+    double *cur = buf0, *nxt = buf1;
+    for (int t = basepoint ? 0 : 1; t < L; ++t) {
+        __syncthreads();
+        const double *inc = incs;
+        if (staged) {
+            inc = incs + (size_t)t * C;
+        } else {
+            if (tid < C)
+                incs[tid] = (double)x[(size_t)t * C + tid] - (t > 0 ? (double)x[(size_t)(t - 1) * C + tid] : 0.0);
+            __syncthreads();
+        }
+        if (small) { // one element per thread, every level in the same pass
+            if (tid < sigdim) {
+                double h = 1.0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (r < myk) h = cur[pk[r] >> 8] + h * inc[pk[r] & 255] * rc[r];
+                nxt[tid] = h;
+            }
+        } else {
+            int off = 0, len = C;
+            for (int k = 1; k <= depth; ++k) {
+                for (int e = tid; e < len; e += nt) {
+                    const int *tb = tab + (off + e) * depth;
+                    double h = 1.0;
+                    for (int r = 1; r <= k; ++r) {
+                        const int pkk = tb[r - 1];
+                        h = cur[pkk >> 8] + h * inc[pkk & 255] * RECIP[k - r + 1];
+                    }
+                    nxt[off + e] = h;
+                }
+                off += len;
+                len *= C;
+            }
         }
         double *tmp = cur;
         cur = nxt;
@@ -273,12 +329,24 @@ int signature_launch(const void *X, int N, int L, int C, int depth, int basepoin
                      hipStream_t stream)
 {
     const long long sigdim = signature_channels(C, depth);
-    const size_t lds = (size_t)(2 * sigdim + C) * sizeof(double);
-    if (sigdim < 0 || lds > 150 * 1024) {
-        set_error("signature: %lld channels (C=%d, depth=%d) need %zu B of LDS, more than the 150 KB this kernel uses",
-                  sigdim, C, depth, lds);
+    if (depth > SIG_MAX_DEPTH || C > 255) {
+        set_error("signature: depth %d > %d or C=%d > 255", depth, SIG_MAX_DEPTH, C);
         return SIGSVGD_E_UNSUPPORTED;
     }
+    const size_t tab_bytes = sigdim > 0 ? (size_t)sigdim * depth * sizeof(int) : 0;
+    const size_t lds_min = (size_t)(2 * sigdim + C) * sizeof(double) + tab_bytes;
+    if (sigdim < 0 || lds_min > 150 * 1024) {
+        set_error("signature: %lld channels (C=%d, depth=%d) need %zu B of LDS, more than the 150 KB this kernel uses",
+                  sigdim, C, depth, lds_min);
+        return SIGSVGD_E_UNSUPPORTED;
+    }
+    // stage the whole path in LDS when it fits next to the two signature buffers
+    const size_t lds_staged = (size_t)(2 * sigdim + (long long)L * C) * sizeof(double) + tab_bytes;
+    const int staged = lds_staged <= 150 * 1024;
+    const size_t lds = staged ? lds_staged : lds_min;
+    // one wavefront per path while the signature has no more elements than lanes (PathSigKernel's own
+    // use: C = 2, depth 3 -> 14): the per-point barriers of a single-wave workgroup cost nothing
+    const int threads = sigdim <= 64 ? 64 : (sigdim <= 128 ? 128 : 256);
     hipError_t e;
     if (dtype == SIGSVGD_F64) {
         if (lds > 64 * 1024) {
@@ -286,16 +354,16 @@ int signature_launch(const void *X, int N, int L, int C, int depth, int basepoin
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(signature_kernel)");
         }
-        hipLaunchKernelGGL((signature_kernel<double>), dim3(N), dim3(256), lds, stream, static_cast<const double *>(X),
-                           L, C, depth, basepoint, (int)sigdim, static_cast<double *>(out));
+        hipLaunchKernelGGL((signature_kernel<double>), dim3(N), dim3(threads), lds, stream, static_cast<const double *>(X),
+                           L, C, depth, basepoint, (int)sigdim, staged, static_cast<double *>(out));
     } else {
         if (lds > 64 * 1024) {
             e = hipFuncSetAttribute(reinterpret_cast<const void *>(&signature_kernel<float>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(signature_kernel)");
         }
-        hipLaunchKernelGGL((signature_kernel<float>), dim3(N), dim3(256), lds, stream, static_cast<const float *>(X), L,
-                           C, depth, basepoint, (int)sigdim, static_cast<float *>(out));
+        hipLaunchKernelGGL((signature_kernel<float>), dim3(N), dim3(threads), lds, stream, static_cast<const float *>(X), L,
+                           C, depth, basepoint, (int)sigdim, staged, static_cast<float *>(out));
     }
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "launch signature_kernel");
