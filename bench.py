@@ -216,6 +216,29 @@ def main():
         torch.cuda.synchronize()
         eager = n_e / (time.perf_counter() - t0)
 
+    # ---- the other BASELINE.json configurations that fit one GPU, a few iterations each --------
+    others = None
+    if rank == 0 and not use_dist:
+        others = {}
+        for name, (n_, t_, d_, dy) in {"C1": (16, 20, 2, 2), "C2": (128, 32, 7, 0), "C3": (512, 64, 3, 0),
+                                       "C5 path shape, N=256 of 4096": (256, 128, 14, 0)}.items():
+            Xo, so = O.synthetic_inputs(n_, t_, d_)
+            Xo, so = Xo.to(dev), so.to(dev)
+
+            def it(Xc):
+                K, gk = ops.gram_fwd_bwd(Xc, Xc, 1.0 / H, dy, y_is_x=True, check_regime=False)
+                return ops.svgd_phi(K, so, gk, X=Xc, lr=LR)[1]
+
+            for _ in range(3):
+                Xo = it(Xo)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                Xo = it(Xo)
+            torch.cuda.synchronize()
+            others[name] = {"N": n_, "T": t_, "d": d_, "dyadic_order": dy,
+                            "ms_per_iter": (time.perf_counter() - t0) / 10 * 1e3}
+
     if rank == 0:
         out = {
             "metric": "SVGD iters/sec, sig-kernel N=1024 T=64 d=7",
@@ -239,6 +262,7 @@ def main():
                 "host_copies": "none in the timed region (reference-style eager .cpu() of K is opt-in)",
             },
             "eager_cpu_copies_iters_per_sec": eager,
+            "other_configs": others,
             "roofline": roofline,
         }
         if not args.no_cpu_baseline and world == 1:
