@@ -164,6 +164,10 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
     int i = 0, j0 = 0, j1 = 0;
     bool row_ok = false;
     const int lane_q = (lane < P) ? lane : 0x40000000; // rows without PDE cells never pass the range test below
+    // bit k: slot k of this lane holds a grid cell, i.e. lane < P and column (k - lane) & 63 < P
+    const unsigned long long vmask =
+        (lane < P) ? ((((1ull << P) - 1ull) << lane) | (lane ? (((1ull << P) - 1ull) >> (64 - lane)) : 0ull)) : 0ull;
+    const int vm_lo = (int)(unsigned)vmask, vm_hi = (int)(unsigned)(vmask >> 32);
     float *Gs = Gs_all + (GRAD ? wave * GS_WAVE : 0);
     const double inv_h = a.inv_h;
     const float m2h = (float)(-2.0 * inv_h);
@@ -391,7 +395,7 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
 
                 int yfrow = 64 - lane;                          // row (sigma + 2 - lane) & 63 == yfrow + k2
                 int gsoff = (GRAD ? wave * GS_WAVE : 0) + lane; // this wave's [slot][lane] image
-                auto grad_part = [&](int sigma, float Snew) {
+                auto grad_part = [&](int sigma, float Snew, bool accumulate) {
                     const int k2 = (sigma + 2) & 63;
                     const float Na = dpp_shr1_zero(Snew); // S[l-1, q+1]
                     float dN = Na - Nb;
@@ -400,6 +404,7 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
                     Sc = Sb;
                     Sb = Snew;
                     Nb = Na;
+                    if (!accumulate) return; // warm-up iteration: only the two-deep history is filled
                     const int gi = gsoff + k2 * GS_STRIDE;
                     const float rg = R * Gs_all[gi];
                     const f32x2 *yr = reinterpret_cast<const f32x2 *>(yf + (yfrow + k2) * YFS);
@@ -443,18 +448,30 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
                         double u = t - ddiag;
                         u = __builtin_fma(t, (double)aa, u);
                         const double nw = __builtin_fma(ddiag, (double)b, u);
-                        float Snew = 0.f;
                         if (act) {
-                            Snew = Ksl[k] * (float)ddiag; // K[l,q] * U[l+1,q+1]
+                            Ksl[k] *= (float)ddiag; // S[l,q] = K[l,q] * U[l+1,q+1] replaces K[l,q] in its slot
                             cur = nw;
                             ddiag = down;
                         }
-                        grad_part(sigma, Snew);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
-                grad_part(-1, 0.f);
-                grad_part(-2, 0.f);
+
+                // ---- phase 4: 4-corner scatter R and both contractions, one column per lane and iteration ----
+                // The reverse sweep has only half of its lanes inside the grid at any step, so nothing but the
+                // recurrence is left in it.  Here every lane is busy on every iteration: lane l takes the slots in
+                // descending order, i.e. column q = (63 - it - l) & 63 with wrap-around; cells outside the grid
+                // (column >= P, row >= P) read as S = 0, which is also exactly what the scatter needs at the
+                // wrap (S[.][-1] = S[.][63] = 0).  Two warm-up iterations fill the history, the next 64 visit
+                // every column n = q + 2 once; the travelling sums rotate as before and end in lane (64 - n) & 63.
+#pragma unroll
+                for (int it = 0; it < 66; ++it) {
+                    const int k = (63 - it) & 63;
+                    const int keep = __builtin_amdgcn_sbfe(k < 32 ? vm_lo : vm_hi, k & 31, 1); // -1 if the cell exists
+                    const float Sv = __int_as_float(__float_as_int(Ksl[k]) & keep);
+                    grad_part(k, Sv, it >= 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
 
                 // row-side gradient of this pair: -(2/h) * sum_n R G (x~_m - y~_n)
                 float w_ij = 1.f, w_ji = 1.f;
