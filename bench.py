@@ -93,6 +93,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=256)
+    ap.add_argument("--headline-only", action="store_true",
+                    help="skip the other configurations and the eager-copy figure (clean per-kernel profiles)")
     ap.add_argument("--force-dist", action="store_true", help="use the sharded path even with one rank (rehearsal)")
     args = ap.parse_args()
 
@@ -208,7 +210,7 @@ def main():
     # ---- second figure: the reference's eager per-iteration `.cpu()` of K, grad_k and v
     # (svgd.py:85-90), PCIe-inclusive.  Reported beside `value`, never as `value`.
     eager = None
-    if rank == 0 and not use_dist:
+    if rank == 0 and not use_dist and not args.headline_only:
         Xe2 = X0.to(dev)
         n_e = 20
         torch.cuda.synchronize()
@@ -222,7 +224,7 @@ def main():
 
     # ---- the other BASELINE.json configurations that fit one GPU, a few iterations each --------
     others = None
-    if rank == 0 and not use_dist:
+    if rank == 0 and not use_dist and not args.headline_only:
         others = {}
         for name, (n_, t_, d_, dy) in {"C1": (16, 20, 2, 2), "C2": (128, 32, 7, 0), "C3": (512, 64, 3, 0),
                                        "C5 path shape, N=256 of 4096": (256, 128, 14, 0)}.items():
