@@ -335,7 +335,11 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
 
             // ---- phase 2: forward sweep, anti-diagonal sigma = 0 .. 2P-2 ---------------------------
             {
-                double cur = 1.0, diag = 1.0, up = 1.0; // `up` persists: lane 0 keeps the boundary K[0][.] = 1
+                // `up` persists (lane 0 keeps the boundary K[0][.] = 1) in TWO registers used on alternate steps:
+                // the diagonal neighbour K[l][q] of a step is the upper neighbour of the step before, whether or
+                // not this lane was active then (a lane's value is 1.0 until its row starts and frozen after it
+                // ends), so it needs no copy.
+                double cur = 1.0, upA = 1.0, upB = 1.0;
                 const int smax = 2 * P - 2;
                 for (int rnd = 0; rnd < 2; ++rnd) {
                     if (rnd * 64 > smax) break;
@@ -345,6 +349,8 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
                     for (int k = 0; k < 64; ++k) {
                         const int sigma = rnd * 64 + k;
                         const bool act = (unsigned)(sigma - lane_q) < (unsigned)P;
+                        double &up = (k & 1) ? upB : upA;
+                        const double diag = (k & 1) ? upA : upB;
                         dpp_shr1_keep(up, cur);
                         const float g = Dsl[k];
                         const float b = g * (g * c12); // c12, chalf: per-round opaque constants; (g*c12) first so nothing here is round-invariant
@@ -356,7 +362,6 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
                         if (act) {
                             if (GRAD) Ksl[k] = (float)diag; // K[l, q]
                             cur = nw;
-                            diag = up;
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
@@ -369,7 +374,7 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
 
             if (GRAD) {
                 // ---- phase 3: reverse sweep + lagged R -> row-side contraction ----------------------
-                double cur = 1.0, ddiag = 1.0, down = 1.0; // `down` persists: lane 63 keeps U[P][.] = 1
+                double cur = 1.0, downA = 1.0, downB = 1.0; // `down` persists (lane 63 keeps U[P][.] = 1), alternating as above
                 float Sb = 0.f, Sc = 0.f, Nb = 0.f, s0 = 0.f;
                 f32x2 acc[DPAD / 2]; // packed pairs: the contraction runs on v_pk_fma_f32
 #pragma unroll
@@ -440,6 +445,8 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
                         const int k = 63 - kk;
                         const int sigma = rnd * 64 + k;
                         const bool act = (unsigned)(sigma - lane_q) < (unsigned)P;
+                        double &down = (kk & 1) ? downB : downA;
+                        const double ddiag = (kk & 1) ? downA : downB; // U[l+1][q+1]: the lower neighbour one step ago
                         dpp_shl1_keep(down, cur);
                         const float g = Dsl[k];
                         const float b = g * (g * c12);
@@ -451,7 +458,6 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
                         if (act) {
                             Ksl[k] *= (float)ddiag; // S[l,q] = K[l,q] * U[l+1,q+1] replaces K[l,q] in its slot
                             cur = nw;
-                            ddiag = down;
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
