@@ -195,10 +195,10 @@ def main():
             "median_launch_ms": ms[len(ms) // 2],
             "note": "fused pair solves are fp64-VALU/latency bound, not HBM bound (SURVEY.md §8d); "
                     "secondary figure below",
-            # SQ counters of the same kernel (own rocprofv3 --pmc pass, profiles/r01_sq_counters_gram_fast.csv):
+            # SQ counters of the same kernel (own rocprofv3 --pmc pass, profiles/r01_sq_counters_gram_fast_final.csv):
             # what actually bounds it is vector-instruction issue
-            "valu_issue": {"vector_pipe_busy_frac": 0.84, "vector_insts_per_launch": 4.72e9,
-                           "source": "profiles/r01_sq_counters_gram_fast.csv"},
+            "valu_issue": {"vector_pipe_busy_frac": 0.82, "vector_insts_per_launch": 3.81e9,
+                           "source": "profiles/r01_sq_counters_gram_fast_final.csv"},
             "valu_fp64": {
                 "achieved_tflops": fl / (k_ms * 1e-3) / 1e12,
                 "peak_tflops": FP64_VALU_PEAK_TF,
