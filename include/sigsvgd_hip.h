@@ -14,6 +14,7 @@
  *   sigsvgd_svgd_phi       SVGD._velocity dense part: v = -((K @ score - grad_k)/N) [* mask]
  *                          src/inference/svgd.py:82-83, src/inference/trajectory_svgd.py:84
  *                          optionally fused with the optimizer=None update X - lr*v (svgd.py:115)
+ *   sigsvgd_svgd_step      the same with the adaptive_gradient=True scaling fused (svgd.py:110-113)
  *   sigsvgd_vec_sqdist     src/utils/math.py:69-86 pw_dist_sq, :116-144 scaled_pw_dist_sq
  *   sigsvgd_vec_kernel     src/kernels/_kernels.py:64-299 GaussianKernel / ScaledGaussianKernel /
  *                          IMQKernel / ScaledIMQKernel: K and d_K.sum(1) without the [A,B,D] tensor
@@ -118,6 +119,15 @@ int sigsvgd_gram_sym_partial(const void *X, int N, int T, int d, int dtype, doub
 int sigsvgd_svgd_phi(const float *K, const float *score, const float *grad_k, const float *mask,
                      int N, int D, float *v_out, const float *X_in, float *X_out, float lr,
                      void *stream);
+
+/* The same launch with the reference's "simple Adagrad" (SVGD(adaptive_gradient=True), svgd.py:110-113)
+ * fused into the epilogue when adagrad_state[N,D] is non-NULL:
+ *   state += v^2;  v_out = v / sqrt(state + 1e-12);  X_out = X_in - lr * v_out
+ * (v already multiplied by the mask).  adagrad_state is read and written in place; zero it before the
+ * first iteration.  With adagrad_state == NULL this is sigsvgd_svgd_phi. */
+int sigsvgd_svgd_step(const float *K, const float *score, const float *grad_k, const float *mask,
+                      int N, int D, float *v_out, const float *X_in, float *X_out, float lr,
+                      float *adagrad_state, void *stream);
 
 /* ---- vector kernels on particles X[A,D], Y[B,D] ---------------------------------
  * sq[i,j] = max(0, sum_c (XM[i,c] - YM[j,c]) * (X[i,c] - Y[j,c])).  XM = X @ M, YM = Y @ M for a metric

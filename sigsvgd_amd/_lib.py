@@ -32,6 +32,7 @@ EXPORTS = [
     "sigsvgd_gram_fwd_bwd",
     "sigsvgd_gram_sym_partial",
     "sigsvgd_svgd_phi",
+    "sigsvgd_svgd_step",
     "sigsvgd_vec_sqdist",
     "sigsvgd_vec_kernel",
     "sigsvgd_signature",
@@ -98,6 +99,8 @@ def load():
     L.sigsvgd_gram_sym_partial.argtypes = [vp, ci, ci, ci, ci, cd, ci, cu, ci, ci, vp, vp, vp, vp, ctypes.c_size_t, vp]
     L.sigsvgd_svgd_phi.restype = ci
     L.sigsvgd_svgd_phi.argtypes = [vp, vp, vp, vp, ci, ci, vp, vp, vp, cf, vp]
+    L.sigsvgd_svgd_step.restype = ci
+    L.sigsvgd_svgd_step.argtypes = [vp, vp, vp, vp, ci, ci, vp, vp, vp, cf, vp, vp]
     L.sigsvgd_vec_sqdist.restype = ci
     L.sigsvgd_vec_sqdist.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp, vp]
     L.sigsvgd_vec_kernel.restype = ci

@@ -23,7 +23,7 @@ int hip_fail(hipError_t e, const char *what)
 }
 
 int phi_launch(const float *K, const float *score, const float *grad_k, const float *mask, int N, int D,
-               float *v_out, const float *X_in, float *X_out, float lr, hipStream_t stream);
+               float *v_out, const float *X_in, float *X_out, float lr, float *adagrad, hipStream_t stream);
 
 int vec_sqdist_launch(const void *X, const void *Y, const void *XM, const void *YM, int A, int B, int D, int dtype,
                       void *sq, hipStream_t stream);
@@ -150,7 +150,14 @@ int sigsvgd_gram_sym_partial(const void *X, int N, int T, int d, int dtype, doub
 int sigsvgd_svgd_phi(const float *K, const float *score, const float *grad_k, const float *mask, int N, int D,
                      float *v_out, const float *X_in, float *X_out, float lr, void *stream)
 {
-    return phi_launch(K, score, grad_k, mask, N, D, v_out, X_in, X_out, lr, static_cast<hipStream_t>(stream));
+    return phi_launch(K, score, grad_k, mask, N, D, v_out, X_in, X_out, lr, nullptr, static_cast<hipStream_t>(stream));
+}
+
+int sigsvgd_svgd_step(const float *K, const float *score, const float *grad_k, const float *mask, int N, int D,
+                      float *v_out, const float *X_in, float *X_out, float lr, float *adagrad_state, void *stream)
+{
+    return phi_launch(K, score, grad_k, mask, N, D, v_out, X_in, X_out, lr, adagrad_state,
+                      static_cast<hipStream_t>(stream));
 }
 
 int sigsvgd_vec_sqdist(const void *X, const void *Y, const void *XM, const void *YM, int A, int B, int D, int dtype,

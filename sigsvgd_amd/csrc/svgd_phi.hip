@@ -1,5 +1,6 @@
-// SVGD velocity: v = -((K @ score - grad_k) / N) [* mask], optionally fused with the
-// optimizer=None particle update X_out = X_in - lr * v   (reference src/inference/svgd.py:82-83,115;
+// SVGD velocity: v = -((K @ score - grad_k) / N) [* mask], optionally fused with the simple Adagrad
+// scaling of the reference (svgd.py:110-113) and the optimizer=None particle update X_out = X_in - lr * v
+// (reference src/inference/svgd.py:82-83,115;
 // mask: src/inference/trajectory_svgd.py:84).
 //
 // The N x N x D product is the only GEMM-shaped piece of the hot path and runs on the fp32 MFMA
@@ -24,7 +25,8 @@ constexpr int SS = PN + 16; // = 16 mod 32: the two k rows a 32-lane read touche
 __global__ __launch_bounds__(256) void svgd_phi_kernel(const float *__restrict__ K, const float *__restrict__ S,
                                                        const float *__restrict__ gk, const float *__restrict__ mask,
                                                        int N, int D, float *__restrict__ v_out,
-                                                       const float *__restrict__ X_in, float *__restrict__ X_out, float lr)
+                                                       const float *__restrict__ X_in, float *__restrict__ X_out, float lr,
+                                                       float *__restrict__ adagrad)
 {
     __shared__ __align__(16) float kt[PM * KS];     // K tile      [row][k]
     __shared__ __align__(16) float st[PK * SS];     // score tile  [k][col]
@@ -135,6 +137,11 @@ __global__ __launch_bounds__(256) void svgd_phi_kernel(const float *__restrict__
                         const size_t idx = (size_t)gr * D + gc;
                         float v = -((s - gk[idx]) * invN);
                         if (mask) v *= mask[idx];
+                        if (adagrad) { // reference svgd.py:110-113: running sum of squared gradients, g / sqrt(sum + 1e-12)
+                            const float acc2 = adagrad[idx] + v * v;
+                            adagrad[idx] = acc2;
+                            v = v / sqrtf(acc2 + 1e-12f);
+                        }
                         v_out[idx] = v;
                         if (X_out) X_out[idx] = X_in[idx] - lr * v;
                     }
@@ -143,7 +150,7 @@ __global__ __launch_bounds__(256) void svgd_phi_kernel(const float *__restrict__
 }
 
 int phi_launch(const float *K, const float *score, const float *grad_k, const float *mask, int N, int D,
-               float *v_out, const float *X_in, float *X_out, float lr, hipStream_t stream)
+               float *v_out, const float *X_in, float *X_out, float lr, float *adagrad, hipStream_t stream)
 {
     if (N < 1 || D < 1 || !K || !score || !grad_k || !v_out) {
         set_error("svgd_phi: bad arguments N=%d D=%d", N, D);
@@ -154,7 +161,8 @@ int phi_launch(const float *K, const float *score, const float *grad_k, const fl
         return SIGSVGD_E_BADARG;
     }
     dim3 grid((D + PN - 1) / PN, (N + PM - 1) / PM);
-    hipLaunchKernelGGL(svgd_phi_kernel, grid, dim3(256), 0, stream, K, score, grad_k, mask, N, D, v_out, X_in, X_out, lr);
+    hipLaunchKernelGGL(svgd_phi_kernel, grid, dim3(256), 0, stream, K, score, grad_k, mask, N, D, v_out, X_in, X_out, lr,
+                       adagrad);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "launch svgd_phi_kernel");
     return SIGSVGD_OK;

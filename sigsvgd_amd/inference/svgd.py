@@ -108,7 +108,16 @@ class SVGD:
             X.detach_()
 
         # v = -((k_xx @ score - grad_k) / N), one HIP launch (fp32 MFMA GEMM + fused epilogue)
-        velocity = ops.svgd_phi(k_xx, score, grad_k).reshape(X.shape).to(X.dtype)
+        fuse = getattr(self, "_fuse_manual_update", None)
+        if fuse is not None:
+            # step() with optimizer=None asked for the whole update in the same launch:
+            # [Adagrad scaling,] X - lr * v   (reference svgd.py:108-115)
+            velocity, X_new = ops.svgd_phi(k_xx, score, grad_k, X=X.detach(), lr=fuse["lr"],
+                                           adagrad_state=fuse["adagrad_state"])
+            fuse["X_new"] = X_new.reshape(X.shape).to(X.dtype)
+            velocity = velocity.reshape(X.shape).to(X.dtype)
+        else:
+            velocity = ops.svgd_phi(k_xx, score, grad_k).reshape(X.shape).to(X.dtype)
 
         iter_dict = {"k_xx": k_xx, "grad_k": grad_k, "loss": loss}
         iter_dict.update(kwargs)
@@ -124,7 +133,21 @@ class SVGD:
 
         if isinstance(optimizer, torch.optim.Optimizer):
             iter_dict = optimizer.step(closure)
-        else:
+        elif type(self)._velocity is SVGD._velocity and X.dtype == torch.float32 and X.device.type == "cuda":
+            # velocity, the reference's simple Adagrad (adaptive_gradient=True) and X - lr * grad in ONE launch
+            state = None
+            if self.opt_adagrad:
+                if not torch.is_tensor(self.opt_inertia):
+                    self.opt_inertia = torch.zeros(X.shape, dtype=torch.float32, device=X.device)
+                state = self.opt_inertia
+            self._fuse_manual_update = {"lr": float(self.opt_args["lr"]), "adagrad_state": state}
+            try:
+                grad, iter_dict = self._velocity(X, grad_log_p, **kwargs)
+                X = self._fuse_manual_update["X_new"]
+            finally:
+                self._fuse_manual_update = None
+            iter_dict["grad"] = self._grad_entry(grad)
+        else:  # subclasses that post-process the velocity (TrajectorySVGD's mask), other dtypes
             grad, iter_dict = self._velocity(X, grad_log_p, **kwargs)
             if self.opt_adagrad:  # simple Adagrad: running sum of squared gradients
                 self.opt_inertia = self.opt_inertia + grad**2

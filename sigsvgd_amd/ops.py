@@ -162,10 +162,12 @@ def gram_fwd_bwd(X, Y, inv_h: float, dyadic_order: int = 0, static_kind: int = _
     return K, gX
 
 
-def svgd_phi(K, score, grad_k, mask=None, X=None, lr: Optional[float] = None):
+def svgd_phi(K, score, grad_k, mask=None, X=None, lr: Optional[float] = None, adagrad_state=None):
     """v = -((K @ score - grad_k)/N) [* mask]; with X and lr also returns X - lr*v.
 
     All fp32, shapes K [N,N], score/grad_k/mask/X [N, ...] (flattened to [N,D]).
+    adagrad_state: contiguous fp32 tensor shaped like score, updated IN PLACE (state += v^2) and applied
+    (v / sqrt(state + 1e-12)) before the update -- the reference's adaptive_gradient=True (svgd.py:110-113).
     Returns v (shaped like score) or (v, X_new)."""
     L = _lib.load()
     dev = _require_gpu(K, score, grad_k, mask, X)
@@ -190,11 +192,18 @@ def svgd_phi(K, score, grad_k, mask=None, X=None, lr: Optional[float] = None):
             raise ValueError("lr is required with X")
         Xc = f(X)
         Xn = torch.empty_like(Xc)
+    ag = None
+    if adagrad_state is not None:
+        _require_gpu(adagrad_state)
+        if adagrad_state.dtype != torch.float32 or not adagrad_state.is_contiguous() or adagrad_state.numel() != N * D:
+            raise ValueError("adagrad_state must be a contiguous float32 tensor with the shape of score")
+        ag = adagrad_state
     with torch.cuda.device(dev):
-        rc = L.sigsvgd_svgd_phi(Kc.data_ptr(), s.data_ptr(), gk.data_ptr(), m.data_ptr() if m is not None else None,
-                                N, D, v.data_ptr(), Xc.data_ptr() if Xc is not None else None,
-                                Xn.data_ptr() if Xn is not None else None, float(lr or 0.0), _stream_ptr(dev))
-    _lib.check(rc, "svgd_phi")
+        rc = L.sigsvgd_svgd_step(Kc.data_ptr(), s.data_ptr(), gk.data_ptr(), m.data_ptr() if m is not None else None,
+                                 N, D, v.data_ptr(), Xc.data_ptr() if Xc is not None else None,
+                                 Xn.data_ptr() if Xn is not None else None, float(lr or 0.0),
+                                 ag.data_ptr() if ag is not None else None, _stream_ptr(dev))
+    _lib.check(rc, "svgd_step")
     v = v.reshape(shape)
     if X is not None:
         return v, Xn.reshape(X.shape)

@@ -30,11 +30,14 @@ def gram_fwd_bwd(X, Y, inv_h, dyadic_order=0, static_kind=0, grad_out=None, naiv
     return torch.as_tensor(K, dtype=X.dtype), torch.as_tensor(g, dtype=X.dtype)
 
 
-def svgd_phi(K, score, grad_k, mask=None, X=None, lr=None):
+def svgd_phi(K, score, grad_k, mask=None, X=None, lr=None, adagrad_state=None):
     N = K.shape[0]
     v = -((K.float() @ score.float().reshape(N, -1) - grad_k.float().reshape(N, -1)) / N)
     if mask is not None:
         v = v * torch.broadcast_to(torch.as_tensor(mask, dtype=torch.float32), score.shape).reshape(N, -1)
+    if adagrad_state is not None:
+        adagrad_state += (v * v).reshape(adagrad_state.shape)
+        v = v / torch.sqrt(adagrad_state.reshape(N, -1) + 1e-12)
     v = v.reshape(score.shape)
     if X is not None:
         return v, X.float() - lr * v

@@ -266,3 +266,30 @@ def test_sigkernel_paired_distance_mmd(gpu):
     _, g_xx = O.gram_backward(X, X, w, O.RBF, h, n, False, True)  # sym: both slots of Gram(X, X)
     _, g_xy = O.gram_backward(X, Y, w, O.RBF, h, n)
     assert rel(g, g_xx - 2 * g_xy) < 1e-5
+
+
+def test_fused_adagrad_step_matches_torch(gpu):
+    """sigsvgd_svgd_step: velocity + the reference's simple Adagrad + X - lr*g in one launch, state in place"""
+    from sigsvgd_amd import ops
+
+    g = torch.Generator().manual_seed(5)
+    N, D = 70, 45
+    K = torch.rand(N, N, generator=g)
+    s, gk, X = (torch.randn(N, D, generator=g) for _ in range(3))
+    mask = (torch.rand(N, D, generator=g) > 0.3).float()
+    state = torch.zeros(N, D)
+    st_g = state.clone().to(gpu)
+    Xc = X.clone()
+    Xg = X.to(gpu)
+    for _ in range(3):
+        v = -((K @ s - gk) / N) * mask
+        state = state + v * v
+        gsc = v / torch.sqrt(state + 1e-12)
+        Xc = Xc - 0.05 * gsc
+        vg, Xg = ops.svgd_phi(K.to(gpu), s.to(gpu), gk.to(gpu), mask=mask.to(gpu), X=Xg, lr=0.05, adagrad_state=st_g)
+        # entries where K @ s and grad_k nearly cancel carry the fp32 product's rounding at full weight after the
+        # normalisation (|g| = 1 on the first step), hence 1e-4 here; X and the state are compared at 1e-5
+        assert rel(vg, gsc.double().numpy()) < 1e-4
+    assert rel(Xg, Xc.double().numpy()) < 1e-5 and rel(st_g, state.double().numpy()) < 1e-5
+    with pytest.raises(ValueError):
+        ops.svgd_phi(K.to(gpu), s.to(gpu), gk.to(gpu), adagrad_state=torch.zeros(N, D + 1, device=gpu))
