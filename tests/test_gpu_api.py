@@ -260,7 +260,7 @@ def test_sigkernel_paired_distance_mmd(gpu):
     want_m = Kxx.mean() + Kyy.mean() - 2 * Kxy.mean()
     xg = Xg.clone().requires_grad_(True)
     mmd = sk.compute_mmd(xg, Yg)
-    assert abs(float(mmd) - want_m) < 1e-5 * abs(want_m) + 1e-7
+    assert abs(float(mmd.detach()) - want_m) < 1e-5 * abs(want_m) + 1e-7
     (g,) = torch.autograd.grad(mmd, xg)
     w = np.full((6, 6), 1.0 / 36)
     _, g_xx = O.gram_backward(X, X, w, O.RBF, h, n, False, True)  # sym: both slots of Gram(X, X)
