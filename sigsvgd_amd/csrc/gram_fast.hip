@@ -270,7 +270,7 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
         const bool pair_ok = row_ok && (!SYM || j >= i);
         if (j + 1 < j1) stage_load(j + 1); // in flight during the pair
 
-        float Dsl[64];
+        f32x2 Dsl2[32]; // increments, two slots per register pair: the stencil coefficients of two steps share packed math
         float Ksl[64];
 
         if (pair_ok) {
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
                     if (t >= 2) {
                         // lane l+1 holds the same column difference one iteration later
                         const double nb = dpp_shl1_zero(rd);
-                        Dsl[(t - 2) & 63] = (float)(nb - rdprev);
+                        Dsl2[((t - 2) & 63) >> 1][(t - 2) & 1] = (float)(nb - rdprev);
                     }
                     rdprev = rd;
                     __builtin_amdgcn_sched_barrier(0); // one column per scheduling region: bounds live ranges
@@ -340,6 +340,7 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
                 // not this lane was active then (a lane's value is 1.0 until its row starts and frozen after it
                 // ends), so it needs no copy.
                 double cur = 1.0, upA = 1.0, upB = 1.0;
+                f32x2 b2 = {0.f, 0.f}, aa2 = {0.f, 0.f};
                 const int smax = 2 * P - 2;
                 for (int rnd = 0; rnd < 2; ++rnd) {
                     if (rnd * 64 > smax) break;
@@ -352,9 +353,14 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
                         double &up = (k & 1) ? upB : upA;
                         const double diag = (k & 1) ? upA : upB;
                         dpp_shr1_keep(up, cur);
-                        const float g = Dsl[k];
-                        const float b = g * (g * c12); // c12, chalf: per-round opaque constants; (g*c12) first so nothing here is round-invariant
-                        const float aa = __builtin_fmaf(g, chalf, b);
+                        // a = g/2 + g^2/12, b = g^2/12 for steps k and k+1 at once (v_pk_mul/v_pk_fma); c12, chalf are
+                        // per-round opaque constants and (g*c12) comes first so that nothing here is round-invariant
+                        if ((k & 1) == 0) {
+                            const f32x2 g2 = Dsl2[k >> 1];
+                            b2 = g2 * (g2 * f32x2{c12, c12});
+                            aa2 = __builtin_elementwise_fma(g2, f32x2{chalf, chalf}, b2);
+                        }
+                        const float b = b2[k & 1], aa = aa2[k & 1];
                         const double t = cur + up;
                         double u = t - diag;
                         u = __builtin_fma(t, (double)aa, u);
@@ -375,6 +381,7 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
             if (GRAD) {
                 // ---- phase 3: reverse sweep + lagged R -> row-side contraction ----------------------
                 double cur = 1.0, downA = 1.0, downB = 1.0; // `down` persists (lane 63 keeps U[P][.] = 1), alternating as above
+                f32x2 b2 = {0.f, 0.f}, aa2 = {0.f, 0.f};
                 float Sb = 0.f, Sc = 0.f, Nb = 0.f, s0 = 0.f;
                 f32x2 acc[DPAD / 2]; // packed pairs: the contraction runs on v_pk_fma_f32
 #pragma unroll
@@ -448,9 +455,12 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
                         double &down = (kk & 1) ? downB : downA;
                         const double ddiag = (kk & 1) ? downA : downB; // U[l+1][q+1]: the lower neighbour one step ago
                         dpp_shl1_keep(down, cur);
-                        const float g = Dsl[k];
-                        const float b = g * (g * c12);
-                        const float aa = __builtin_fmaf(g, chalf, b);
+                        if ((k & 1) == 1) { // descending: steps k and k-1 share one packed evaluation
+                            const f32x2 g2 = Dsl2[k >> 1];
+                            b2 = g2 * (g2 * f32x2{c12, c12});
+                            aa2 = __builtin_elementwise_fma(g2, f32x2{chalf, chalf}, b2);
+                        }
+                        const float b = b2[k & 1], aa = aa2[k & 1];
                         const double t = cur + down;
                         double u = t - ddiag;
                         u = __builtin_fma(t, (double)aa, u);
