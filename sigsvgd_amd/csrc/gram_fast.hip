@@ -407,8 +407,9 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
 
                 int yfrow = 64 - lane;                          // row (sigma + 2 - lane) & 63 == yfrow + k2
                 int gsoff = (GRAD ? wave * GS_WAVE : 0) + lane; // this wave's [slot][lane] image
-                auto grad_part = [&](int sigma, float Snew, bool accumulate) {
-                    const int k2 = (sigma + 2) & 63;
+                // one iteration of the phase-4 pass (below); `gcu`, `ycu`: G[l][n] and the y~_n row, fetched one
+                // iteration ahead so that the LDS latency is off the chain and one s_waitcnt serves the iteration
+                auto grad_part = [&](float Snew, bool accumulate, float gcu, const f32x2 *ycu) {
                     const float Na = dpp_shr1_zero(Snew); // S[l-1, q+1]
                     float dN = Na - Nb;
                     asm volatile("" : "+v"(dN)); // keeps hipcc from SLP-packing the two differences (costs 2 moves)
@@ -417,13 +418,11 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
                     Sb = Snew;
                     Nb = Na;
                     if (!accumulate) return; // warm-up iteration: only the two-deep history is filled
-                    const int gi = gsoff + k2 * GS_STRIDE;
-                    const float rg = R * Gs_all[gi];
-                    const f32x2 *yr = reinterpret_cast<const f32x2 *>(yf + (yfrow + k2) * YFS);
+                    const float rg = R * gcu;
                     const f32x2 rg2 = {rg, rg};
                     s0 += rg;
 #pragma unroll
-                    for (int c = 0; c < DPAD / 2; ++c) acc[c] = __builtin_elementwise_fma(rg2, yr[c], acc[c]);
+                    for (int c = 0; c < DPAD / 2; ++c) acc[c] = __builtin_elementwise_fma(rg2, ycu[c], acc[c]);
                     // pin the running sums here: the contraction must stay inside its step
 #pragma unroll
                     for (int c = 0; c < DPAD / 2; ++c) asm volatile("" : "+v"(acc[c]));
@@ -480,12 +479,31 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
                 // (column >= P, row >= P) read as S = 0, which is also exactly what the scatter needs at the
                 // wrap (S[.][-1] = S[.][63] = 0).  Two warm-up iterations fill the history, the next 64 visit
                 // every column n = q + 2 once; the travelling sums rotate as before and end in lane (64 - n) & 63.
+                auto slot_value = [&](int k) { // S of the cell in slot k, 0 where the slot holds no grid cell
+                    const int keep = __builtin_amdgcn_sbfe(k < 32 ? vm_lo : vm_hi, k & 31, 1);
+                    return __int_as_float(__float_as_int(Ksl[k]) & keep);
+                };
+                float gnx = 0.f, Svn = slot_value(63);
+                f32x2 ynx[DPAD / 2];
+#pragma unroll
+                for (int c = 0; c < DPAD / 2; ++c) ynx[c] = f32x2{0.f, 0.f};
 #pragma unroll
                 for (int it = 0; it < 66; ++it) {
-                    const int k = (63 - it) & 63;
-                    const int keep = __builtin_amdgcn_sbfe(k < 32 ? vm_lo : vm_hi, k & 31, 1); // -1 if the cell exists
-                    const float Sv = __int_as_float(__float_as_int(Ksl[k]) & keep);
-                    grad_part(k, Sv, it >= 2);
+                    const float Sv = Svn, gcu = gnx;
+                    f32x2 ycu[DPAD / 2];
+#pragma unroll
+                    for (int c = 0; c < DPAD / 2; ++c) ycu[c] = ynx[c];
+                    if (it + 1 < 66) { // next iteration's operands: slot (62 - it) & 63, column slot (64 - it) & 63
+                        Svn = slot_value((62 - it) & 63);
+                        if (it + 1 >= 2) {
+                            const int k2n = (64 - it) & 63;
+                            gnx = Gs_all[gsoff + k2n * GS_STRIDE];
+                            const f32x2 *yr = reinterpret_cast<const f32x2 *>(yf + (yfrow + k2n) * YFS);
+#pragma unroll
+                            for (int c = 0; c < DPAD / 2; ++c) ynx[c] = yr[c];
+                        }
+                    }
+                    grad_part(Sv, it >= 2, gcu, ycu);
                     __builtin_amdgcn_sched_barrier(0);
                 }
 
