@@ -314,7 +314,7 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
                         }
 #pragma unroll
                         for (int c = 0; c < DPAD; ++c) e2 = __builtin_fma(xs[c], ycu[c], e2);
-                        g = exp2_p8(e2);
+                        g = exp2_p7(e2);
                         if (GRAD) Gs[gs_index(t, lane)] = (float)g;
                         if (t == 0) g0 = g;
                         if (t == 1) g1 = g;

@@ -58,6 +58,23 @@ __device__ __forceinline__ double exp2_p8(double t)
     return ldexp(p, (int)kf);
 }
 
+// Degree-7 variant (max relative error 5.5e-11 on [-1/2, 1/2]) for the register-resident kernel, whose
+// increments are rounded to fp32 (6e-8 relative) right after: one Horner step fewer per static-kernel value.
+__device__ __forceinline__ double exp2_p7(double t)
+{
+    const double kf = __builtin_rint(t);
+    const double f = t - kf;
+    double p = 1.5303701161442145e-05;
+    p = __builtin_fma(p, f, 1.5469729221575116e-04);
+    p = __builtin_fma(p, f, 1.3333478471058548e-03);
+    p = __builtin_fma(p, f, 9.618025613268967e-03);
+    p = __builtin_fma(p, f, 5.5504109063307244e-02);
+    p = __builtin_fma(p, f, 2.4022651213498578e-01);
+    p = __builtin_fma(p, f, 6.931471805568296e-01);
+    p = __builtin_fma(p, f, 0.9999999999595621);
+    return ldexp(p, (int)kf);
+}
+
 // Same polynomial with the coefficients handed in by the caller, who keeps them in scalar registers inside
 // a rolled loop (empty `asm volatile("" : "+s"(c))` per iteration): hipcc otherwise hoists them into
 // VGPRs and pays one v_mov_b64 per Horner step to feed v_fmac_f64.
