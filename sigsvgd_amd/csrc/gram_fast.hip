@@ -133,9 +133,12 @@ __device__ __forceinline__ void store_any(void *base, size_t idx, double v, int 
         static_cast<float *>(base)[idx] = (float)v;
 }
 
-template <int DPAD, int NW, bool GRAD, bool SYM>
+// LP: the last of the DPAD channels is padding (d == DPAD - 1, e.g. the 7-DoF arm at DPAD = 8): its FMA in the
+// static kernel and its travelling column sum are dropped.
+template <int DPAD, int NW, bool GRAD, bool SYM, bool LP>
 __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
 {
+    constexpr int DC = LP ? DPAD - 1 : DPAD; // channels that can be non-zero
     constexpr int NT = NW * 64;
     // y rows are stored twice (row r and r + 64) so that the skewed row (t - lane) & 63 becomes
     // (64 - lane) + t: a per-lane base plus a compile-time offset.
@@ -313,7 +316,7 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
                             nnx = nbase[t + 1];
                         }
 #pragma unroll
-                        for (int c = 0; c < DPAD; ++c) e2 = __builtin_fma(xs[c], ycu[c], e2);
+                        for (int c = 0; c < DC; ++c) e2 = __builtin_fma(xs[c], ycu[c], e2);
                         g = exp2_p7(e2);
                         if (GRAD) Gs[gs_index(t, lane)] = (float)g;
                         if (t == 0) g0 = g;
@@ -433,7 +436,7 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
                         for (int c = 0; c < DPAD / 2; ++c) {
                             const f32x2 pr = rg2 * xc2[c];
                             tacc[2 * c] = add_rol1(tacc[2 * c], pr[0]);
-                            tacc[2 * c + 1] = add_rol1(tacc[2 * c + 1], pr[1]);
+                            if (2 * c + 1 < DC) tacc[2 * c + 1] = add_rol1(tacc[2 * c + 1], pr[1]);
                         }
 #pragma unroll
                         for (int c = 0; c < DPAD; ++c) asm volatile("" : "+v"(tacc[c]));
@@ -619,12 +622,18 @@ int launch_variant(const GramProblem &p, FastArgs &a, bool grad, bool sym)
     const long long resident = 256LL * (grad ? 1 : 3); // workgroups the chip holds at once (LDS / VGPR bound)
     dim3 grid((unsigned)(total < resident ? total : resident), 1);
     dim3 block(NW * 64);
+    constexpr bool HAS_LP = DPAD <= 8; // the d == DPAD - 1 instantiations exist for the 4- and 8-channel layouts
+    const bool lp = HAS_LP && grad && p.d == DPAD - 1;
     if (!grad)
-        hipLaunchKernelGGL((gram_fast_kernel<DPAD, NW, false, false>), grid, block, 0, p.stream, a);
+        hipLaunchKernelGGL((gram_fast_kernel<DPAD, NW, false, false, false>), grid, block, 0, p.stream, a);
+    else if (sym && lp)
+        hipLaunchKernelGGL((gram_fast_kernel<DPAD, NW, true, true, HAS_LP>), grid, block, 0, p.stream, a);
     else if (sym)
-        hipLaunchKernelGGL((gram_fast_kernel<DPAD, NW, true, true>), grid, block, 0, p.stream, a);
+        hipLaunchKernelGGL((gram_fast_kernel<DPAD, NW, true, true, false>), grid, block, 0, p.stream, a);
+    else if (lp)
+        hipLaunchKernelGGL((gram_fast_kernel<DPAD, NW, true, false, HAS_LP>), grid, block, 0, p.stream, a);
     else
-        hipLaunchKernelGGL((gram_fast_kernel<DPAD, NW, true, false>), grid, block, 0, p.stream, a);
+        hipLaunchKernelGGL((gram_fast_kernel<DPAD, NW, true, false, false>), grid, block, 0, p.stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "launch gram_fast_kernel");
     return SIGSVGD_OK;
