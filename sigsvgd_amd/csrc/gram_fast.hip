@@ -167,14 +167,17 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
     int i = 0, j0 = 0, j1 = 0;
     bool row_ok = false;
     const int lane_q = (lane < P) ? lane : 0x40000000; // rows without PDE cells never pass the range test below
-    // bit k: slot k of this lane holds a grid cell, i.e. lane < P and column (k - lane) & 63 < P
-    const unsigned long long vmask =
-        (lane < P) ? ((((1ull << P) - 1ull) << lane) | (lane ? (((1ull << P) - 1ull) >> (64 - lane)) : 0ull)) : 0ull;
-    const int vm_lo = (int)(unsigned)vmask, vm_hi = (int)(unsigned)(vmask >> 32);
     float *Gs = Gs_all + (GRAD ? wave * GS_WAVE : 0);
     const double inv_h = a.inv_h;
     const float m2h = (float)(-2.0 * inv_h);
 
+    // K_fwd, then S = K_fwd * U, of this lane's row, one slot per anti-diagonal (slot = (column + lane) & 63).
+    // Declared (and zeroed) once per kernel: the sweeps write a slot only while its cell is inside the grid, so
+    // the slots without a grid cell (column >= P or lane >= P) hold 0 for the whole launch and the phase-4 pass
+    // can read all 64 slots unmasked.
+    float Ksl[64];
+#pragma unroll
+    for (int k = 0; k < 64; ++k) Ksl[k] = 0.f;
     double gacc[DPAD]; // per-lane fp64 accumulators of d sum_j w_ij k(x_i, y_j) / d x_i[lane, c]
     double xraw[DPAD]; // raw row of x_i owned by this lane (fp64 copy of the fp32/fp64 input; exact)
 
@@ -274,7 +277,6 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
         if (j + 1 < j1) stage_load(j + 1); // in flight during the pair
 
         f32x2 Dsl2[32]; // increments, two slots per register pair: the stencil coefficients of two steps share packed math
-        float Ksl[64];
 
         if (pair_ok) {
             // ---- phase 0: centre x_i on y_j[0] ----------------------------------------------------
@@ -478,15 +480,11 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
                 // ---- phase 4: 4-corner scatter R and both contractions, one column per lane and iteration ----
                 // The reverse sweep has only half of its lanes inside the grid at any step, so nothing but the
                 // recurrence is left in it.  Here every lane is busy on every iteration: lane l takes the slots in
-                // descending order, i.e. column q = (63 - it - l) & 63 with wrap-around; cells outside the grid
-                // (column >= P, row >= P) read as S = 0, which is also exactly what the scatter needs at the
+                // descending order, i.e. column q = (63 - it - l) & 63 with wrap-around; slots without a grid cell
+                // (column >= P, row >= P) hold S = 0 (see Ksl), which is also exactly what the scatter needs at the
                 // wrap (S[.][-1] = S[.][63] = 0).  Two warm-up iterations fill the history, the next 64 visit
                 // every column n = q + 2 once; the travelling sums rotate as before and end in lane (64 - n) & 63.
-                auto slot_value = [&](int k) { // S of the cell in slot k, 0 where the slot holds no grid cell
-                    const int keep = __builtin_amdgcn_sbfe(k < 32 ? vm_lo : vm_hi, k & 31, 1);
-                    return __int_as_float(__float_as_int(Ksl[k]) & keep);
-                };
-                float gnx = 0.f, Svn = slot_value(63);
+                float gnx = 0.f, Svn = Ksl[63];
                 f32x2 ynx[DPAD / 2];
 #pragma unroll
                 for (int c = 0; c < DPAD / 2; ++c) ynx[c] = f32x2{0.f, 0.f};
@@ -497,7 +495,7 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
 #pragma unroll
                     for (int c = 0; c < DPAD / 2; ++c) ycu[c] = ynx[c];
                     if (it + 1 < 66) { // next iteration's operands: slot (62 - it) & 63, column slot (64 - it) & 63
-                        Svn = slot_value((62 - it) & 63);
+                        Svn = Ksl[(62 - it) & 63];
                         if (it + 1 >= 2) {
                             const int k2n = (64 - it) & 63;
                             gnx = Gs_all[gsoff + k2n * GS_STRIDE];
