@@ -202,8 +202,10 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
             if (e < 64 * DPAD) {
                 const int t = e / DPAD, c = e % DPAD;
                 const double v = stage_v[k] - stage_r[k];
-                yd[t * YDS + c] = v;
-                yd[(t + 64) * YDS + c] = v;
+                if (!(LP && c == DPAD - 1)) { // (LP: that slot receives the norm below)
+                    yd[t * YDS + c] = v;
+                    yd[(t + 64) * YDS + c] = v;
+                }
                 if (GRAD) {
                     yf[t * YFS + c] = (float)v;
                     yf[(t + 64) * YFS + c] = (float)v;
@@ -215,6 +217,10 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
                 if (c == 0) {
                     ynd[t] = s;
                     ynd[t + 64] = s;
+                    if (LP) { // the padded channel of the fp64 row carries the norm: phase 1 needs no separate read
+                        yd[t * YDS + DPAD - 1] = s;
+                        yd[(t + 64) * YDS + DPAD - 1] = s;
+                    }
                 }
             }
         }
@@ -302,7 +308,7 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
                 double ynx[DPAD], nnx;
 #pragma unroll
                 for (int c = 0; c < DPAD; ++c) ynx[c] = ybase[c];
-                nnx = nbase[0];
+                nnx = LP ? 0.0 : nbase[0];
 #pragma unroll
                 for (int t = 0; t < 66; ++t) {
                     double g;
@@ -310,12 +316,12 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
                         double ycu[DPAD];
 #pragma unroll
                         for (int c = 0; c < DPAD; ++c) ycu[c] = ynx[c];
-                        double e2 = xn + nnx;
+                        double e2 = LP ? xn + ycu[DPAD - 1] : xn + nnx; // LP: the row's last slot is the norm
                         if (t < 63) {
                             const double *yr = ybase + (t + 1) * YDS;
 #pragma unroll
                             for (int c = 0; c < DPAD; ++c) ynx[c] = yr[c];
-                            nnx = nbase[t + 1];
+                            if (!LP) nnx = nbase[t + 1];
                         }
 #pragma unroll
                         for (int c = 0; c < DC; ++c) e2 = __builtin_fma(xs[c], ycu[c], e2);
