@@ -180,7 +180,7 @@ def main():
         achieved = by / (k_ms * 1e-3) / 1e9
         roofline = {
             "bound": "hbm",
-            "kernel": "gram_fast_kernel<8,8,grad,sym> (+3.7 MB memset, finalize cast)",
+            "kernel": "gram_fast_kernel<8,8,grad,sym,d=7> (+3.7 MB memset, finalize cast)",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
@@ -197,7 +197,7 @@ def main():
                     "secondary figure below",
             # SQ counters of the same kernel (own rocprofv3 --pmc pass, profiles/r01_sq_counters_gram_fast_final.csv):
             # what actually bounds it is vector-instruction issue
-            "valu_issue": {"vector_pipe_busy_frac": 0.82, "vector_insts_per_launch": 3.81e9,
+            "valu_issue": {"vector_pipe_busy_frac": 0.84, "vector_insts_per_launch": 3.45e9,
                            "source": "profiles/r01_sq_counters_gram_fast_final.csv"},
             "valu_fp64": {
                 "achieved_tflops": fl / (k_ms * 1e-3) / 1e12,
