@@ -5,22 +5,29 @@
 //   * lane l owns row l of the T x T static-kernel matrix G, row l of the (T-1)^2 increment matrix D,
 //     row l+1 of the forward PDE solution K and row l of the reverse solution U;
 //   * on anti-diagonal sigma (= row + column) every lane works on column sigma - l, so every
-//     per-cell quantity a lane will need again (D, K_fwd, G) is filed under slot sigma & 63:
+//     per-cell quantity a lane will need again (D, K_fwd / S, G) is filed under slot sigma & 63:
 //     the slot index is a compile-time constant of the (fully unrolled) step, the same for all
-//     lanes, so D and K_fwd live in 2 x 64 VGPRs and G in a [slot][lane] LDS image (XOR-swizzled so
-//     that the transposed read of the symmetric pass is also bank-conflict free);
+//     lanes, so D and K_fwd live in 2 x 64 VGPRs and G in a [slot][lane] LDS image;
 //   * neighbour rows are reached with wave-wide DPP shifts (no LDS round trip in the recurrence);
 //   * the static kernel, the 4-corner increments and both PDE sweeps run in fp64 (the increments
 //     cancel ~1e-2 of G; the sweep accumulates ~4e3 cells), everything that is only stored or
 //     contracted (D, K_fwd, G, S = K_fwd*U, R, gradient sums per pair) is fp32, the reduction over
 //     pairs is fp64 -- measured to keep K within 3e-8 and grad within 1e-6 of the fp64 oracle.
 //
+// Per pair: phase 1 static kernel + increments (wrap-around skew, all lanes busy, 66 iterations);
+// phase 2 forward sweep (K_fwd into the slots); phase 3 reverse sweep (U recurrence only, S = K_fwd*U
+// overwrites K_fwd in its slot); phase 4 scatter R, R*G and both contractions in a second wrap-around
+// pass (66 iterations, all lanes busy).  The two sweeps have on average half of their lanes outside the
+// grid, so they contain nothing but the recurrence.  The kernel is bound by vector-instruction issue
+// (84 % pipe occupancy at two waves per SIMD), i.e. by its instruction count: see DESIGN.md 5.1.
+//
 // A workgroup is NW wavefronts = NW consecutive rows i of X against a chunk of columns j; the
 // column trajectory (centred on its first point, fp64 + fp32 copies) is staged once per j in LDS
 // and shared by the NW pairs.  With Y == X each unordered pair {i<j} is solved once: the row-side
-// contraction gives d k(x_i,x_j)/d x_i, the column-side contraction (transposed read of R*G from
-// LDS) gives d k(x_j,x_i)/d x_j.  Gradients are accumulated per lane in fp64 over the j loop and
-// added to an fp64 accumulation buffer with one atomic per element per workgroup.
+// contraction gives d k(x_i,x_j)/d x_i, the column-side sums (travelling accumulators, one wave
+// rotation per sum and iteration) give d k(x_j,x_i)/d x_j.  Row-side gradients stay in per-lane fp64
+// registers while a workgroup works on its row tile (work queue); column-side results of the NW waves
+// are summed in fixed order through LDS and added with one fp64 atomic per element and column.
 //
 // Reference semantics: sigkernel _SigKernelGram.forward/backward [RECALLED, SURVEY.md App. A];
 // static kernel src/kernels/_traj_kernels.py:176-195; callers src/inference/score.py:68-69.
@@ -390,7 +397,7 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
             }
 
             if (GRAD) {
-                // ---- phase 3: reverse sweep + lagged R -> row-side contraction ----------------------
+                // ---- phase 3: reverse sweep (U recurrence; S replaces K_fwd slot by slot) -----------------
                 double cur = 1.0, downA = 1.0, downB = 1.0; // `down` persists (lane 63 keeps U[P][.] = 1), alternating as above
                 f32x2 b2 = {0.f, 0.f}, aa2 = {0.f, 0.f};
                 float Sb = 0.f, Sc = 0.f, Nb = 0.f, s0 = 0.f;
@@ -454,7 +461,9 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
 
                 for (int rnd = 1; rnd >= 0; --rnd) {
                     if (rnd * 64 > smax) continue;
-                    asm volatile("" : "+v"(yfrow), "+v"(gsoff)); // loads below are not round-invariant
+                    // (keeps the phase-4 LDS addresses out of this loop's invariants: without the pin hipcc
+                    //  rearranges the pass that follows and the C4 launch goes from 6.9 to 10.9 ms)
+                    asm volatile("" : "+v"(yfrow), "+v"(gsoff));
                     float c12 = 1.0f / 12.0f, chalf = 0.5f;
                     asm volatile("" : "+s"(c12), "+s"(chalf));
 #pragma unroll
