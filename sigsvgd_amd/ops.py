@@ -111,19 +111,9 @@ def gram_fwd(X, Y, inv_h: float, dyadic_order: int = 0, static_kind: int = _lib.
 STREAM_GMAX = 0.4  # include/sigsvgd_hip.h SIGSVGD_STREAM_GMAX
 
 
-def _needs_coverage_kernel(Xc, Yc, inv_h: float, dyadic_order: int, static_kind: int) -> bool:
-    """Long paths (65 <= T <= 128, dyadic order 0, RBF) run on the streaming kernel, which regenerates the
-    forward solution backwards and is accurate only while the static-kernel increments stay below
-    STREAM_GMAX (it returns NaN gradients beyond).  The largest increment of a launch is that of a path
-    against itself, 2 (1 - exp(-max |dx|^2 / h)): one small device reduction + one scalar read-back."""
-    T = Xc.shape[1]
-    if dyadic_order != 0 or static_kind != _lib.STATIC_RBF or T < 65 or T > 128 or Xc.shape[2] > 16:
-        return False
-    m = (Xc[:, 1:] - Xc[:, :-1]).square().sum(-1).max()
-    if Yc is not Xc:
-        m = torch.maximum(m, (Yc[:, 1:] - Yc[:, :-1]).square().sum(-1).max())
-    gest = 2.0 * (1.0 - torch.exp(-float(inv_h) * m.double()))
-    return bool(gest > STREAM_GMAX)  # NaN increments fall through to the streaming kernel (NaN out either way)
+def _is_streaming_shape(T: int, d: int, dyadic_order: int, static_kind: int, naive: bool) -> bool:
+    """Launches the streaming kernel serves (include/sigsvgd_hip.h): long paths, dyadic order 0, RBF."""
+    return dyadic_order == 0 and static_kind == _lib.STATIC_RBF and 65 <= T <= 128 and d <= 16 and not naive
 
 
 def gram_fwd_bwd(X, Y, inv_h: float, dyadic_order: int = 0, static_kind: int = _lib.STATIC_RBF,
@@ -132,15 +122,17 @@ def gram_fwd_bwd(X, Y, inv_h: float, dyadic_order: int = 0, static_kind: int = _
                  check_regime: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
     """(K[A,B], gradX[A,T,d]) with gradX = d sum(grad_out*K)/dX (first slot); grad_out None = ones.
 
-    check_regime: for long paths, pick the coverage kernel when the paths are too rough for the streaming
-    kernel (see _needs_coverage_kernel; costs one host sync, skipped for T <= 64)."""
+    check_regime: long paths (65 <= T <= 128) run on the streaming kernel, which regenerates the forward
+    solution backwards and returns NaN gradients for the pairs whose increments exceed STREAM_GMAX (very
+    rough paths, typically a path against itself).  With check_regime the result is inspected (one scalar
+    read-back) and, if the guard fired on finite inputs, the launch is repeated on the coverage kernel,
+    which keeps the forward solution.  Skipped for T <= 64."""
     L = _lib.load()
     dev = _require_gpu(X, Y, grad_out)
     Xc, Yc = _prep_paths(X, Y)
     A, T, d = Xc.shape
     B = Yc.shape[0]
-    if check_regime and not force_generic and not naive and _needs_coverage_kernel(Xc, Yc, inv_h, dyadic_order, static_kind):
-        force_generic = True
+    guarded = check_regime and not force_generic and _is_streaming_shape(T, d, dyadic_order, static_kind, naive)
     go = None
     if grad_out is not None:
         if tuple(grad_out.shape) != (A, B):
@@ -159,6 +151,8 @@ def gram_fwd_bwd(X, Y, inv_h: float, dyadic_order: int = 0, static_kind: int = _
                                     go.data_ptr() if go is not None else None, K.data_ptr(), gX.data_ptr(),
                                     ws.data_ptr() if ws is not None else None, wsn, _stream_ptr(dev))
     _lib.check(rc, "gram_fwd_bwd")
+    if guarded and bool(torch.isnan(gX).any()) and bool(torch.isfinite(Xc).all()) and bool(torch.isfinite(Yc).all()):
+        return gram_fwd_bwd(X, Y, inv_h, dyadic_order, static_kind, grad_out, naive, sym, y_is_x, True, False)
     return K, gX
 
 
