@@ -637,7 +637,9 @@ int launch_variant(const GramProblem &p, FastArgs &a, bool grad, bool sym)
     dim3 block(NW * 64);
     constexpr bool HAS_LP = DPAD <= 8; // the d == DPAD - 1 instantiations exist for the 4- and 8-channel layouts
     const bool lp = HAS_LP && grad && p.d == DPAD - 1;
-    if (!grad)
+    if (!grad && sym)
+        hipLaunchKernelGGL((gram_fast_kernel<DPAD, NW, false, true, false>), grid, block, 0, p.stream, a);
+    else if (!grad)
         hipLaunchKernelGGL((gram_fast_kernel<DPAD, NW, false, false, false>), grid, block, 0, p.stream, a);
     else if (sym && lp)
         hipLaunchKernelGGL((gram_fast_kernel<DPAD, NW, true, true, HAS_LP>), grid, block, 0, p.stream, a);
@@ -656,7 +658,7 @@ int launch_variant(const GramProblem &p, FastArgs &a, bool grad, bool sym)
 int fast_launch(const GramProblem &p)
 {
     const bool grad = p.gradX_out != nullptr;
-    const bool sym = grad && (p.flags & SIGSVGD_FLAG_Y_IS_X) && p.A == p.B;
+    const bool sym = (p.flags & SIGSVGD_FLAG_Y_IS_X) && p.A == p.B; // Y is X: each unordered pair once, K mirrored
     FastArgs a;
     a.X = p.X; a.Y = p.Y; a.go = p.grad_out; a.K = p.K_out;
     a.io64 = p.dtype == SIGSVGD_F64; a.A = p.A; a.B = p.B; a.T = p.T; a.d = p.d;
@@ -685,9 +687,9 @@ int fast_launch(const GramProblem &p)
     }
     int rc;
     if (!grad && p.d <= 4) // forward only: no G image, <=168 VGPRs -> 4-wave workgroups pack 3 waves per SIMD
-        rc = launch_variant<4, 4>(p, a, false, false);
+        rc = launch_variant<4, 4>(p, a, false, sym);
     else if (!grad && p.d <= 8)
-        rc = launch_variant<8, 4>(p, a, false, false);
+        rc = launch_variant<8, 4>(p, a, false, sym);
     else if (p.d <= 4)
         rc = launch_variant<4, 8>(p, a, grad, sym);
     else if (p.d <= 8)

@@ -87,14 +87,15 @@ def _flags(naive: bool, sym: bool, y_is_x: bool, force_generic: bool) -> int:
 
 
 def gram_fwd(X, Y, inv_h: float, dyadic_order: int = 0, static_kind: int = _lib.STATIC_RBF,
-             naive: bool = False, force_generic: bool = False) -> torch.Tensor:
-    """K[A,B] = signature-kernel Gram matrix (forward only)."""
+             naive: bool = False, force_generic: bool = False, y_is_x: bool = False) -> torch.Tensor:
+    """K[A,B] = signature-kernel Gram matrix (forward only).  y_is_x: the caller states that Y holds the
+    same values as X, so each unordered pair is solved once and K is mirrored."""
     L = _lib.load()
     dev = _require_gpu(X, Y)
     Xc, Yc = _prep_paths(X, Y)
     A, T, d = Xc.shape
     B = Yc.shape[0]
-    flags = _flags(naive, False, False, force_generic)
+    flags = _flags(naive, False, bool(y_is_x) and A == B, force_generic)
     nbytes = ctypes.c_size_t(0)
     _lib.check(L.sigsvgd_gram_workspace_bytes(A, B, T, d, dyadic_order, 0, flags, ctypes.byref(nbytes)),
                "gram_workspace_bytes")

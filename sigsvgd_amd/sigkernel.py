@@ -158,7 +158,7 @@ class _SigKernelGram(torch.autograd.Function):
             K, g1 = ops.gram_fwd_bwd(Xd, Yd, inv_h, dyadic_order, static_kind, None, naive, sym, y_is_x)
             ctx.g_ones = g1
         else:
-            K = ops.gram_fwd(Xd, Yd, inv_h, dyadic_order, static_kind, naive)
+            K = ops.gram_fwd(Xd, Yd, inv_h, dyadic_order, static_kind, naive, y_is_x=y_is_x)
         ctx.save_for_backward(Xd, Yd)
         return K
 

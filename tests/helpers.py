@@ -18,7 +18,7 @@ def _np(t):
     return t.detach().cpu().numpy().astype(np.float64)
 
 
-def gram_fwd(X, Y, inv_h, dyadic_order=0, static_kind=0, naive=False, force_generic=False):
+def gram_fwd(X, Y, inv_h, dyadic_order=0, static_kind=0, naive=False, force_generic=False, y_is_x=False):
     K = O.gram(_np(X), _np(Y), static_kind, 1.0 / inv_h, dyadic_order, naive)
     return torch.as_tensor(K, dtype=X.dtype)
 

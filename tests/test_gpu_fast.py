@@ -157,3 +157,15 @@ def test_argument_errors(gpu):
         ops.gram_fwd(x.half(), x.half(), 1.0)
     with pytest.raises(RuntimeError, match="inv_h"):
         ops.gram_fwd(x, x, -1.0)
+
+
+@pytest.mark.parametrize("N,T,d", [(21, 64, 7), (9, 33, 3), (12, 128, 14), (7, 100, 5)])
+def test_forward_only_symmetric_solve(gpu, N, T, d):
+    """gram_fwd(X, X, y_is_x=True): each unordered pair once, K mirrored == the ordered forward launch"""
+    from sigsvgd_amd import ops
+
+    X = torch.as_tensor(_paths(N, T, d, 31), device=gpu)
+    K1 = ops.gram_fwd(X, X, 1.0, y_is_x=True)
+    K0 = ops.gram_fwd(X, X.clone(), 1.0)
+    assert torch.equal(K1, K1.T)
+    assert _rel(K1.cpu().numpy(), K0.double().cpu().numpy()) < 1e-6
