@@ -1,50 +1,72 @@
-"""Score estimator wiring cost -> grad log p and kernel -> (K, grad_k) for SVGD
-(reference src/inference/score.py:6-76; only the signature-kernel branch is in scope)."""
+"""Score estimation for SVGD: turns a batch cost function into grad log p and asks the kernel for the
+Gram matrix and its repulsive gradient (reference API: src/inference/score.py:6-76).
+
+`ScoreEstimator(kernel, cost_fn, cost_fn_params, scheduler, ctx).score(x)` returns
+`(grad_log_p, {"k_xx", "grad_k", "loss", **aux})` exactly like the reference; which kernel route is taken is
+decided once, at construction:
+
+    SignatureKernel               -> one fused HIP launch for K and d sum(K)/dx        (`_pathsig_score`)
+    BaseKernel with analytic_grad -> kernel(x, x) returns (K, summed gradient)        (`_svgd_score`)
+    other BaseKernel              -> K differentiable, gradient by autograd           (`_svgd_ag_score`)
+`sgd_score` (no interaction between particles) is available for plain gradient descent baselines.
+"""
 from __future__ import annotations
 
 import torch
-from torch.autograd import grad as ag
 
 from ..kernels import BaseKernel, SignatureKernel
 
 
 class ScoreEstimator:
     def __init__(self, kernel, cost_fn, cost_fn_params, scheduler=None, ctx={"device": "cpu"}):
-        self.ctx = ctx
         self.kernel = kernel
         self.cost_fn = cost_fn
         self.cost_fn_params = cost_fn_params
-        self.scheduler = (lambda: 1) if scheduler is None else scheduler
-        if isinstance(self.kernel, SignatureKernel):
-            self.score = self._pathsig_score
-        elif isinstance(self.kernel, BaseKernel):
-            self.score = self._svgd_score if self.kernel.analytic_grad is True else self._svgd_ag_score
+        self.ctx = ctx
+        self.scheduler = scheduler if scheduler is not None else (lambda: 1)
+        route = self._route_for(kernel)
+        if route is not None:
+            self.score = route
 
+    def _route_for(self, kernel):
+        if isinstance(kernel, SignatureKernel):
+            return self._pathsig_score
+        if isinstance(kernel, BaseKernel):
+            return self._svgd_score if kernel.analytic_grad is True else self._svgd_ag_score
+        return None  # like the reference: `score` stays undefined for unknown kernel types
+
+    # -- shared pieces ---------------------------------------------------------------------------------
+    def _likelihood_gradient(self, x):
+        """cost(x) -> (grad of log exp(-cost), cost, aux dict); the graph is kept for the kernel term."""
+        cost, aux = self.cost_fn(x, **self.cost_fn_params)
+        (grad_log_p,) = torch.autograd.grad(-cost.sum(), x, retain_graph=True)
+        return grad_log_p, cost, aux
+
+    def _pack(self, k_xx, grad_k, cost, aux, scale=True):
+        out = {"k_xx": k_xx, "grad_k": self.scheduler() * grad_k if scale else grad_k, "loss": cost}
+        out.update(aux)
+        return out
+
+    # -- routes ----------------------------------------------------------------------------------------
     def sgd_score(self, x):
-        """No interaction between particles: identity Gram matrix, zero repulsion."""
-        cost, cost_dict = self.cost_fn(x, **self.cost_fn_params)
-        grad_log_p = ag(-cost.sum(), x, retain_graph=True)[0]  # likelihood is exp(-cost)
-        k_xx = torch.eye(x.shape[0], **self.ctx)
-        grad_k = torch.zeros_like(grad_log_p, **self.ctx)
-        return grad_log_p, {"k_xx": k_xx, "grad_k": grad_k, "loss": cost, **cost_dict}
+        grad_log_p, cost, aux = self._likelihood_gradient(x)
+        eye = torch.eye(x.shape[0], **self.ctx)
+        return grad_log_p, self._pack(eye, torch.zeros_like(grad_log_p, **self.ctx), cost, aux, scale=False)
 
     def _svgd_score(self, x):
-        cost, cost_dict = self.cost_fn(x, **self.cost_fn_params)
-        grad_log_p = ag(-cost.sum(), x, retain_graph=True)[0]
+        grad_log_p, cost, aux = self._likelihood_gradient(x)
         k_xx, grad_k = self.kernel(x, x, compute_grad=True)
-        return grad_log_p, {"k_xx": k_xx, "grad_k": self.scheduler() * grad_k, "loss": cost, **cost_dict}
+        return grad_log_p, self._pack(k_xx, grad_k, cost, aux)
 
     def _svgd_ag_score(self, x):
-        cost, cost_dict = self.cost_fn(x, **self.cost_fn_params)
-        grad_log_p = ag(-cost.sum(), x, retain_graph=True)[0]
+        grad_log_p, cost, aux = self._likelihood_gradient(x)
         k_xx = self.kernel(x, x.detach(), compute_grad=False)
-        grad_k = ag(k_xx.sum(), x)[0]
-        return grad_log_p, {"k_xx": k_xx, "grad_k": self.scheduler() * grad_k, "loss": cost, **cost_dict}
+        (grad_k,) = torch.autograd.grad(k_xx.sum(), x)
+        return grad_log_p, self._pack(k_xx, grad_k, cost, aux)
 
     def _pathsig_score(self, x):
-        """k_xx = K(x, x.detach()), grad_k = d sum(k_xx)/dx -- fused into one HIP launch."""
-        cost, cost_dict = self.cost_fn(x, **self.cost_fn_params)
-        grad_log_p = ag(-cost.sum(), x, retain_graph=True)[0]
+        # reference: k_xx = kernel(x, x.detach()); grad_k = autograd(k_xx.sum(), x) (score.py:68-69) --
+        # here both come out of one fused forward+backward launch on detached particles
+        grad_log_p, cost, aux = self._likelihood_gradient(x)
         k_xx, grad_k = self.kernel.gram_and_grad(x.detach())
-        score_dict = {"k_xx": k_xx, "grad_k": self.scheduler() * grad_k, "loss": cost, **cost_dict}
-        return grad_log_p, score_dict
+        return grad_log_p, self._pack(k_xx, grad_k, cost, aux)

@@ -1,194 +1,192 @@
-"""Stein variational gradient descent driver (reference src/inference/svgd.py:11-159).
+"""Stein variational gradient descent driver with the reference's interface (src/inference/svgd.py:11-159):
+`SVGD(kernel, log_p, log_prior, bw_scale, optimizer_class, adaptive_gradient, **opt_args)`,
+`.step(X, grad_log_p, optimizer, **kw) -> (X, iter_dict)` and
+`.optimize(particles, score_estimator, opt_state, n_steps, debug, callback_func, **kw) -> (data_dict, opt_state)`.
 
-Same constructor, `step()` and `optimize()` signatures and return values as the reference.  The
-dense part of the velocity, v = -((K @ score - grad_k)/N), and the optimizer=None update run in
-one HIP launch (`ops.svgd_phi`, fp32 MFMA).  Differences, all opt-in or invisible in the results:
+What runs where: the dense part of the velocity, v = -((K @ score - grad_k)/N), is one HIP launch
+(`ops.svgd_phi`, fp32 MFMA); with `optimizer_class=None` the same launch also applies the reference's simple
+Adagrad (`adaptive_gradient=True`) and the update X - lr*g.  torch optimizers (Adam by default) are driven
+through the usual closure.  Deliberate differences, none of which changes a result:
 
-  * `iter_dict_device`: "cpu" (default, reference behaviour: every tensor of the per-iteration
-    dict is moved to the host, svgd.py:85-90) or None to leave tensors on the GPU -- the eager
-    D2H of the N x N Gram matrix otherwise dominates a sub-millisecond iteration;
-  * the trace is written into a preallocated [n_steps+1, ...] device buffer and copied to the host
-    once, instead of an O(n_steps^2) torch.cat per iteration (svgd.py:150-152);
-  * with optimizer_class=None the reference re-binds X to a non-leaf whose autograd graph grows
-    every iteration (svgd.py:115,146); here X stays detached.
+  * `iter_dict_device`: "cpu" (default; the reference moves every tensor of the per-iteration dict to the host,
+    svgd.py:85-90) or None to leave them on the GPU -- the eager copy of the N x N Gram matrix otherwise
+    dominates a millisecond-scale iteration;
+  * the particle trace is written into one preallocated [n_steps+1, ...] device buffer and copied to the host
+    once, not re-concatenated on the host every iteration (svgd.py:150-152);
+  * with `optimizer_class=None` X stays detached between iterations (the reference re-binds it to a non-leaf
+    whose autograd graph grows, svgd.py:115,146).
 """
 from __future__ import annotations
 
-from typing import Callable, Tuple
+from typing import Callable, Optional, Tuple
 
 import torch
-import torch.autograd as autograd
 import torch.optim as optim
 
 from .. import ops
+
+_NEEDS_TARGET = (
+    "SVGD needs a function to evaluate the log probability of the target distribution or an estimate of the "
+    "gradient for every particle."
+)
 
 
 class SVGD:
     """Stein variational gradient descent with pluggable kernels."""
 
-    def __init__(
-        self,
-        kernel=None,
-        log_p: Callable = None,
-        log_prior: Callable = None,
-        bw_scale: float = 1.0,
-        optimizer_class: optim.Optimizer = optim.Adam,
-        adaptive_gradient: bool = False,
-        iter_dict_device="cpu",
-        **opt_args,
-    ):
-        if kernel is None:
+    def __init__(self, kernel=None, log_p: Callable = None, log_prior: Callable = None, bw_scale: float = 1.0,
+                 optimizer_class: optim.Optimizer = optim.Adam, adaptive_gradient: bool = False,
+                 iter_dict_device="cpu", **opt_args):
+        if kernel is None:  # the reference's default (svgd.py:24-25)
             from ..kernels import GaussianKernel
 
-            kernel = GaussianKernel()  # reference default (svgd.py:24-25)
-        self.kernel = kernel
-        self.log_p = log_p
-        self.log_prior = log_prior
+            kernel = GaussianKernel()
+        self.kernel, self.log_p, self.log_prior = kernel, log_p, log_prior
         self.bw_scale = bw_scale
-        self.optimizer_class = optimizer_class
-        self.opt_args = opt_args
-        self.opt_adagrad = adaptive_gradient
-        self.opt_inertia = 0
+        self.optimizer_class, self.opt_args = optimizer_class, opt_args
+        self.opt_adagrad, self.opt_inertia = adaptive_gradient, 0
         self.iter_dict_device = iter_dict_device
+        self._fuse_manual_update = None
 
-    # -- kernel ---------------------------------------------------------------------------------
+    # ---------------------------------------------------------------------------------------------------
+    # kernel term
+    # ---------------------------------------------------------------------------------------------------
     def _compute_kernel(self, X: torch.Tensor, **kwargs):
-        """(K, grad_k [N, T*d]) with grad_k = d sum_j k(x_i, x_j) / d x_i (first slot)."""
-        if hasattr(self.kernel, "gram_and_grad"):  # SignatureKernel / SigKernel: one fused launch
-            k_xx, grad_k = self.kernel.gram_and_grad(X.detach())
+        """(K, grad_k [N, D]): grad_k[i] = sum_j d k(x_i, x_j) / d x_i (derivative in the first slot)."""
+        kernel = self.kernel
+        if hasattr(kernel, "gram_and_grad"):  # signature kernels: K and its gradient from one fused launch
+            k_xx, grad_k = kernel.gram_and_grad(X.detach())
             return k_xx, grad_k.flatten(1)
-        if hasattr(self.kernel, "analytic_grad") and self.kernel.analytic_grad:
-            k_xx, grad_k = self.kernel(X, X)
+        if getattr(kernel, "analytic_grad", False):
+            k_xx, grad_k = kernel(X, X)
         else:
-            X = X.detach().requires_grad_(True)
-            k_xx = self.kernel(X, X.detach(), compute_grad=False)
-            grad_k = autograd.grad(k_xx.sum(), X)[0].flatten(1)
+            Xg = X.detach().requires_grad_(True)
+            k_xx = kernel(Xg, Xg.detach(), compute_grad=False)
+            grad_k = torch.autograd.grad(k_xx.sum(), Xg)[0].flatten(1)
         return k_xx.detach(), grad_k.detach()
 
-    def _to_host(self, iter_dict: dict) -> dict:
-        if self.iter_dict_device is None:
-            return {k: v.detach() if hasattr(v, "detach") else v for k, v in iter_dict.items()}
-        return {
-            k: v.detach().to(self.iter_dict_device) if hasattr(v, "detach") else v for k, v in iter_dict.items()
-        }
+    def _kernel_terms(self, X, kwargs):
+        if "k_xx" in kwargs and "grad_k" in kwargs:  # handed in by a score estimator
+            k_xx, grad_k = kwargs["k_xx"], kwargs["grad_k"]
+            return k_xx, (grad_k.flatten(1) if grad_k.dim() > 1 else grad_k)
+        return self._compute_kernel(X, **kwargs)
 
-    # -- velocity -------------------------------------------------------------------------------
-    def _velocity(self, X: torch.Tensor, grad_log_p: torch.Tensor, **kwargs) -> Tuple[torch.Tensor, dict]:
-        if self.log_p is None and grad_log_p is None:
-            raise ValueError(
-                """SVGD needs a function to evaluate the log probability of the target
-                distribution or an estimate of the gradient for every particle.""",
-            )
-        if "k_xx" in kwargs and "grad_k" in kwargs:
-            k_xx = kwargs["k_xx"]
-            grad_k = kwargs["grad_k"]
-            if len(grad_k.shape) > 1:
-                grad_k = grad_k.flatten(1)
-        else:
-            k_xx, grad_k = self._compute_kernel(X, **kwargs)
-
+    # ---------------------------------------------------------------------------------------------------
+    # score term
+    # ---------------------------------------------------------------------------------------------------
+    def _score_terms(self, X, grad_log_p, kwargs):
+        """(score [N, D], loss): grad log p of the target (given, or differentiated from log_p) plus the
+        gradient of the log prior if there is one."""
         if grad_log_p is None:
-            X = X.detach().requires_grad_(True)
-            log_lik = self.log_p(X).sum()
-            score = autograd.grad(log_lik, X)[0].flatten(1)
-            X.detach_()
+            Xg = X.detach().requires_grad_(True)
+            log_lik = self.log_p(Xg).sum()
+            score = torch.autograd.grad(log_lik, Xg)[0].flatten(1)
             loss = -log_lik.detach()
         else:
             score = grad_log_p.flatten(1)
-            if "loss" in kwargs:
-                loss = kwargs["loss"].sum()
-            else:
-                loss = grad_log_p.norm()
-
+            loss = kwargs["loss"].sum() if "loss" in kwargs else grad_log_p.norm()
         if self.log_prior is not None:
-            X = X.detach().requires_grad_(True)
-            log_prior_sum = self.log_prior(X).sum()
-            log_prior_grad = torch.autograd.grad(log_prior_sum, X)[0]
-            score = score + log_prior_grad.detach().flatten(1)
-            X.detach_()
+            Xg = X.detach().requires_grad_(True)
+            prior_grad = torch.autograd.grad(self.log_prior(Xg).sum(), Xg)[0]
+            score = score + prior_grad.detach().flatten(1)
+        return score, loss
 
-        # v = -((k_xx @ score - grad_k) / N), one HIP launch (fp32 MFMA GEMM + fused epilogue)
-        fuse = getattr(self, "_fuse_manual_update", None)
-        if fuse is not None:
-            # step() with optimizer=None asked for the whole update in the same launch:
-            # [Adagrad scaling,] X - lr * v   (reference svgd.py:108-115)
+    def _export(self, iter_dict: dict) -> dict:
+        dev = self.iter_dict_device
+        move = (lambda t: t.detach()) if dev is None else (lambda t: t.detach().to(dev))
+        return {k: (move(v) if hasattr(v, "detach") else v) for k, v in iter_dict.items()}
+
+    # ---------------------------------------------------------------------------------------------------
+    # velocity
+    # ---------------------------------------------------------------------------------------------------
+    def _velocity(self, X: torch.Tensor, grad_log_p: torch.Tensor, **kwargs) -> Tuple[torch.Tensor, dict]:
+        if self.log_p is None and grad_log_p is None:
+            raise ValueError(_NEEDS_TARGET)
+        k_xx, grad_k = self._kernel_terms(X, kwargs)
+        score, loss = self._score_terms(X, grad_log_p, kwargs)
+
+        fuse = self._fuse_manual_update
+        if fuse is None:
+            velocity = ops.svgd_phi(k_xx, score, grad_k)
+        else:  # step(optimizer=None): [Adagrad scaling,] X - lr*g in the same launch (reference svgd.py:108-115)
             velocity, X_new = ops.svgd_phi(k_xx, score, grad_k, X=X.detach(), lr=fuse["lr"],
                                            adagrad_state=fuse["adagrad_state"])
             fuse["X_new"] = X_new.reshape(X.shape).to(X.dtype)
-            velocity = velocity.reshape(X.shape).to(X.dtype)
-        else:
-            velocity = ops.svgd_phi(k_xx, score, grad_k).reshape(X.shape).to(X.dtype)
+        velocity = velocity.reshape(X.shape).to(X.dtype)
 
-        iter_dict = {"k_xx": k_xx, "grad_k": grad_k, "loss": loss}
-        iter_dict.update(kwargs)
-        return velocity, self._to_host(iter_dict)
+        iter_dict = {"k_xx": k_xx, "grad_k": grad_k, "loss": loss, **kwargs}
+        return velocity, self._export(iter_dict)
 
-    # -- one update -----------------------------------------------------------------------------
+    # ---------------------------------------------------------------------------------------------------
+    # one update
+    # ---------------------------------------------------------------------------------------------------
+    def _grad_entry(self, g):
+        g = g.detach()
+        return g if self.iter_dict_device is None else g.to(self.iter_dict_device)
+
+    def _fused_manual_step(self, X, grad_log_p, kwargs):
+        """velocity, optional simple Adagrad (state in self.opt_inertia, in place) and X - lr*g: one launch."""
+        state = None
+        if self.opt_adagrad:
+            if not torch.is_tensor(self.opt_inertia):
+                self.opt_inertia = torch.zeros(X.shape, dtype=torch.float32, device=X.device)
+            state = self.opt_inertia
+        self._fuse_manual_update = {"lr": float(self.opt_args["lr"]), "adagrad_state": state}
+        try:
+            grad, iter_dict = self._velocity(X, grad_log_p, **kwargs)
+            X_new = self._fuse_manual_update["X_new"]
+        finally:
+            self._fuse_manual_update = None
+        return X_new, grad, iter_dict
+
     def step(self, X: torch.Tensor, grad_log_p: torch.Tensor = None, optimizer: optim.Optimizer = None, **kwargs):
-        def closure():
-            optimizer.zero_grad()
-            X.grad, iter_dict = self._velocity(X, grad_log_p, **kwargs)
-            iter_dict["grad"] = self._grad_entry(X.grad)
-            return iter_dict
-
         if isinstance(optimizer, torch.optim.Optimizer):
-            iter_dict = optimizer.step(closure)
-        elif type(self)._velocity is SVGD._velocity and X.dtype == torch.float32 and X.device.type == "cuda":
-            # velocity, the reference's simple Adagrad (adaptive_gradient=True) and X - lr * grad in ONE launch
-            state = None
-            if self.opt_adagrad:
-                if not torch.is_tensor(self.opt_inertia):
-                    self.opt_inertia = torch.zeros(X.shape, dtype=torch.float32, device=X.device)
-                state = self.opt_inertia
-            self._fuse_manual_update = {"lr": float(self.opt_args["lr"]), "adagrad_state": state}
-            try:
-                grad, iter_dict = self._velocity(X, grad_log_p, **kwargs)
-                X = self._fuse_manual_update["X_new"]
-            finally:
-                self._fuse_manual_update = None
-            iter_dict["grad"] = self._grad_entry(grad)
+            def closure():  # torch optimizers: the velocity is the "gradient" they descend along
+                optimizer.zero_grad()
+                X.grad, info = self._velocity(X, grad_log_p, **kwargs)
+                info["grad"] = self._grad_entry(X.grad)
+                return info
+
+            return X, optimizer.step(closure)
+
+        fusable = type(self)._velocity is SVGD._velocity and X.dtype == torch.float32 and X.device.type == "cuda"
+        if fusable:
+            X, grad, iter_dict = self._fused_manual_step(X, grad_log_p, kwargs)
         else:  # subclasses that post-process the velocity (TrajectorySVGD's mask), other dtypes
             grad, iter_dict = self._velocity(X, grad_log_p, **kwargs)
-            if self.opt_adagrad:  # simple Adagrad: running sum of squared gradients
+            if self.opt_adagrad:  # running sum of squared gradients (reference svgd.py:110-113)
                 self.opt_inertia = self.opt_inertia + grad**2
                 grad = grad / torch.sqrt(self.opt_inertia + 1e-12)
-            iter_dict["grad"] = self._grad_entry(grad)
             X = X.detach() - self.opt_args["lr"] * grad
+        iter_dict["grad"] = self._grad_entry(grad)
         return X, iter_dict
 
-    def _grad_entry(self, g):
-        return g.detach() if self.iter_dict_device is None else g.detach().to(self.iter_dict_device)
+    # ---------------------------------------------------------------------------------------------------
+    # loop
+    # ---------------------------------------------------------------------------------------------------
+    def _make_optimizer(self, X, opt_state: Optional[dict]):
+        if self.optimizer_class is None:
+            return None
+        optimizer = self.optimizer_class(params=[X], **self.opt_args)
+        if opt_state is not None:
+            optimizer.load_state_dict(opt_state)
+        return optimizer
 
-    # -- loop -----------------------------------------------------------------------------------
-    def optimize(
-        self,
-        particles: torch.Tensor,
-        score_estimator: Callable = None,
-        opt_state: dict = None,
-        n_steps: int = 100,
-        debug: bool = False,
-        callback_func=None,
-        **kwargs,
-    ) -> tuple:
+    def optimize(self, particles: torch.Tensor, score_estimator: Callable = None, opt_state: dict = None,
+                 n_steps: int = 100, debug: bool = False, callback_func=None, **kwargs) -> tuple:
         X = particles.detach()
-        if self.optimizer_class is not None:
-            optimizer = self.optimizer_class(params=[X], **self.opt_args)
-            if opt_state is not None:
-                optimizer.load_state_dict(opt_state)
-        else:
-            optimizer = None
-        grad_log_p = None
-        data_dict = {}
+        optimizer = self._make_optimizer(X, opt_state)
         if debug:
             from tqdm import trange
 
-            iterator = trange(n_steps, position=0, leave=True)
+            steps = trange(n_steps, position=0, leave=True)
         else:
-            iterator = range(n_steps)
+            steps = range(n_steps)
 
-        trace = torch.empty((n_steps + 1,) + tuple(X.shape), dtype=X.dtype, device=X.device)
+        trace = torch.empty((n_steps + 1, *X.shape), dtype=X.dtype, device=X.device)
         trace[0] = X
-        for i in iterator:
+        data_dict, grad_log_p = {}, None
+        for i in steps:
             if score_estimator is not None:
                 X.requires_grad_(True)
                 grad_log_p, score_dict = score_estimator(X)
@@ -196,10 +194,9 @@ class SVGD:
             X, data_dict[i] = self.step(X, grad_log_p, optimizer, **kwargs)
             trace[i + 1] = X.detach()
             if debug:
-                iterator.set_postfix(loss=data_dict[i]["loss"].norm(), refresh=False)
+                steps.set_postfix(loss=data_dict[i]["loss"].norm(), refresh=False)
             if callback_func is not None:
                 callback_func(X)
         data_dict["trace"] = trace.cpu()
-        particles[:] = X.detach()  # assign last X value to the input, in place
-        opt_state = optimizer.state_dict() if optimizer is not None else None
-        return data_dict, opt_state
+        particles[:] = X.detach()  # the reference hands the result back through its input, in place
+        return data_dict, (optimizer.state_dict() if optimizer is not None else None)

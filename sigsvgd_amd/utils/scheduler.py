@@ -1,5 +1,10 @@
-"""Scalar schedules multiplying the repulsive term grad_k (reference src/utils/scheduler.py:4,25,50;
-used at src/inference/score.py:72).  Each call returns the current value and advances the epoch."""
+"""Scalar schedules that multiply the repulsive term grad_k (reference API: src/utils/scheduler.py:4,25,50,
+consumed at src/inference/score.py:72).  A schedule is a callable; every call returns the value for the
+current epoch and, unless `update_epoch=False`, moves on to the next one.
+
+All three share one stepping mechanism (`_Schedule`) and differ only in `value_at(epoch)`; attribute names
+(`param`, `last_epoch`, ...) follow the reference because user code reads and resets them.
+"""
 from __future__ import annotations
 
 import math
@@ -7,57 +12,57 @@ import math
 import torch
 
 
-class SquareRootScheduler:
-    r"""rho_t = rho_0 (t+1)^{-1/2}."""
+class _Schedule:
+    """Epoch counter + call protocol; subclasses provide value_at(epoch) -> 0-dim tensor."""
 
     def __init__(self, parameter):
         self.param = torch.as_tensor(parameter)
         self.last_epoch = 0
 
-    def __call__(self, update_epoch=True):
-        val = self.param * (self.last_epoch + 1) ** -0.5
-        if update_epoch:
-            self.last_epoch += 1
-        return val
+    def value_at(self, epoch: int) -> torch.Tensor:  # pragma: no cover - abstract
+        raise NotImplementedError
+
+    def __call__(self, update_epoch: bool = True) -> torch.Tensor:
+        epoch = self.last_epoch
+        self.last_epoch = epoch + (1 if update_epoch else 0)
+        return self.value_at(epoch)
 
 
-class FactorScheduler:
+class SquareRootScheduler(_Schedule):
+    r"""rho_t = rho_0 / sqrt(t + 1)."""
+
+    def value_at(self, epoch):
+        return self.param * (epoch + 1) ** -0.5
+
+
+class FactorScheduler(_Schedule):
     r"""rho_t = max(rho_min, rho_0 * gamma^t)."""
 
     def __init__(self, parameter, gamma, parameter_min=1e-7):
-        self.param = torch.as_tensor(parameter)
+        super().__init__(parameter)
         self.gamma = gamma
         self.param_min = torch.as_tensor(parameter_min)
-        self.last_epoch = 0
 
-    def __call__(self, update_epoch=True):
-        val = torch.max(self.param_min, self.param * self.gamma**self.last_epoch)
-        if update_epoch:
-            self.last_epoch += 1
-        return val
+    def value_at(self, epoch):
+        return torch.max(self.param_min, self.param * self.gamma**epoch)
 
 
-class CosineScheduler:
-    r"""Constant until `warmup_steps`, then rho_T + (rho_0-rho_T)/2 (1 + cos(pi (t - warmup)/T))
-    while t <= T = final_epoch, then rho_T.  (The denominator is final_epoch, as in the reference.)"""
+class CosineScheduler(_Schedule):
+    r"""rho_0 while t <= warmup_steps; rho_T after final_epoch; in between the half-cosine
+    rho_T + (rho_0 - rho_T)/2 * (1 + cos(pi (t - warmup_steps) / final_epoch)) -- the phase is divided by
+    final_epoch, not by the length of the decay window, as in the reference."""
 
     def __init__(self, parameter, target_paremeter, final_epoch, warmup_steps=0):
-        self.param = torch.as_tensor(parameter)
-        self.target = torch.as_tensor(target_paremeter)
+        super().__init__(parameter)
+        self.target = torch.as_tensor(target_paremeter)  # (the keyword keeps the reference's spelling)
         self.final_epoch = final_epoch
         self.warmup = warmup_steps
-        self.last_epoch = 0
         self.pi = torch.tensor(math.pi)
 
-    def __call__(self, update_epoch=True):
-        t = self.last_epoch
-        if t <= self.warmup:
-            val = self.param
-        elif t <= self.final_epoch:
-            phase = torch.cos(self.pi * (t - self.warmup) / self.final_epoch)
-            val = self.target + (self.param - self.target) / 2 * (1 + phase)
-        else:
-            val = self.target
-        if update_epoch:
-            self.last_epoch += 1
-        return val
+    def value_at(self, epoch):
+        if epoch <= self.warmup:
+            return self.param
+        if epoch > self.final_epoch:
+            return self.target
+        swing = 1 + torch.cos(self.pi * (epoch - self.warmup) / self.final_epoch)
+        return self.target + (self.param - self.target) / 2 * swing
