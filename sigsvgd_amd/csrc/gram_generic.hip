@@ -6,6 +6,10 @@
 // forward solution is parked in a per-workgroup HBM scratch in [step][lane] order (coalesced
 // 256-B rows, written and re-read by the same wavefront, so it stays in L2).
 //
+// With Y == X and enough pairs to fill the chip (>= 4096) each unordered pair is solved once: K is mirrored and
+// the pair's gradient with respect to x_j comes from a second contraction of the same coarse scatter, added
+// through an fp64 accumulation buffer; work items are then pulled from a counter.
+//
 // This is the coverage kernel (reference call sites use T=3..30 with n=2..6); the
 // headline shapes (n=0, T<=64) take the register-resident kernel in gram_fast.hip.
 //
@@ -19,7 +23,11 @@ struct GenericArgs {
     const void *X, *Y, *grad_out;
     void *K_out;
     double *partials; // [A][nchunks][T*d]
+    double *colacc;   // [B][T*d] column-side gradients of the symmetric solve (yx), zeroed by the launcher
     float *wsk;       // [grid][nbands*nsteps*64]
+    int yx;           // Y is X: solve the pairs j >= i only, mirror K, add d k(x_j, x_i)/d x_j through colacc
+    unsigned long long *next_item; // work counter (zeroed by the launcher): items are pulled, not assigned, because
+                                   // with yx their cost varies from nothing to JC pairs
     int A, B, T, d, dp, n, r, P, Tm, TmS, nbands, nsteps, JC, nchunks, kind, naive, sym, want_grad;
     int big; // long paths (dyadic order 0 only): S kept in fp32 (one write per entry), no LDS gradient accumulator
     double inv_h, inv_r2;
@@ -64,12 +72,22 @@ __global__ __launch_bounds__(64) void gram_generic_kernel(GenericArgs a)
     IO *Kout = static_cast<IO *>(a.K_out);
     float *wsk = a.wsk + (size_t)blockIdx.x * a.wsk_per_block;
 
-    for (long long item = blockIdx.x; item < a.total_items; item += gridDim.x) {
+    for (long long round = 0;; ++round) {
+        long long item;
+        if (a.next_item) { // symmetric solve: item costs vary from nothing to JC pairs -> pull from a counter
+            unsigned long long pulled = 0;
+            if (lane == 0) pulled = atomicAdd(a.next_item, 1ull);
+            item = (long long)__shfl(pulled, 0, kWave);
+        } else {
+            item = (long long)blockIdx.x + round * gridDim.x;
+        }
+        if (item >= a.total_items) break;
         const int i = (int)(item / a.nchunks);
         const int chunk = (int)(item % a.nchunks);
         const int j0 = chunk * a.JC;
         const int j1 = min(a.B, j0 + a.JC);
         const IO *xi = X + (size_t)i * T * d;
+        const bool empty = a.yx && j1 <= i; // chunk entirely left of the diagonal: solved from the other side
 
         double *slab = a.want_grad ? a.partials + ((size_t)i * a.nchunks + chunk) * T * d : nullptr;
         if (a.want_grad && big)
@@ -90,7 +108,8 @@ __global__ __launch_bounds__(64) void gram_generic_kernel(GenericArgs a)
             xn[t] = s;
         }
 
-        for (int j = j0; j < j1; ++j) {
+        for (int j = empty ? j1 : j0; j < j1; ++j) {
+            if (a.yx && j < i) continue; // (one wavefront per workgroup: uniform)
             const IO *yj = Y + (size_t)j * T * d;
             __syncthreads();
             for (int e = lane; e < T * dp; e += kWave) {
@@ -152,7 +171,10 @@ __global__ __launch_bounds__(64) void gram_generic_kernel(GenericArgs a)
                 }
                 if (p == P - 1) Kval = cur;
             }
-            if (((P - 1) & (kWave - 1)) == lane) Kout[(size_t)i * a.B + j] = (IO)Kval;
+            if (((P - 1) & (kWave - 1)) == lane) {
+                Kout[(size_t)i * a.B + j] = (IO)Kval;
+                if (a.yx && j != i) Kout[(size_t)j * a.B + i] = (IO)Kval;
+            }
 
             if (!a.want_grad) continue;
             __syncthreads();
@@ -236,6 +258,49 @@ __global__ __launch_bounds__(64) void gram_generic_kernel(GenericArgs a)
                     }
                 }
             }
+            // ---- phase 4b (Y is X, j != i): the same pair seen from x_j, d k(x_j, x_i) / d x_j ---------
+            if (a.yx && j != i) {
+                double wc = 1.0;
+                if (GO) {
+                    wc = (double)GO[(size_t)j * a.B + i];
+                    if (a.sym) wc += (double)GO[(size_t)i * a.B + j];
+                } else if (a.sym) {
+                    wc = 2.0;
+                }
+                auto Sat = [&](int aa, int bb) { return big ? (double)Sm32[aa * Tm + bb] : Sm[aa * Tm + bb]; };
+                for (int nn = lane; nn < T; nn += kWave) {
+                    for (int c0 = 0; c0 < d; c0 += 16) {
+                        double accv[16];
+#pragma unroll
+                        for (int c = 0; c < 16; ++c) accv[c] = 0.0;
+                        double s0 = 0.0;
+                        for (int m = 0; m < T; ++m) {
+                            double R = 0.0;
+                            if (m >= 1 && nn >= 1) R += Sat(m - 1, nn - 1);
+                            if (m < Tm && nn < Tm) R += Sat(m, nn);
+                            if (m >= 1 && nn < Tm) R -= Sat(m - 1, nn);
+                            if (m < Tm && nn >= 1) R -= Sat(m, nn - 1);
+                            double rg = R;
+                            if (rbf) {
+                                double dot = 0.0;
+                                for (int c = 0; c < d; ++c) dot = __builtin_fma(xs[m * dp + c], ys[nn * dp + c], dot);
+                                rg = R * exp64((2.0 * dot - xn[m] - yn[nn]) * a.inv_h);
+                                s0 += rg;
+                            }
+#pragma unroll
+                            for (int c = 0; c < 16; ++c)
+                                if (c0 + c < d) accv[c] = __builtin_fma(rg, xs[m * dp + c0 + c], accv[c]);
+                        }
+#pragma unroll
+                        for (int c = 0; c < 16; ++c) {
+                            if (c0 + c < d) {
+                                const double val = rbf ? (-2.0 * a.inv_h) * (ys[nn * dp + c0 + c] * s0 - accv[c]) : accv[c];
+                                unsafeAtomicAdd(&a.colacc[((size_t)j * T + nn) * d + c0 + c], wc * val);
+                            }
+                        }
+                    }
+                }
+            }
         } // j
 
         if (a.want_grad && !big) {
@@ -247,12 +312,13 @@ __global__ __launch_bounds__(64) void gram_generic_kernel(GenericArgs a)
 
 // gradX[i][e] = sum_chunk partials[i][chunk][e]  (fixed order => deterministic)
 template <typename IO>
-__global__ void reduce_partials_kernel(const double *partials, IO *gradX, int A, int nchunks, int TD)
+__global__ void reduce_partials_kernel(const double *partials, const double *colacc, IO *gradX, int A, int nchunks,
+                                       int TD)
 {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)A * TD) return;
     const size_t i = idx / TD, e = idx % TD;
-    double s = 0.0;
+    double s = colacc ? colacc[idx] : 0.0;
     for (int c = 0; c < nchunks; ++c) s += partials[(i * nchunks + c) * TD + e];
     gradX[idx] = (IO)s;
 }
@@ -261,10 +327,10 @@ namespace {
 struct GenericPlan {
     int dp, Tm, TmS, r, P, nbands, nsteps, JC, nchunks, grid, big;
     long long items;
-    size_t lds, partial_bytes, wsk_per_block, wsk_bytes;
+    size_t lds, partial_bytes, col_bytes, wsk_per_block, wsk_bytes;
 };
 
-int make_plan(int A, int B, int T, int d, int n, int want_grad, GenericPlan &pl)
+int make_plan(int A, int B, int T, int d, int n, int want_grad, GenericPlan &pl, bool yx = false)
 {
     if (A < 1 || B < 1 || T < 2 || d < 1 || n < 0 || n > 10) {
         set_error("generic: bad shape A=%d B=%d T=%d d=%d n=%d", A, B, T, d, n);
@@ -294,7 +360,7 @@ int make_plan(int A, int B, int T, int d, int n, int want_grad, GenericPlan &pl)
     }
     // j-chunk: enough work items to fill the chip, few enough partial slabs
     int JC = 32;
-    while (JC > 1 && (long long)A * ((B + JC - 1) / JC) < 2048) JC >>= 1;
+    while (JC > 1 && (long long)A * ((B + JC - 1) / JC) < (yx ? 16384 : 2048)) JC >>= 1; // yx: half the items are empty
     pl.JC = JC;
     pl.nchunks = (B + JC - 1) / JC;
     pl.items = (long long)A * pl.nchunks;
@@ -303,29 +369,44 @@ int make_plan(int A, int B, int T, int d, int n, int want_grad, GenericPlan &pl)
     if ((long long)grid > pl.items) grid = (int)pl.items;
     pl.grid = grid;
     pl.partial_bytes = want_grad ? (size_t)A * pl.nchunks * T * d * sizeof(double) : 0;
+    pl.col_bytes = want_grad ? (((size_t)B * T * d * sizeof(double) + 255) & ~(size_t)255) : 0; // symmetric solve only
     pl.wsk_per_block = want_grad ? (size_t)pl.nbands * pl.nsteps * kWave : 0;
     pl.wsk_bytes = pl.wsk_per_block * sizeof(float) * grid;
     return SIGSVGD_OK;
 }
 } // namespace
 
+namespace {
+inline size_t plan_bytes(const GenericPlan &pl) { return 512 + pl.partial_bytes + pl.col_bytes + pl.wsk_bytes; }
+}
+
 int generic_workspace_bytes(int A, int B, int T, int d, int n, int want_grad, size_t *bytes)
 {
+    // the query carries no flags: size for whichever of the ordered / symmetric plans needs more (the symmetric
+    // one uses shorter column chunks, i.e. more partial slabs)
     GenericPlan pl;
-    int rc = make_plan(A, B, T, d, n, want_grad, pl);
+    int rc = make_plan(A, B, T, d, n, want_grad, pl, false);
     if (rc) return rc;
-    *bytes = pl.partial_bytes + pl.wsk_bytes + 256;
+    *bytes = plan_bytes(pl);
+    if (A == B) {
+        rc = make_plan(A, B, T, d, n, want_grad, pl, true);
+        if (rc) return rc;
+        if (plan_bytes(pl) > *bytes) *bytes = plan_bytes(pl);
+    }
     return SIGSVGD_OK;
 }
 
 int generic_launch(const GramProblem &p)
 {
     const int want_grad = p.gradX_out != nullptr;
+    // Y is X: each unordered pair once -- when there are enough pairs to fill the chip; below that the launch is
+    // latency-bound and the second contraction pass of the symmetric solve only lengthens the critical path
+    const bool yx = (p.flags & SIGSVGD_FLAG_Y_IS_X) && p.A == p.B && (long long)p.A * p.B >= 4096;
     GenericPlan pl;
-    int rc = make_plan(p.A, p.B, p.T, p.d, p.n, want_grad, pl);
+    int rc = make_plan(p.A, p.B, p.T, p.d, p.n, want_grad, pl, yx);
     if (rc) return rc;
-    const size_t need = pl.partial_bytes + pl.wsk_bytes + 256;
-    if (want_grad && (p.ws == nullptr || p.ws_bytes < need)) {
+    const size_t need = plan_bytes(pl);
+    if (p.ws == nullptr || p.ws_bytes < need) {
         set_error("generic: workspace %zu B < required %zu B", p.ws_bytes, need);
         return SIGSVGD_E_WORKSPACE;
     }
@@ -336,9 +417,23 @@ int generic_launch(const GramProblem &p)
     }
     GenericArgs a;
     a.X = p.X; a.Y = p.Y; a.grad_out = p.grad_out; a.K_out = p.K_out;
-    unsigned char *base = static_cast<unsigned char *>(p.ws);
-    a.partials = want_grad ? reinterpret_cast<double *>((reinterpret_cast<uintptr_t>(base) + 255) & ~(uintptr_t)255) : nullptr;
-    a.wsk = want_grad ? reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(a.partials) + pl.partial_bytes) : nullptr;
+    unsigned char *base = reinterpret_cast<unsigned char *>((reinterpret_cast<uintptr_t>(p.ws) + 255) & ~(uintptr_t)255);
+    a.next_item = nullptr;
+    if (yx) {
+        a.next_item = reinterpret_cast<unsigned long long *>(base);
+        hipError_t ce = hipMemsetAsync(a.next_item, 0, sizeof(unsigned long long), p.stream);
+        if (ce != hipSuccess) return hip_fail(ce, "hipMemsetAsync(work counter)");
+    }
+    a.partials = want_grad ? reinterpret_cast<double *>(base + 256) : nullptr;
+    a.yx = yx ? 1 : 0;
+    a.colacc = nullptr;
+    unsigned char *after = want_grad ? reinterpret_cast<unsigned char *>(a.partials) + pl.partial_bytes : nullptr;
+    if (want_grad && yx) {
+        a.colacc = reinterpret_cast<double *>(after);
+        hipError_t me = hipMemsetAsync(a.colacc, 0, (size_t)p.B * p.T * p.d * sizeof(double), p.stream);
+        if (me != hipSuccess) return hip_fail(me, "hipMemsetAsync(colacc)");
+    }
+    a.wsk = want_grad ? reinterpret_cast<float *>(after + pl.col_bytes) : nullptr;
     a.A = p.A; a.B = p.B; a.T = p.T; a.d = p.d; a.dp = pl.dp; a.n = p.n; a.r = pl.r; a.P = pl.P;
     a.Tm = pl.Tm; a.TmS = pl.TmS; a.nbands = pl.nbands; a.nsteps = pl.nsteps; a.JC = pl.JC;
     a.nchunks = pl.nchunks; a.kind = p.kind; a.naive = (p.flags & SIGSVGD_FLAG_NAIVE_SOLVER) ? 1 : 0;
@@ -367,10 +462,12 @@ int generic_launch(const GramProblem &p)
         const unsigned gs = (unsigned)((tot + bs - 1) / bs);
         if (p.dtype == SIGSVGD_F64)
             hipLaunchKernelGGL(reduce_partials_kernel<double>, dim3(gs), dim3(bs), 0, p.stream, a.partials,
-                               static_cast<double *>(p.gradX_out), p.A, pl.nchunks, TD);
+                               static_cast<const double *>(a.colacc), static_cast<double *>(p.gradX_out), p.A,
+                               pl.nchunks, TD);
         else
             hipLaunchKernelGGL(reduce_partials_kernel<float>, dim3(gs), dim3(bs), 0, p.stream, a.partials,
-                               static_cast<float *>(p.gradX_out), p.A, pl.nchunks, TD);
+                               static_cast<const double *>(a.colacc), static_cast<float *>(p.gradX_out), p.A,
+                               pl.nchunks, TD);
         e = hipGetLastError();
         if (e != hipSuccess) return hip_fail(e, "launch reduce_partials_kernel");
     }

@@ -3,6 +3,7 @@ import numpy as np
 import pytest
 import torch
 
+from oracle import c_oracle as C
 from oracle import sigkernel_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -79,3 +80,29 @@ def test_phi(gpu):
         assert _rel(Xn.cpu().numpy(), X - 0.1 * vref) < TOL
         v2 = ops.svgd_phi(*(torch.as_tensor(t, device=gpu) for t in (K, s, gk)))
         assert _rel(v2.cpu().numpy(), O.svgd_velocity(K, s, gk)) < TOL
+
+
+@pytest.mark.parametrize("N,T,d,n,kind", [(70, 10, 2, 4, 0), (66, 20, 2, 2, 0), (64, 5, 3, 5, 0), (65, 30, 2, 2, 0), (67, 12, 3, 1, 1),
+                                          (64, 128, 14, 0, 0), (9, 10, 2, 3, 0)])
+@pytest.mark.parametrize("weights", ["ones", "random", "sym"])
+def test_generic_symmetric_solve(gpu, N, T, d, n, kind, weights):
+    """Y is X on the coverage kernel: pairs j >= i only, K mirrored, column-side gradient through the fp64
+    accumulation buffer -- must equal the ordered-pair result of the oracle (also with asymmetric weights)."""
+    from sigsvgd_amd import ops
+
+    rng = np.random.default_rng(N * 100 + T)
+    X = np.cumsum(0.1 * rng.standard_normal((N, T, d)), axis=1).astype(np.float32)
+    h = 1.3
+    go = None if weights == "ones" else rng.uniform(0.5, 1.5, (N, N)).astype(np.float32)
+    sym = weights == "sym"
+    w = None if go is None else (go + go.T if sym else go).astype(np.float64)
+    if go is None and sym:
+        w = np.full((N, N), 2.0)
+    Kref, gref = C.gram_fwd_bwd(X, X, h, n, kind=kind, grad_out=w)
+    Xg = torch.as_tensor(X, device=gpu)
+    gog = None if go is None else torch.as_tensor(go, device=gpu)
+    K, g = ops.gram_fwd_bwd(Xg, Xg, 1.0 / h, n, static_kind=kind, grad_out=gog, sym=sym, y_is_x=True, force_generic=True)
+    assert torch.equal(K, K.T)
+    assert _rel(K.cpu().numpy(), Kref) < TOL and _rel(g.cpu().numpy(), gref) < TOL
+    Kf = ops.gram_fwd(Xg, Xg, 1.0 / h, n, static_kind=kind, force_generic=True, y_is_x=True)
+    assert _rel(Kf.cpu().numpy(), Kref) < TOL
