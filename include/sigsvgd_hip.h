@@ -81,7 +81,9 @@ extern "C" {
 int sigsvgd_abi_version(void);
 const char *sigsvgd_last_error(void);
 
-/* Bytes of scratch the two Gram entry points need for this problem (0 is possible).
+/* Bytes of scratch the two Gram entry points need for this problem.  Forward-only launches need some too
+ * (work queues / counters of the persistent grids), so always query; the size covers every value of
+ * SIGSVGD_FLAG_Y_IS_X / SIGSVGD_FLAG_SYM for the given shape.
  * want_grad = 0 for sigsvgd_gram_fwd, 1 for sigsvgd_gram_fwd_bwd.  Returns 0 and sets *bytes. */
 int sigsvgd_gram_workspace_bytes(int A, int B, int T, int d, int dyadic_order, int want_grad,
                                  unsigned flags, size_t *bytes);
