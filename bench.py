@@ -3,24 +3,30 @@
 (BASELINE.json metric; config C4 of SURVEY.md §8) on 1..8 MI355X.
 
 One step = one pass of the hot path over the (device-resident) particle batch:
-    K = Gram(X, X), grad_k = d sum(K)/dX           HIP: gram_fast_kernel (+ memset, finalize)
+    K = Gram(X, X), grad_k = d sum(K)/dX           HIP: gram_fast_kernel (+ finalize)
     X <- X - lr * v,  v = -((K @ score - grad_k)/N)  HIP: svgd_phi_kernel (fp32 MFMA + fused update)
 K and grad_k are materialised in HBM every step (they are API outputs of the reference's
 `SVGD.step`); nothing is copied to the host inside the timed region.
 
 N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), particles sharded by rows,
 all-gather of X/score + reduce-scatter of v (sigsvgd_amd/distributed.py).  The problem size is
-fixed, so scaling is "strong".
+fixed, so scaling is "strong".  `python bench.py --gpus N` without a launcher starts the N ranks
+itself (a `torch.distributed.run` child process, started before this process touches the GPU) and
+forwards rank 0's JSON line; under `torch.distributed.run` (WORLD_SIZE set) it is one of the ranks.
 
 Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (dominant kernel,
-HBM bound as BASELINE.json asks, plus the fp64-VALU figure that actually bounds it) and
-`cpu_baseline` (the C/OpenMP oracle timed on this box's host cores on a bounded row sample).
+HBM bound as BASELINE.json asks, plus the fp64-VALU figure that actually bounds it), `cpu_baseline`
+(the C/OpenMP oracle timed on this box's host cores on a bounded row sample) and, for sharded runs,
+`sharded` (per-rank partial-solve / velocity milliseconds, all-gather and reduce-scatter microseconds).
 """
 from __future__ import annotations
 
 import argparse
+import csv
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,11 +34,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-
 N, T, D_CH, H, LR = 1024, 64, 7, 1.0, 1e-3
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VALU_PEAK_TF = 78.6       # vector fp64: 256 CU x 4 SIMD x 16 FMA lanes x 2 x 2.4 GHz
+PROFILES = os.path.join(ROOT, "profiles")
+PMC_TRAFFIC_CSV = os.path.join(PROFILES, "r02_pmc_hbm_traffic.csv")   # written by scripts/pmc_summary.py
+PMC_SQ_CSV = os.path.join(PROFILES, "r02_sq_counters_gram_fast.csv")
 
 
 def algorithmic_bytes(n, t, d):
@@ -53,19 +60,19 @@ def algorithmic_flops(n, t, d, symmetric=True):
 def cpu_baseline(n, t, d, budget_rows=256):
     """C/OpenMP restatement (oracle/sigkernel_c.c) on all host cores, bounded sample: the first
     `budget_rows` rows of the N x N Gram + gradient (ordered pairs, as the reference computes them),
-    scaled by N/rows, plus the dense update."""
-    from oracle import c_oracle as C
-    from oracle import sigkernel_oracle as O
+    scaled by N/rows, plus the dense update.  The only place bench.py touches oracle/."""
+    import numpy as np
 
-    X, score = O.synthetic_inputs(n, t, d)
+    from oracle import c_oracle as C
+    from sigsvgd_amd.utils.synthetic import synthetic_inputs
+
+    X, score = synthetic_inputs(n, t, d)
     Xn = X.numpy()
     C.build()
     C.gram_fwd_bwd(Xn, Xn, H, 0, rows=(0, 8))  # warm-up (thread pool, page faults)
     t0 = time.perf_counter()
     K, g = C.gram_fwd_bwd(Xn, Xn, H, 0, rows=(0, budget_rows))
     dt_rows = time.perf_counter() - t0
-    import numpy as np
-
     Kfull = np.zeros((n, n))
     Kfull[:budget_rows] = K
     gfull = np.zeros((n, t, d))
@@ -86,7 +93,41 @@ def cpu_baseline(n, t, d, budget_rows=256):
     }
 
 
-def main():
+def committed_counters():
+    """HBM-side traffic and vector-issue counters of the dominant kernel, read from the rocprofv3 --pmc
+    summaries committed under profiles/ (own passes of `scripts/one_gram.py`; the CSVs name the kernel
+    instantiation and the git revision they were taken on).  None when a file is absent."""
+    out = {"traffic": None, "valu_issue": None}
+    try:
+        with open(PMC_TRAFFIC_CSV) as f:
+            rows = [r for r in csv.DictReader(f) if "gram_fast_kernel" in r["kernel"]]
+        fetch = [float(r["bytes_per_dispatch"]) for r in rows if r["counter"] == "FETCH_SIZE"]
+        write = [float(r["bytes_per_dispatch"]) for r in rows if r["counter"] == "WRITE_SIZE"]
+        if fetch and write:
+            out["traffic"] = sum(fetch) / len(fetch) + sum(write) / len(write)
+            out["traffic_detail"] = {"fetch_bytes": sum(fetch) / len(fetch), "write_bytes": sum(write) / len(write),
+                                     "kernel": rows[0]["kernel"], "revision": rows[0].get("revision"),
+                                     "source": os.path.relpath(PMC_TRAFFIC_CSV, ROOT)}
+    except (OSError, KeyError, ValueError):
+        pass
+    try:
+        with open(PMC_SQ_CSV) as f:
+            rows = [r for r in csv.DictReader(f) if "gram_fast_kernel" in r["Kernel_Name"]]
+        if rows:
+            avg = lambda k: sum(float(r[k]) for r in rows) / len(rows)
+            out["valu_issue"] = {
+                "vector_insts_per_launch": avg("SQ_INSTS_VALU"),
+                "wave_frac_issuing_valu": avg("SQ_ACTIVE_INST_VALU") / avg("SQ_WAVE_CYCLES"),
+                "wave_frac_parked": avg("SQ_WAIT_ANY") / avg("SQ_WAVE_CYCLES"),
+                "wave_frac_issue_stalled": avg("SQ_WAIT_INST_ANY") / avg("SQ_WAVE_CYCLES"),
+                "kernel": rows[0]["Kernel_Name"], "vgpr_count_field": rows[0].get("VGPR_Count"),
+                "source": os.path.relpath(PMC_SQ_CSV, ROOT)}
+    except (OSError, KeyError, ValueError, ZeroDivisionError):
+        pass
+    return out
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -96,51 +137,102 @@ def main():
     ap.add_argument("--headline-only", action="store_true",
                     help="skip the other configurations and the eager-copy figure (clean per-kernel profiles)")
     ap.add_argument("--force-dist", action="store_true", help="use the sharded path even with one rank (rehearsal)")
-    args = ap.parse_args()
+    ap.add_argument("--rehearse-cpu", action="store_true",
+                    help="TEST ONLY: run the launcher + sharded loop on CPU tensors over gloo with the oracle-backed "
+                         "doubles of tests/helpers.py at a toy size; the line it prints is marked as a rehearsal and "
+                         "is not a measurement")
+    return ap.parse_args(argv)
 
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` outside a launcher: start the N ranks as ONE child process tree
+    (`python -m torch.distributed.run`, rendezvous on 127.0.0.1) and forward their output.  This process has
+    not imported torch.cuda nor made any HIP call, so nothing GPU-initialised is ever exec'ed or forked."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    proc = subprocess.run(cmd, env=env)
+    return proc.returncode
+
+
+def main(argv=None) -> int:
+    args = parse_args(argv)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-    from oracle import sigkernel_oracle as O
-    from sigsvgd_amd import _lib, ops
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
 
-    _lib.load()  # fail loudly if the HIP extension is missing
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
-    X0, score0 = O.synthetic_inputs(N, T, D_CH)
+    import torch
 
-    use_dist = world > 1 or args.force_dist
+    from sigsvgd_amd.utils.synthetic import synthetic_inputs
+
+    rehearse = args.rehearse_cpu
+    n, t, d = (16, 6, 2) if rehearse else (N, T, D_CH)
+    if rehearse:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import helpers as compute  # oracle-backed doubles; TEST ONLY (see --rehearse-cpu)
+
+        dev = torch.device("cpu")
+    else:
+        from sigsvgd_amd import _lib
+        from sigsvgd_amd import ops as compute
+
+        _lib.load()  # fail loudly if the HIP extension is missing
+        dev = torch.device("cuda", local_rank)
+        torch.cuda.set_device(dev)
+    sync = (lambda: None) if rehearse else torch.cuda.synchronize
+    X0, score0 = synthetic_inputs(n, t, d)
+
+    use_dist = world > 1 or args.force_dist or rehearse
+    sharded = None
     if use_dist:
         import torch.distributed as dist
 
         from sigsvgd_amd.distributed import ShardedSigSVGD, shard_rows
 
-        dist.init_process_group(backend="nccl", device_id=dev)
-        r0, r1 = shard_rows(N, rank, world)
+        if rehearse:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+            sharded = ShardedSigSVGD(1.0 / H, LR, partial_fn=compute.gram_sym_partial, phi_fn=compute.svgd_phi,
+                                     rows_fn=compute.gram_fwd_bwd)
+        else:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29541")
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+            sharded = ShardedSigSVGD(1.0 / H, LR)
+        r0, r1 = shard_rows(n, rank, world)
         X = X0[r0:r1].to(dev).contiguous()
         score = score0[r0:r1].to(dev).contiguous()
-        sharded = ShardedSigSVGD(1.0 / H, LR)
 
         def step(Xc):
             return sharded.step(Xc, score)
 
         def barrier():
             dist.barrier()
-            torch.cuda.synchronize()
+            sync()
     else:
         X = X0.to(dev)
         score = score0.to(dev)
 
         def step(Xc):
-            K, gk = ops.gram_fwd_bwd(Xc, Xc, 1.0 / H, 0, y_is_x=True)
-            _, Xn = ops.svgd_phi(K, score, gk, X=Xc, lr=LR)
+            K, gk = compute.gram_fwd_bwd(Xc, Xc, 1.0 / H, 0, y_is_x=True)
+            _, Xn = compute.svgd_phi(K, score, gk, X=Xc, lr=LR)
             return Xn
 
         def barrier():
-            torch.cuda.synchronize()
+            sync()
 
     for _ in range(args.warmup):
         X = step(X)
@@ -153,24 +245,47 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if use_dist:
-        import torch.distributed as dist
-
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     assert torch.isfinite(X).all()
 
+    # ---- sharded runs: where the step's time goes on every rank (outside the timed region) -------------
+    shard_report = None
+    if use_dist:
+        n_prof = 5
+        acc = {}
+        for _ in range(n_prof):
+            X = sharded.step(X, score, profile=True)
+            for k, v in sharded.phase_ms.items():
+                acc[k] = acc.get(k, 0.0) + v / n_prof
+        gathered = [None] * world
+        dist.all_gather_object(gathered, acc)
+        if rank == 0:
+            keys = list(gathered[0].keys())
+            shard_report = {
+                "ranks": world,
+                "rows_per_rank": n // world,
+                "per_rank_ms": {k: [round(g[k], 4) for g in gathered] for k in keys},
+                "all_gather_us_max": round(max(g["all_gather"] for g in gathered) * 1e3, 1),
+                "reduce_scatter_us_max": round(max(g.get("reduce_scatter", 0.0) for g in gathered) * 1e3, 1),
+                "partial_solve_ms_max": round(max(g.get("partial_solve", 0.0) for g in gathered), 4),
+                "payload_bytes": {"all_gather_out": 2 * n * t * d * 4, "reduce_scatter_in": n * t * d * 4},
+                "note": f"mean of {n_prof} instrumented steps after the timed region (events on the launch stream; "
+                        "each instrumented step synchronises)",
+            }
+
     # ---- dominant kernel timed live with HIP events on the launch stream (rank 0, N=1 workload) ----
     roofline = None
-    if rank == 0:
+    if rank == 0 and not rehearse:
         Xe = X0.to(dev)
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
         for _ in range(3):
-            ops.gram_fwd_bwd(Xe, Xe, 1.0 / H, 0, y_is_x=True)
+            compute.gram_fwd_bwd(Xe, Xe, 1.0 / H, 0, y_is_x=True)
         torch.cuda.synchronize()
         for a, b in ev:
             a.record()  # torch's current stream == the stream the library launches on
-            ops.gram_fwd_bwd(Xe, Xe, 1.0 / H, 0, y_is_x=True)
+            compute.gram_fwd_bwd(Xe, Xe, 1.0 / H, 0, y_is_x=True)
             b.record()
         torch.cuda.synchronize()
         ms = sorted(a.elapsed_time(b) for a, b in ev)
@@ -178,27 +293,25 @@ def main():
         by = algorithmic_bytes(N, T, D_CH)
         fl = algorithmic_flops(N, T, D_CH)
         achieved = by / (k_ms * 1e-3) / 1e9
+        pmc = committed_counters()
         roofline = {
             "bound": "hbm",
-            "kernel": "gram_fast_kernel<8,8,grad,sym,d=7> (+3.7 MB memset, finalize cast)",
+            "kernel": "sigsvgd::gram_fast_kernel<8, 8, true, true, true> (DPAD=8, 8 waves, gradient, symmetric, "
+                      "d=DPAD-1) + finalize_grad_kernel",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            # HBM-side bytes per launch from rocprofv3 PMC passes (profiles/r01_pmc_hbm_traffic.csv):
-            # FETCH_SIZE 162 MB + WRITE_SIZE 1260 MB.  Both are the ~29 M fp64 atomics of the column-side
-            # gradient reduction (448 per row tile and column, executed at the memory side and counted
-            # ~43 B written / ~5 B fetched each), not re-reads of inputs; they cost ~1.3 % of kernel time
-            "traffic": 162e6 + 1.26e9,
+            # HBM-side bytes per launch: FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes, read from the
+            # committed summary (null if it is missing); raw counters, 4-8 B/lane accesses (no x2 correction applies)
+            "traffic": pmc["traffic"],
+            "traffic_detail": pmc.get("traffic_detail"),
             "algorithmic_bytes_per_launch": by,
             "avg_launch_ms": k_ms,
             "median_launch_ms": ms[len(ms) // 2],
             "note": "fused pair solves are fp64-VALU/latency bound, not HBM bound (SURVEY.md §8d); "
                     "secondary figure below",
-            # SQ counters of the same kernel (own rocprofv3 --pmc pass, profiles/r01_sq_counters_gram_fast_final.csv):
-            # what actually bounds it is vector-instruction issue
-            "valu_issue": {"vector_pipe_busy_frac": 0.84, "vector_insts_per_launch": 3.45e9,
-                           "source": "profiles/r01_sq_counters_gram_fast_final.csv"},
+            "valu_issue": pmc["valu_issue"],
             "valu_fp64": {
                 "achieved_tflops": fl / (k_ms * 1e-3) / 1e12,
                 "peak_tflops": FP64_VALU_PEAK_TF,
@@ -216,8 +329,8 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(n_e):
-            K, gk = ops.gram_fwd_bwd(Xe2, Xe2, 1.0 / H, 0, y_is_x=True)
-            v, Xe2 = ops.svgd_phi(K, score, gk, X=Xe2, lr=LR)
+            K, gk = compute.gram_fwd_bwd(Xe2, Xe2, 1.0 / H, 0, y_is_x=True)
+            v, Xe2 = compute.svgd_phi(K, score, gk, X=Xe2, lr=LR)
             _ = (K.cpu(), gk.cpu(), v.cpu())
         torch.cuda.synchronize()
         eager = n_e / (time.perf_counter() - t0)
@@ -228,12 +341,12 @@ def main():
         others = {}
         for name, (n_, t_, d_, dy) in {"C1": (16, 20, 2, 2), "C2": (128, 32, 7, 0), "C3": (512, 64, 3, 0),
                                        "C5 path shape, N=256 of 4096": (256, 128, 14, 0)}.items():
-            Xo, so = O.synthetic_inputs(n_, t_, d_)
+            Xo, so = synthetic_inputs(n_, t_, d_)
             Xo, so = Xo.to(dev), so.to(dev)
 
             def it(Xc):
-                K, gk = ops.gram_fwd_bwd(Xc, Xc, 1.0 / H, dy, y_is_x=True, check_regime=False)
-                return ops.svgd_phi(K, so, gk, X=Xc, lr=LR)[1]
+                K, gk = compute.gram_fwd_bwd(Xc, Xc, 1.0 / H, dy, y_is_x=True, check_regime=False)
+                return compute.svgd_phi(K, so, gk, X=Xc, lr=LR)[1]
 
             for _ in range(3):
                 Xo = it(Xo)
@@ -257,30 +370,36 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f64",
+            # arithmetic types on the path: static kernel, increments and both PDE sweeps fp64; stored D / K_fwd / G,
+            # the gradient contraction and the velocity GEMM fp32; reduction over partners fp64; fp32 I/O
+            "dtype": "f64 sweeps + f32 contraction (mixed), f32 I/O",
             "data": "synthetic",
             "config": {
                 "workload": "C4: 7-DoF Panda-shaped particles, N=1024 trajectories x T=64 points x d=7, "
                             "sig-kernel PDE dyadic order 0, RBF h=1, fwd+grad+phi+update, lr=1e-3",
-                "N": N, "T": T, "d": D_CH,
+                "N": n, "T": t, "d": d,
                 "io_dtype": "f32",
-                "parallelism": f"particle-sharded x{world}" if world > 1 else "single GPU",
+                "parallelism": f"particle-sharded x{world}" if use_dist else "single GPU",
                 "host_copies": "none in the timed region (reference-style eager .cpu() of K is opt-in)",
             },
             "eager_cpu_copies_iters_per_sec": eager,
             "other_configs": others,
             "roofline": roofline,
+            "sharded": shard_report,
         }
-        if not args.no_cpu_baseline and world == 1:
+        if rehearse:
+            out["rehearsal"] = ("CPU tensors over gloo with oracle-backed test doubles at a toy size: exercises the "
+                                "launcher and the sharded loop only, NOT a measurement")
+            out["config"]["workload"] = f"rehearsal N={n} T={t} d={d}"
+        if not args.no_cpu_baseline and world == 1 and not rehearse:
             out["cpu_baseline"] = cpu_baseline(N, T, D_CH, args.cpu_rows)
         print(json.dumps(out), flush=True)
 
     if use_dist:
-        import torch.distributed as dist
-
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

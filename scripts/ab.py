@@ -7,5 +7,5 @@ shape = sys.argv[4] if len(sys.argv) > 4 else "c4"
 for r in range(rounds):
     for lib in libs:
         env = dict(os.environ, SIGSVGD_LIB_PATH=os.path.abspath(lib))
-        out = subprocess.run([sys.executable, "scripts/dbgbench.py", shape], env=env, capture_output=True, text=True).stdout
+        out = subprocess.run([sys.executable, "scripts/dev/bench_shapes.py", shape], env=env, capture_output=True, text=True).stdout
         print(os.path.basename(lib), " || ".join(out.strip().splitlines()) if out.strip() else "??", flush=True)

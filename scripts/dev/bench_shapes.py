@@ -1,6 +1,6 @@
 import os, sys, time, torch
 sys.path.insert(0,'.')
-from oracle import sigkernel_oracle as O
+from sigsvgd_amd.utils.synthetic import synthetic_inputs
 from sigsvgd_amd import ops
 dev=torch.device('cuda:0')
 def t(fn,n=5):
@@ -11,5 +11,5 @@ def t(fn,n=5):
 arg=sys.argv[1] if len(sys.argv)>1 else ''
 shapes={'c4':[(1024,64,7)],'c5':[(256,128,14)],'stream':[(256,128,14),(256,100,7),(256,96,3)],'c5big':[(1024,128,14)]}.get(arg,[(1024,64,7),(512,64,3),(128,32,7)])
 for (N,T,d) in shapes:
-    X,s=O.synthetic_inputs(N,T,d); X=X.to(dev)
+    X,s=synthetic_inputs(N,T,d); X=X.to(dev)
     print(f'N={N} T={T} d={d}: sym %.3f ms | ordered %.3f ms | fwd %.3f ms'%(t(lambda: ops.gram_fwd_bwd(X,X,1.0,y_is_x=True)), t(lambda: ops.gram_fwd_bwd(X,X,1.0)), t(lambda: ops.gram_fwd(X,X,1.0))), flush=True)

@@ -1,0 +1,41 @@
+"""Diagnostic build of the library with in-kernel phase stamps (-DSIGSVGD_PHASE_STAMPS): where a wave of
+gram_fast_kernel spends its cycles.  Builds sigsvgd_amd/libsigsvgd_stamps.so (never the product library) and
+runs a few launches; the library prints the split to stderr after each launch.
+usage (on the GPU box): python scripts/dev/phase_stamps.py [N T d]      (build only: --build)"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+OUT = os.path.join(ROOT, "sigsvgd_amd", "libsigsvgd_stamps.so")
+
+
+def build():
+    from sigsvgd_amd import _lib
+
+    cmd = [_lib._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DSIGSVGD_PHASE_STAMPS",
+           "-o", OUT] + [os.path.join(_lib._CSRC, s) for s in _lib.SOURCES]
+    subprocess.run(cmd, check=True)
+
+
+if __name__ == "__main__":
+    if "--build" in sys.argv:
+        build()
+        sys.exit(0)
+    if os.environ.get("SIGSVGD_LIB_PATH") != OUT:
+        if not os.path.exists(OUT):
+            build()
+        env = dict(os.environ, SIGSVGD_LIB_PATH=OUT)
+        sys.exit(subprocess.run([sys.executable] + sys.argv, env=env).returncode)
+    import torch
+
+    from sigsvgd_amd import ops
+    from sigsvgd_amd.utils.synthetic import synthetic_inputs
+
+    n, t, d = (int(v) for v in sys.argv[1:4]) if len(sys.argv) >= 4 else (1024, 64, 7)
+    X, _ = synthetic_inputs(n, t, d)
+    Xg = X.cuda()
+    for _ in range(3):
+        ops.gram_fwd_bwd(Xg, Xg, 1.0, 0, y_is_x=True)
+    torch.cuda.synchronize()

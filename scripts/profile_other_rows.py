@@ -7,13 +7,13 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
-from oracle import sigkernel_oracle as O
+from sigsvgd_amd.utils.synthetic import synthetic_inputs
 from sigsvgd_amd import _lib, ops
 
 dev = torch.device("cuda:0")
-X5, s5 = O.synthetic_inputs(256, 128, 14)
+X5, s5 = synthetic_inputs(256, 128, 14)
 X5, s5 = X5.to(dev), s5.to(dev)
-X1, s1 = O.synthetic_inputs(16, 20, 2)
+X1, s1 = synthetic_inputs(16, 20, 2)
 X1, s1 = X1.to(dev), s1.to(dev)
 g = torch.Generator().manual_seed(0)
 V = torch.randn(1024, 448, generator=g).to(dev)

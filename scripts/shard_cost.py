@@ -1,9 +1,9 @@
 import sys, time, torch
 sys.path.insert(0,'.')
-from oracle import sigkernel_oracle as O
+from sigsvgd_amd.utils.synthetic import synthetic_inputs
 from sigsvgd_amd import ops
 dev=torch.device('cuda:0')
-X,s=O.synthetic_inputs(1024,64,7); X=X.to(dev); s=s.to(dev)
+X,s=synthetic_inputs(1024,64,7); X=X.to(dev); s=s.to(dev)
 def t(fn,n=20):
     for _ in range(3): fn()
     torch.cuda.synchronize(); t0=time.time()

@@ -65,7 +65,31 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
+    _check_dpp_hazards(LIB_PATH)
     return LIB_PATH
+
+
+def _check_dpp_hazards(lib_path: str) -> None:
+    """The kernels' inline-asm DPP moves/adds rely on hipcc's schedule for the 2 wait states after a VALU
+    write of their source (csrc/gram_fast.hip); verify that on the disassembly of what was just built and
+    refuse the library otherwise (scripts/check_dpp_hazards.py)."""
+    import importlib.util
+
+    script = os.path.join(_PKG, "..", "scripts", "check_dpp_hazards.py")
+    if not os.path.exists(script):
+        return
+    spec = importlib.util.spec_from_file_location("check_dpp_hazards", script)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    total, bad = 0, []
+    for text in mod.disassemble(lib_path):
+        n, b = mod.check_disassembly(text)
+        total += n
+        bad += b
+    if bad or total == 0:
+        os.replace(lib_path, lib_path + ".rejected")
+        raise RuntimeError(f"sigsvgd_amd: {len(bad)} DPP data hazards (of {total} DPP instructions) in the library "
+                           f"hipcc produced, e.g. {bad[:2]}; kept as {lib_path}.rejected")
 
 
 def load():

@@ -32,6 +32,9 @@
 // Reference semantics: sigkernel _SigKernelGram.forward/backward [RECALLED, SURVEY.md App. A];
 // static kernel src/kernels/_traj_kernels.py:176-195; callers src/inference/score.py:68-69.
 #include "sig_common.h"
+#ifdef SIGSVGD_PHASE_STAMPS
+#include <cstdio>
+#endif
 
 namespace sigsvgd {
 
@@ -44,7 +47,23 @@ struct FastArgs {
     int owned;                    // number of owned row tiles
     int *queue;                   // [owned] next-chunk counters (zeroed by the launcher)
     double inv_h;
+#ifdef SIGSVGD_PHASE_STAMPS
+    unsigned long long *stamps; // diagnostic build only: [8] shader-clock totals per phase, summed over waves
+#endif
 };
+
+// Diagnostic build (-DSIGSVGD_PHASE_STAMPS, scripts/dev/phase_stamps.py): s_memtime around the phases of a pair,
+// summed per wave in scalar registers and added to a buffer no output depends on.  Compiled out of the product.
+#ifdef SIGSVGD_PHASE_STAMPS
+#define SIG_STAMP(i)                                                         \
+    {                                                                        \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();        \
+        ph_[i] += now_ - tlast_;                                             \
+        tlast_ = now_;                                                       \
+    }
+#else
+#define SIG_STAMP(i)
+#endif
 
 // ---- wave-wide shifts on the DPP path ----------------------------------------------------------
 // wave_shr:1 (0x138): lane l reads lane l-1; wave_shl:1 (0x130): lane l reads lane l+1.
@@ -76,8 +95,13 @@ __device__ __forceinline__ double dpp_shl1_one(double v)
 // Same shifts with the 1.0 boundary kept in a PERSISTENT destination: the lane without a source
 // (0 for shr, 63 for shl) is never written, so once `dst` holds 1.0 there it stays -- no per-step
 // re-initialisation of the DPP `old` operand.  (asm: hipcc would re-materialise `old` every step.)
-// The DPP source is written by the previous step's stencil, tens of instructions earlier, so the
-// 2-wait-state VALU->DPP hazard cannot occur.
+// Hazard note (gfx9: VALU write of a VGPR -> DPP read of it needs 2 wait states; hipcc pads its own
+// instructions, not the inside of an asm statement): the DPP source is the stencil result of the step
+// before, and whether two instructions separate them is hipcc's scheduling decision, not a property of
+// this source.  `scripts/check_dpp_hazards.py` therefore checks every DPP instruction of the built
+// library on its disassembly; `_lib.build()` runs it and refuses a library that violates the rule, and
+// tests/test_dpp_hazards.py runs it again in the CPU suite.  (An `s_nop 1` inside the asm string would
+// also do, at ~5 % of the launch: measured.)
 __device__ __forceinline__ void dpp_shr1_keep(double &dst, double v)
 {
     int dlo = __double2loint(dst), dhi = __double2hiint(dst);
@@ -92,6 +116,15 @@ __device__ __forceinline__ void dpp_shl1_keep(double &dst, double v)
     asm("v_mov_b32_dpp %0, %1 wave_shl:1 row_mask:0xf bank_mask:0xf" : "+v"(dhi) : "v"(__double2hiint(v)));
     dst = __hiloint2double(dhi, dlo);
 }
+// fp32 forms of the persistent-boundary shifts (the PDE sweeps run in fp32, see the kernel header)
+__device__ __forceinline__ void dpp_shr1_keep(float &dst, float v)
+{
+    asm("v_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(dst) : "v"(v));
+}
+__device__ __forceinline__ void dpp_shl1_keep(float &dst, float v)
+{
+    asm("v_mov_b32_dpp %0, %1 wave_shl:1 row_mask:0xf bank_mask:0xf" : "+v"(dst) : "v"(v));
+}
 __device__ __forceinline__ double dpp_shl1_zero(double v)
 {
     return __hiloint2double(dpp_shl1_z(__double2hiint(v)), dpp_shl1_z(__double2loint(v)));
@@ -102,10 +135,7 @@ __device__ __forceinline__ float dpp_rol1(float v)
     return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x134, 0xF, 0xF, false));
 }
 // rotate-and-add in ONE VALU instruction: returns acc[lane+1] + v.  (hipcc does not fold a wave_rol
-// v_mov_b32_dpp into the add.)  hipcc does not pad hazards inside an asm statement: a DPP read needs
-// 2 wait states after a VALU write of the same VGPR.  `acc` is written one sweep step (>30
-// instructions) earlier, except possibly on the first step, when the compiler may materialise the
-// zero initialisation right in front -- the caller issues one `s_nop 1` per step for that.
+// v_mov_b32_dpp into the add.)  `acc` is the shuffled source: same hazard, same build-time check as above.
 __device__ __forceinline__ float add_rol1(float acc, float v)
 {
     float out;
@@ -113,6 +143,94 @@ __device__ __forceinline__ float add_rol1(float acc, float v)
     return out;
 }
 __device__ __forceinline__ float dpp_shr1_zero(float v) { return __int_as_float(dpp_shr1_z(__float_as_int(v))); }
+
+// ---- one step of a PDE sweep, hand-scheduled (fp32 difference form, see phase 2 in the kernel) ------------------
+// Every vector instruction of a step is listed here because three properties of the step are scheduling
+// properties: (1) no scalar instruction inside the sweep -- measured on MI355X (scripts/micro/valu_model.hip) a
+// scalar instruction between vector ones costs the wave ~8 cycles, so the EXEC save/restore hipcc wraps around an
+// `if (active)` body cost as much as three vector instructions per step; inactive lanes are handled with two
+// v_cndmask instead (a zero increment leaves V, hence the row, unchanged; a lane whose row has not started keeps
+// K = 1 on its own because its upper neighbour still holds 1; a finished lane's value is never read again);
+// (2) the compare and the counter update sit between the previous step's write of `cur` and the DPP read of it
+// (2 wait states: the gfx9 VALU-write -> DPP-read hazard, which hipcc does not pad inside asm);
+// (3) the two independent instructions are placed inside the dependent chain dpp -> t -> w -> y -> V -> cur.
+//   cnt: sigma - (first active sigma of this lane), compared unsigned against P (the number of cells per row).
+// Eight steps form ONE asm statement (hipcc pads every asm statement with an `s_nop 0`, an issue slot of its own).
+#define SIG_FWD_STEP(UP, DIAG, G, KSL)                                                        \
+    "v_cmp_gt_u32 vcc, %[P], %[cnt]\n\t"                                                      \
+    "v_add_u32 %[cnt], 1, %[cnt]\n\t"                                                         \
+    "v_mov_b32_dpp %[" UP "], %[cur] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"               \
+    "v_cndmask_b32 %[ge], 0, %[" G "], vcc\n\t"                                               \
+    "v_add_f32 %[t], %[cur], %[" UP "]\n\t"                                                   \
+    "v_mul_f32 %[y], %[r3], %[t]\n\t"                                                         \
+    "v_add_f32 %[t], %[t], %[" DIAG "]\n\t"                                                   \
+    "v_fmac_f32 %[y], %[t], %[ge]\n\t" KSL "v_fmac_f32 %[V], %[ge], %[y]\n\t"                \
+    "v_add_f32 %[cur], %[" UP "], %[V]\n\t"
+#define SIG_FWD_KSL(DIAG, K) "v_cndmask_b32 %[" K "], %[" K "], %[" DIAG "], vcc\n\t"
+#define SIG_REV_STEP(DN, DDIAG, G, K)                                                         \
+    "v_cmp_gt_u32 vcc, %[P], %[cnt]\n\t"                                                      \
+    "v_add_u32 %[cnt], -1, %[cnt]\n\t"                                                        \
+    "v_mov_b32_dpp %[" DN "], %[cur] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"               \
+    "v_cndmask_b32 %[ge], 0, %[" G "], vcc\n\t"                                               \
+    "v_add_f32 %[t], %[cur], %[" DN "]\n\t"                                                   \
+    "v_mul_f32 %[y], %[r3], %[t]\n\t"                                                         \
+    "v_add_f32 %[t], %[t], %[" DDIAG "]\n\t"                                                  \
+    "v_fmac_f32 %[y], %[t], %[ge]\n\t"                                                        \
+    "v_mul_f32 %[sv], %[" K "], %[" DDIAG "]\n\t"                                             \
+    "v_fmac_f32 %[V], %[ge], %[y]\n\t"                                                        \
+    "v_cndmask_b32 %[" K "], %[" K "], %[sv], vcc\n\t"                                        \
+    "v_add_f32 %[cur], %[" DN "], %[V]\n\t"
+
+// steps k0 .. k0+7 of the forward sweep (k0 even): g, ksl point at slots k0..k0+7
+template <bool STORE>
+__device__ __forceinline__ void sweep_fwd8(float &cur, float &upA, float &upB, float &V, const float *g, float *ksl,
+                                           int &cnt, const int P, const float r3)
+{
+    float ge, t, y;
+    if (STORE)
+        asm volatile(SIG_FWD_STEP("upA", "upB", "g0", SIG_FWD_KSL("upB", "k0"))
+                     SIG_FWD_STEP("upB", "upA", "g1", SIG_FWD_KSL("upA", "k1"))
+                     SIG_FWD_STEP("upA", "upB", "g2", SIG_FWD_KSL("upB", "k2"))
+                     SIG_FWD_STEP("upB", "upA", "g3", SIG_FWD_KSL("upA", "k3"))
+                     SIG_FWD_STEP("upA", "upB", "g4", SIG_FWD_KSL("upB", "k4"))
+                     SIG_FWD_STEP("upB", "upA", "g5", SIG_FWD_KSL("upA", "k5"))
+                     SIG_FWD_STEP("upA", "upB", "g6", SIG_FWD_KSL("upB", "k6"))
+                     SIG_FWD_STEP("upB", "upA", "g7", SIG_FWD_KSL("upA", "k7"))
+                     : [cur] "+v"(cur), [upA] "+v"(upA), [upB] "+v"(upB), [V] "+v"(V), [cnt] "+v"(cnt),
+                       [ge] "=&v"(ge), [t] "=&v"(t), [y] "=&v"(y), [k0] "+v"(ksl[0]), [k1] "+v"(ksl[1]),
+                       [k2] "+v"(ksl[2]), [k3] "+v"(ksl[3]), [k4] "+v"(ksl[4]), [k5] "+v"(ksl[5]), [k6] "+v"(ksl[6]),
+                       [k7] "+v"(ksl[7])
+                     : [g0] "v"(g[0]), [g1] "v"(g[1]), [g2] "v"(g[2]), [g3] "v"(g[3]), [g4] "v"(g[4]), [g5] "v"(g[5]),
+                       [g6] "v"(g[6]), [g7] "v"(g[7]), [P] "s"(P), [r3] "s"(r3)
+                     : "vcc");
+    else
+        asm volatile(SIG_FWD_STEP("upA", "upB", "g0", "") SIG_FWD_STEP("upB", "upA", "g1", "")
+                     SIG_FWD_STEP("upA", "upB", "g2", "") SIG_FWD_STEP("upB", "upA", "g3", "")
+                     SIG_FWD_STEP("upA", "upB", "g4", "") SIG_FWD_STEP("upB", "upA", "g5", "")
+                     SIG_FWD_STEP("upA", "upB", "g6", "") SIG_FWD_STEP("upB", "upA", "g7", "")
+                     : [cur] "+v"(cur), [upA] "+v"(upA), [upB] "+v"(upB), [V] "+v"(V), [cnt] "+v"(cnt),
+                       [ge] "=&v"(ge), [t] "=&v"(t), [y] "=&v"(y)
+                     : [g0] "v"(g[0]), [g1] "v"(g[1]), [g2] "v"(g[2]), [g3] "v"(g[3]), [g4] "v"(g[4]), [g5] "v"(g[5]),
+                       [g6] "v"(g[6]), [g7] "v"(g[7]), [P] "s"(P), [r3] "s"(r3)
+                     : "vcc");
+}
+// steps k0+7 .. k0 of the reverse sweep (descending; k0 even): lower neighbour through wave_shl, S = K_fwd * U[l+1][q+1]
+// replaces K_fwd in its slot
+__device__ __forceinline__ void sweep_rev8(float &cur, float &dnA, float &dnB, float &V, const float *g, float *ksl,
+                                           int &cnt, const int P, const float r3)
+{
+    float ge, t, y, sv;
+    asm volatile(SIG_REV_STEP("dnA", "dnB", "g7", "k7") SIG_REV_STEP("dnB", "dnA", "g6", "k6")
+                 SIG_REV_STEP("dnA", "dnB", "g5", "k5") SIG_REV_STEP("dnB", "dnA", "g4", "k4")
+                 SIG_REV_STEP("dnA", "dnB", "g3", "k3") SIG_REV_STEP("dnB", "dnA", "g2", "k2")
+                 SIG_REV_STEP("dnA", "dnB", "g1", "k1") SIG_REV_STEP("dnB", "dnA", "g0", "k0")
+                 : [cur] "+v"(cur), [dnA] "+v"(dnA), [dnB] "+v"(dnB), [V] "+v"(V), [cnt] "+v"(cnt), [ge] "=&v"(ge),
+                   [t] "=&v"(t), [y] "=&v"(y), [sv] "=&v"(sv), [k0] "+v"(ksl[0]), [k1] "+v"(ksl[1]), [k2] "+v"(ksl[2]),
+                   [k3] "+v"(ksl[3]), [k4] "+v"(ksl[4]), [k5] "+v"(ksl[5]), [k6] "+v"(ksl[6]), [k7] "+v"(ksl[7])
+                 : [g0] "v"(g[0]), [g1] "v"(g[1]), [g2] "v"(g[2]), [g3] "v"(g[3]), [g4] "v"(g[4]), [g5] "v"(g[5]),
+                   [g6] "v"(g[6]), [g7] "v"(g[7]), [P] "s"(P), [r3] "s"(r3)
+                 : "vcc");
+}
 
 // [slot][lane] image of G (then R*G) with row stride 65 floats: every in-sweep access is
 // lane*4 + constant (one ds instruction with an immediate offset, nothing to keep in registers),
@@ -169,6 +287,9 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
     // element) only when the workgroup leaves the tile -- ~10x fewer reduction atomics than one flush per
     // chunk, and chunks can be short (fine-grained balance; the 1/G launches of the sharded step stay
     // full).  Symmetric launches enumerate only the chunks that reach the diagonal of the row tile.
+#ifdef SIGSVGD_PHASE_STAMPS
+    unsigned long long ph_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast_ = __builtin_amdgcn_s_memtime();
+#endif
     __shared__ int s_item;
     const int nJ = (a.B + a.JC - 1) / a.JC;
     int i = 0, j0 = 0, j1 = 0;
@@ -176,7 +297,7 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
     const int lane_q = (lane < P) ? lane : 0x40000000; // rows without PDE cells never pass the range test below
     float *Gs = Gs_all + (GRAD ? wave * GS_WAVE : 0);
     const double inv_h = a.inv_h;
-    const float m2h = (float)(-2.0 * inv_h);
+    const float m2h = (float)(-2.0 * inv_h * 3.46410161513775459); // the G image holds G / sqrt(12)
 
     // K_fwd, then S = K_fwd * U, of this lane's row, one slot per anti-diagonal (slot = (column + lane) & 63).
     // Declared (and zeroed) once per kernel: the sweeps write a slot only while its cell is inside the grid, so
@@ -289,8 +410,9 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
         const bool pair_ok = row_ok && (!SYM || j >= i);
         if (j + 1 < j1) stage_load(j + 1); // in flight during the pair
 
-        f32x2 Dsl2[32]; // increments, two slots per register pair: the stencil coefficients of two steps share packed math
+        float Dsl[64]; // increments / sqrt(12) (the scale the difference-form stencil wants), one slot per anti-diagonal
 
+        SIG_STAMP(0)
         if (pair_ok) {
             // ---- phase 0: centre x_i on y_j[0] ----------------------------------------------------
             // x~ pre-scaled so that the exponent argument in base 2 is one fused dot product:
@@ -303,7 +425,9 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
                 xn = __builtin_fma(xc, xc, xn);
                 xs[c] = xc * (-2.0 * nscale);
             }
-            xn *= nscale;
+            // everything downstream of the static kernel works with G / sqrt(12): the increments become
+            // gamma = D / sqrt(12) (stencil below), and the gradient pass multiplies the scale back (m2h)
+            xn = __builtin_fma(xn, nscale, -1.79248125036057809); // - log2(sqrt(12))
 
             // ---- phase 1: G rows (skewed: column (t - lane) & 63 on iteration t) -> D slots --------
             {
@@ -344,62 +468,49 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
                     if (t >= 2) {
                         // lane l+1 holds the same column difference one iteration later
                         const double nb = dpp_shl1_zero(rd);
-                        Dsl2[((t - 2) & 63) >> 1][(t - 2) & 1] = (float)(nb - rdprev);
+                        Dsl[(t - 2) & 63] = (float)(nb - rdprev);
                     }
                     rdprev = rd;
                     __builtin_amdgcn_sched_barrier(0); // one column per scheduling region: bounds live ranges
                 }
             }
 
-            // ---- phase 2: forward sweep, anti-diagonal sigma = 0 .. 2P-2 ---------------------------
+            SIG_STAMP(1)
+            // ---- phase 2: forward sweep, anti-diagonal sigma = 0 .. 2P-2, in fp32 DIFFERENCE FORM ----------
+            // With gamma = g / sqrt(12) the second-order stencil reads
+            //     K11 - K01 = (K10 - K00) + F,   F = gamma * (sqrt(3) * t + gamma * (t + K00)),  t = K10 + K01,
+            // so the lane carries V = K[l+1][q] - K[l][q] along its row (V += F: a lane-local recurrence whose
+            // rounding errors are relative to |V| << |K|) and forms K11 = K01 + V with ONE full-magnitude add
+            // that never feeds back into V.  In fp32 this is within 2e-7 of the fp64 recurrence for K and for
+            // the gradient (scripts/dev/precision_vform.py: 1.5e-7 / 1.9e-7 at the C4 shape, where the plain
+            // fp32 stencil loses 4e-6..2e-5), at 10 fp32-rate instructions per step instead of 12.5, seven of
+            // them fp64-rate (measured cost per SIMD at two waves: fp64 2.4 ns, fp32 1.4 ns, DPP move 1.9 ns).
             {
                 // `up` persists (lane 0 keeps the boundary K[0][.] = 1) in TWO registers used on alternate steps:
                 // the diagonal neighbour K[l][q] of a step is the upper neighbour of the step before, whether or
                 // not this lane was active then (a lane's value is 1.0 until its row starts and frozen after it
                 // ends), so it needs no copy.
-                double cur = 1.0, upA = 1.0, upB = 1.0;
-                f32x2 b2 = {0.f, 0.f}, aa2 = {0.f, 0.f};
+                float cur = 1.f, upA = 1.f, upB = 1.f, V = 0.f;
                 const int smax = 2 * P - 2;
                 for (int rnd = 0; rnd < 2; ++rnd) {
                     if (rnd * 64 > smax) break;
-                    float c12 = 1.0f / 12.0f, chalf = 0.5f;
-                    asm volatile("" : "+s"(c12), "+s"(chalf)); // opaque per round: keeps the stencil coefficients in the loop
+                    float r3 = 1.7320508075688772f;
+                    asm volatile("" : "+s"(r3)); // opaque per round: nothing of the step is round-invariant
+                    int cnt = rnd * 64 - lane_q; // sigma - lane at k = 0 (rows without cells: never < P)
 #pragma unroll
-                    for (int k = 0; k < 64; ++k) {
-                        const int sigma = rnd * 64 + k;
-                        const bool act = (unsigned)(sigma - lane_q) < (unsigned)P;
-                        double &up = (k & 1) ? upB : upA;
-                        const double diag = (k & 1) ? upA : upB;
-                        dpp_shr1_keep(up, cur);
-                        // a = g/2 + g^2/12, b = g^2/12 for steps k and k+1 at once (v_pk_mul/v_pk_fma); c12, chalf are
-                        // per-round opaque constants and (g*c12) comes first so that nothing here is round-invariant
-                        if ((k & 1) == 0) {
-                            const f32x2 g2 = Dsl2[k >> 1];
-                            b2 = g2 * (g2 * f32x2{c12, c12});
-                            aa2 = __builtin_elementwise_fma(g2, f32x2{chalf, chalf}, b2);
-                        }
-                        const float b = b2[k & 1], aa = aa2[k & 1];
-                        const double t = cur + up;
-                        double u = t - diag;
-                        u = __builtin_fma(t, (double)aa, u);
-                        const double nw = __builtin_fma(diag, (double)b, u);
-                        if (act) {
-                            if (GRAD) Ksl[k] = (float)diag; // K[l, q]
-                            cur = nw;
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
+                    for (int k0 = 0; k0 < 64; k0 += 8) // Ksl[k] <- K[l, q]
+                        sweep_fwd8<GRAD>(cur, upA, upB, V, &Dsl[k0], &Ksl[k0], cnt, P, r3);
                 }
                 if (lane == P - 1) { // this lane's last value is K[P, P]
-                    store_any(a.K, (size_t)i * a.B + j, cur, io64);
-                    if (SYM && j != i) store_any(a.K, (size_t)j * a.B + i, cur, io64);
+                    store_any(a.K, (size_t)i * a.B + j, (double)cur, io64);
+                    if (SYM && j != i) store_any(a.K, (size_t)j * a.B + i, (double)cur, io64);
                 }
             }
 
+            SIG_STAMP(2)
             if (GRAD) {
                 // ---- phase 3: reverse sweep (U recurrence; S replaces K_fwd slot by slot) -----------------
-                double cur = 1.0, downA = 1.0, downB = 1.0; // `down` persists (lane 63 keeps U[P][.] = 1), alternating as above
-                f32x2 b2 = {0.f, 0.f}, aa2 = {0.f, 0.f};
+                float cur = 1.f, downA = 1.f, downB = 1.f, V = 0.f; // `down` persists (lane 63 keeps U[P][.] = 1), alternating as above
                 float Sb = 0.f, Sc = 0.f, Nb = 0.f, s0 = 0.f;
                 f32x2 acc[DPAD / 2]; // packed pairs: the contraction runs on v_pk_fma_f32
 #pragma unroll
@@ -464,34 +575,16 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
                     // (keeps the phase-4 LDS addresses out of this loop's invariants: without the pin hipcc
                     //  rearranges the pass that follows and the C4 launch goes from 6.9 to 10.9 ms)
                     asm volatile("" : "+v"(yfrow), "+v"(gsoff));
-                    float c12 = 1.0f / 12.0f, chalf = 0.5f;
-                    asm volatile("" : "+s"(c12), "+s"(chalf));
+                    float r3 = 1.7320508075688772f;
+                    asm volatile("" : "+s"(r3));
+                    int cnt = rnd * 64 + 63 - lane_q;
+                    // same difference form, V = U[l][q] - U[l+1][q] carried towards smaller q; `down` alternates between
+                    // two registers like `up` (the diagonal neighbour U[l+1][q+1] is the lower neighbour one step ago)
 #pragma unroll
-                    for (int kk = 0; kk < 64; ++kk) {
-                        const int k = 63 - kk;
-                        const int sigma = rnd * 64 + k;
-                        const bool act = (unsigned)(sigma - lane_q) < (unsigned)P;
-                        double &down = (kk & 1) ? downB : downA;
-                        const double ddiag = (kk & 1) ? downA : downB; // U[l+1][q+1]: the lower neighbour one step ago
-                        dpp_shl1_keep(down, cur);
-                        if ((k & 1) == 1) { // descending: steps k and k-1 share one packed evaluation
-                            const f32x2 g2 = Dsl2[k >> 1];
-                            b2 = g2 * (g2 * f32x2{c12, c12});
-                            aa2 = __builtin_elementwise_fma(g2, f32x2{chalf, chalf}, b2);
-                        }
-                        const float b = b2[k & 1], aa = aa2[k & 1];
-                        const double t = cur + down;
-                        double u = t - ddiag;
-                        u = __builtin_fma(t, (double)aa, u);
-                        const double nw = __builtin_fma(ddiag, (double)b, u);
-                        if (act) {
-                            Ksl[k] *= (float)ddiag; // S[l,q] = K[l,q] * U[l+1,q+1] replaces K[l,q] in its slot
-                            cur = nw;
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
+                    for (int k0 = 56; k0 >= 0; k0 -= 8) sweep_rev8(cur, downA, downB, V, &Dsl[k0], &Ksl[k0], cnt, P, r3);
                 }
 
+                SIG_STAMP(3)
                 // ---- phase 4: 4-corner scatter R and both contractions, one column per lane and iteration ----
                 // The reverse sweep has only half of its lanes inside the grid at any step, so nothing but the
                 // recurrence is left in it.  Here every lane is busy on every iteration: lane l takes the slots in
@@ -523,6 +616,7 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
                     __builtin_amdgcn_sched_barrier(0);
                 }
 
+                SIG_STAMP(4)
                 // row-side gradient of this pair: -(2/h) * sum_n R G (x~_m - y~_n)
                 float w_ij = 1.f, w_ji = 1.f;
                 if (a.go) {
@@ -553,7 +647,11 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
 #pragma unroll
             for (int c = 0; c < DPAD; ++c) Gs[lane * DPAD + c] = 0.f; // idle wave contributes nothing
         }
+        SIG_STAMP(5)
+#ifndef SIG_EXPERIMENT_NO_PAIR_BARRIER // timing experiment only (results are garbage without it)
         __syncthreads(); // every wave is done with y_j (and has parked its column-side result)
+#endif
+        SIG_STAMP(6)
         if (GRAD && SYM) {
             for (int e = tid; e < 64 * DPAD; e += NT) {
                 const int n = e / DPAD, c = e % DPAD;
@@ -564,7 +662,9 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
             }
         }
         if (j + 1 < j1) stage_store();
+#ifndef SIG_EXPERIMENT_NO_PAIR_BARRIER
         __syncthreads();
+#endif
     }
 
     } // chunks of this row tile
@@ -576,6 +676,11 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
     }
     kq = (kq + 1 == a.owned) ? 0 : kq + 1; // this tile is drained: search on from the next one
     } // row tiles
+#ifdef SIGSVGD_PHASE_STAMPS
+    SIG_STAMP(0)
+    if (lane == 0 && a.stamps)
+        for (int k = 0; k < 8; ++k) atomicAdd(&a.stamps[k], ph_[k]);
+#endif
 }
 
 template <typename IO>
@@ -631,6 +736,14 @@ int launch_variant(const GramProblem &p, FastArgs &a, bool grad, bool sym)
     // the queue lives behind the fp64 accumulation buffer in the caller's workspace
     hipError_t qe = hipMemsetAsync(a.queue, 0, (size_t)owned * sizeof(int), p.stream);
     if (qe != hipSuccess) return hip_fail(qe, "hipMemsetAsync(queue)");
+#ifdef SIGSVGD_PHASE_STAMPS
+    {
+        static unsigned long long *dbg = nullptr;
+        if (!dbg) (void)hipMalloc(&dbg, 8 * sizeof(unsigned long long));
+        (void)hipMemsetAsync(dbg, 0, 8 * sizeof(unsigned long long), p.stream);
+        a.stamps = dbg;
+    }
+#endif
     const long long total = nblocks(JC);
     const long long resident = 256LL * (grad ? 1 : 3); // workgroups the chip holds at once (LDS / VGPR bound)
     dim3 grid((unsigned)(total < resident ? total : resident), 1);
@@ -651,6 +764,21 @@ int launch_variant(const GramProblem &p, FastArgs &a, bool grad, bool sym)
         hipLaunchKernelGGL((gram_fast_kernel<DPAD, NW, true, false, false>), grid, block, 0, p.stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "launch gram_fast_kernel");
+#ifdef SIGSVGD_PHASE_STAMPS
+    {
+        unsigned long long h[8];
+        (void)hipStreamSynchronize(p.stream);
+        (void)hipMemcpy(h, a.stamps, sizeof(h), hipMemcpyDeviceToHost);
+        double tot = 0;
+        for (int k = 0; k < 8; ++k) tot += (double)h[k];
+        static const char *nm[8] = {"queue/staging/other", "phase 0+1 static kernel", "phase 2 forward sweep",
+                                    "phase 3 reverse sweep", "phase 4 gradient pass", "pair epilogue",
+                                    "barrier after the pair", "-"};
+        fprintf(stderr, "[phase stamps] A=%d T=%d d=%d grad=%d sym=%d: ", p.A, p.T, p.d, (int)grad, (int)sym);
+        for (int k = 0; k < 7; ++k) fprintf(stderr, "%s %.1f%% | ", nm[k], 100.0 * (double)h[k] / tot);
+        fprintf(stderr, "total %.3e wave-cycles\n", tot);
+    }
+#endif
     return SIGSVGD_OK;
 }
 } // namespace

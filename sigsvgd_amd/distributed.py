@@ -58,6 +58,35 @@ def reduce_scatter_rows(full: torch.Tensor, group=None) -> torch.Tensor:
     return out
 
 
+class _PhaseClock:
+    """Per-phase timing of one sharded step: HIP events on the current stream (the collectives and the
+    library's launches are all enqueued there), host clocks for CPU tensors (gloo rehearsal)."""
+
+    def __init__(self, device: torch.device):
+        self.gpu = device.type == "cuda"
+        self.names = []
+        self.marks = [self._now()]
+
+    def _now(self):
+        if self.gpu:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            return ev
+        import time
+
+        return time.perf_counter()
+
+    def __call__(self, name: str) -> None:
+        self.names.append(name)
+        self.marks.append(self._now())
+
+    def result(self) -> dict:
+        if self.gpu:
+            torch.cuda.synchronize()
+            return {n: self.marks[k].elapsed_time(self.marks[k + 1]) for k, n in enumerate(self.names)}
+        return {n: (self.marks[k + 1] - self.marks[k]) * 1e3 for k, n in enumerate(self.names)}
+
+
 class ShardedSigSVGD:
     """One SVGD iteration with particles sharded across ranks.
 
@@ -76,21 +105,69 @@ class ShardedSigSVGD:
         self.rowwise = bool(rowwise)
         self.last_K_partial = None
         self.last_K_rows = None
+        self.phase_ms = None  # filled by step(profile=True): milliseconds per phase on this rank
 
-    def step(self, X_shard: torch.Tensor, score_shard: torch.Tensor) -> torch.Tensor:
-        """Returns the updated shard X_shard - lr * v_rows."""
+    def step(self, X_shard: torch.Tensor, score_shard: torch.Tensor, profile: bool = False) -> torch.Tensor:
+        """Returns the updated shard X_shard - lr * v_rows.  profile=True brackets the four phases with
+        events on the current stream (device tensors) or host clocks (CPU rehearsal) and leaves the
+        per-phase milliseconds in `self.phase_ms`; it synchronises, so never use it in a timed loop."""
         rank, world = _world(self.group)
+        mark = _PhaseClock(X_shard.device) if profile else None
         # one collective for both operands: [n, 2, T, d] shards -> [N, 2, T, d]
         both = all_gather_rows(torch.stack((X_shard, score_shard.to(X_shard.dtype)), dim=1), self.group)
         X_full = both[:, 0].contiguous()
         s_full = both[:, 1].contiguous()
+        if mark:
+            mark("all_gather")
         if self.rowwise or not self._partial_supported(X_full):
-            return self._step_rowwise(X_shard, X_full, s_full)
+            out = self._step_rowwise(X_shard, X_full, s_full)
+            if mark:
+                mark("rowwise_solve_and_update")
+                self.phase_ms = mark.result()
+            return out
         Kp, gp = self.partial_fn(X_full, self.inv_h, rank, world)
+        if self._guard_fired(X_full, gp):
+            # the long-path kernel declined some pairs of this input (see _guard_fired): every rank repeats the
+            # step row-wise, where `ops.gram_fwd_bwd` reroutes to the kernel that keeps the forward solution
+            out = self._step_rowwise(X_shard, X_full, s_full)
+            if mark:
+                mark("rowwise_solve_and_update")
+                self.phase_ms = mark.result()
+            return out
+        if mark:
+            mark("partial_solve")
         self.last_K_partial = Kp
         v_part = self.phi_fn(Kp, s_full, gp.to(s_full.dtype))  # -((Kp @ s - gp)/N), linear in (Kp, gp)
+        if mark:
+            mark("velocity")
         v_rows = reduce_scatter_rows(v_part.reshape(X_full.shape), self.group)
-        return X_shard - self.lr * v_rows
+        if mark:
+            mark("reduce_scatter")
+        out = X_shard - self.lr * v_rows
+        if mark:
+            mark("update")
+            self.phase_ms = mark.result()
+        return out
+
+    def _guard_fired(self, X_full, grad_partial) -> bool:
+        """Paths longer than 64 points run on a kernel that may return NaN gradients for pairs it cannot solve
+        to tolerance (`ops.STREAM_GUARDED`; very rough paths).  Ranks must agree on the route, so the flag is
+        max-reduced (one 4-byte collective + one host read-back per step, long paths only)."""
+        if not getattr(ops, "STREAM_GUARDED", False) or X_full.shape[1] <= 64 or not torch.is_tensor(grad_partial):
+            return False
+        flag = torch.isnan(grad_partial).any().to(torch.int32).reshape(1)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+        if not int(flag.item()) or not bool(torch.isfinite(X_full).all()):
+            return False
+        if not ShardedSigSVGD._warned:
+            ShardedSigSVGD._warned = True
+            import warnings
+
+            warnings.warn("sigsvgd_amd: long-path partial solve declined rough pairs; this step runs row-wise on "
+                          "the coverage kernel (slower)", RuntimeWarning)
+        return True
+
+    _warned = False
 
     @staticmethod
     def _partial_supported(X_full) -> bool:

@@ -110,6 +110,7 @@ def gram_fwd(X, Y, inv_h: float, dyadic_order: int = 0, static_kind: int = _lib.
 
 
 STREAM_GMAX = 0.4  # include/sigsvgd_hip.h SIGSVGD_STREAM_GMAX
+STREAM_GUARDED = True  # the 65 <= T <= 128 kernel may return NaN gradients for pairs beyond STREAM_GMAX
 
 
 def _is_streaming_shape(T: int, d: int, dyadic_order: int, static_kind: int, naive: bool) -> bool:

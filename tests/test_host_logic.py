@@ -276,3 +276,16 @@ def test_sigkernel_module_surface():
     assert np.allclose(sk.LinearKernel().batch_kernel(X, X).numpy(), O.static_batch(X.numpy(), X.numpy(), O.LINEAR))
     with pytest.raises(NotImplementedError):
         sk.SigKernel(object(), 1).compute_Gram(X, X)
+
+
+def test_package_synthetic_inputs_match_the_oracle_generator():
+    """bench.py takes its inputs from the package (no dependency on oracle/); both generators must agree bit for bit"""
+    import torch
+
+    from oracle import sigkernel_oracle as O
+    from sigsvgd_amd.utils.synthetic import synthetic_inputs
+
+    for shape in [(16, 20, 2), (8, 64, 7)]:
+        Xa, sa = synthetic_inputs(*shape)
+        Xb, sb = O.synthetic_inputs(*shape)
+        assert torch.equal(Xa, Xb) and torch.equal(sa, sb)
