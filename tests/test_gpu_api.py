@@ -240,6 +240,42 @@ def test_sharded_step_on_rccl_single_rank(gpu):
         dist.destroy_process_group()
 
 
+def test_sharded_step_long_paths_on_rccl(gpu):
+    """T=128, d=14 (the C5 path shape) through the sharded step under nccl, world size 1: the long-path
+    partial solve must equal the single-GPU iteration and the oracle, for the benchmark's smooth paths AND for
+    rough paths (scale 0.15: every particle's pair with itself has increments far beyond what a regenerating
+    solver tolerates) -- no NaN may reach the particles whichever kernel serves the launch."""
+    import os
+    import warnings
+
+    import torch.distributed as dist
+
+    from sigsvgd_amd import ops
+    from sigsvgd_amd.distributed import ShardedSigSVGD
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = "29547"
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=gpu)
+    try:
+        for scale, n in ((0.05, 24), (0.15, 12)):
+            rng = np.random.default_rng(5)
+            X = torch.as_tensor(np.cumsum(scale * rng.standard_normal((n, 128, 14)), axis=1).astype(np.float32))
+            s = torch.as_tensor(rng.standard_normal((n, 128, 14)).astype(np.float32))
+            Xg, sg = X.to(gpu), s.to(gpu)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore", RuntimeWarning)
+                Xa = ShardedSigSVGD(1.0, 1e-3).step(Xg, sg)
+            assert bool(torch.isfinite(Xa).all())
+            K, g = ops.gram_fwd_bwd(Xg, Xg, 1.0, y_is_x=True)
+            assert bool(torch.isfinite(g).all())
+            _, Xb = ops.svgd_phi(K, sg, g, X=Xg, lr=1e-3)
+            assert rel(Xa, Xb.double().cpu().numpy()) < 1e-6
+            ref = O.svgd_iteration(X.numpy(), s.numpy(), h=1.0, n=0, lr=1e-3)
+            assert rel(K, ref["K"]) < TOL and rel(g, ref["grad_k"]) < TOL and rel(Xa, ref["X_new"]) < 1e-6
+    finally:
+        dist.destroy_process_group()
+
+
 def test_sigkernel_paired_distance_mmd(gpu):
     """compute_kernel / compute_distance / compute_mmd of the sigkernel surface vs oracle Gram matrices,
     and the gradient of the MMD w.r.t. its first argument vs the oracle's weighted backward."""

@@ -1,0 +1,102 @@
+"""BASELINE.json configurations at their FULL sizes on the HIP path (one launch each; the small-shape
+parity matrix lives in test_gpu_fast / test_gpu_stream / test_gpu_generic).  What only shows at size:
+the column-chunk selection, the persistent grid's queue scan over hundreds of row tiles, the 1-D
+symmetric enumeration, multi-hundred-MB accumulators, the 8-way tile ownership of the sharded step.
+
+    C2  N=128  T=32  d=7    full oracle compare
+    C3  N=512  T=64  d=3    oracle rows at the start / middle / end, symmetric == ordered
+    C5  N=4096 T=128 d=14   finite, K == K^T, oracle rows (0,2) (2047,2049) (4094,4096),
+                            the 8 `gram_sym_partial` shares sum to the full result
+(C4 at full size: test_gpu_fast.test_fast_c4_rows and test_gpu_api.test_properties_at_benchmark_size.)"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle as C
+from sigsvgd_amd.utils.synthetic import synthetic_inputs
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5  # north_star tolerance: K relative to max|K|, gradients relative to max|grad|
+
+
+def _rel(a, b):
+    a = np.asarray(a, np.float64)
+    return float(np.abs(a - b).max() / np.abs(b).max())
+
+
+def test_c2_full(gpu):
+    from sigsvgd_amd import ops
+
+    X, score = synthetic_inputs(128, 32, 7)
+    Kref, gref = C.gram_fwd_bwd(X.numpy(), X.numpy(), 1.0, 0)
+    Xg = X.to(gpu)
+    K, g = ops.gram_fwd_bwd(Xg, Xg, 1.0, y_is_x=True)
+    K2, g2 = ops.gram_fwd_bwd(Xg, Xg, 1.0)
+    Kn, gn = K.cpu().numpy(), g.cpu().numpy()
+    assert np.isfinite(Kn).all() and np.isfinite(gn).all() and np.array_equal(Kn, Kn.T)
+    assert _rel(Kn, Kref) < TOL and _rel(gn, gref) < TOL
+    assert _rel(K2.cpu().numpy(), Kref) < TOL and _rel(g2.cpu().numpy(), gref) < TOL
+    # one full iteration against the oracle's update
+    v, Xn = ops.svgd_phi(K, score.to(gpu), g, X=Xg, lr=1e-3)
+    vref = -((Kref @ score.numpy().astype(np.float64).reshape(128, -1) - gref.reshape(128, -1)) / 128)
+    assert _rel(v.cpu().numpy().reshape(128, -1), vref) < TOL
+    assert _rel(Xn.cpu().numpy().reshape(128, -1), X.numpy().astype(np.float64).reshape(128, -1) - 1e-3 * vref) < 1e-6
+
+
+def test_c3_full(gpu):
+    from sigsvgd_amd import ops
+
+    X, _ = synthetic_inputs(512, 64, 3)
+    Xg = X.to(gpu)
+    K, g = ops.gram_fwd_bwd(Xg, Xg, 1.0, y_is_x=True)
+    K2, g2 = ops.gram_fwd_bwd(Xg, Xg, 1.0)
+    K3 = ops.gram_fwd(Xg, Xg, 1.0, y_is_x=True)
+    torch.cuda.synchronize()
+    Kn, gn = K.cpu().numpy(), g.cpu().numpy()
+    assert np.isfinite(Kn).all() and np.isfinite(gn).all() and np.array_equal(Kn, Kn.T)
+    assert _rel(K2.cpu().numpy(), Kn.astype(np.float64)) < 1e-6 and _rel(g2.cpu().numpy(), gn.astype(np.float64)) < TOL
+    assert _rel(K3.cpu().numpy(), Kn.astype(np.float64)) < 1e-6
+    for rows in [(0, 4), (254, 258), (508, 512)]:
+        Kref, gref = C.gram_fwd_bwd(X.numpy(), X.numpy(), 1.0, 0, rows=rows)
+        assert _rel(Kn[rows[0]:rows[1]], Kref) < TOL
+        assert np.abs(gn[rows[0]:rows[1]] - gref).max() / np.abs(gref).max() < TOL
+    # the sharded step's ownership at this size: 4 shares
+    Ksum = torch.zeros_like(K, dtype=torch.float64)
+    gsum = torch.zeros_like(g, dtype=torch.float64)
+    for off in range(4):
+        Kp, gp = ops.gram_sym_partial(Xg, 1.0, off, 4)
+        Ksum += Kp.double()
+        gsum += gp
+    assert _rel(Ksum.cpu().numpy(), Kn.astype(np.float64)) < 1e-6 and _rel(gsum.cpu().numpy(), gn.astype(np.float64)) < TOL
+
+
+def test_c5_full(gpu):
+    """N=4096, T=128, d=14 on ONE GPU (the 8-GPU configuration's whole problem): ~2 s of kernel time."""
+    from sigsvgd_amd import ops
+
+    N, T, d = 4096, 128, 14
+    X, _ = synthetic_inputs(N, T, d)
+    Xg = X.to(gpu)
+    K, g = ops.gram_fwd_bwd(Xg, Xg, 1.0, y_is_x=True)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(K).all()) and bool(torch.isfinite(g).all())
+    assert torch.equal(K, K.T)
+    Kn, gn = K.cpu().numpy(), g.cpu().numpy()
+    gmax = None
+    for rows in [(0, 2), (2047, 2049), (4094, 4096)]:
+        Kref, gref = C.gram_fwd_bwd(X.numpy(), X.numpy(), 1.0, 0, rows=rows)
+        assert _rel(Kn[rows[0]:rows[1]], Kref) < TOL
+        gmax = np.abs(gref).max()
+        assert np.abs(gn[rows[0]:rows[1]] - gref).max() / gmax < TOL
+    # the 8 tile-cyclic shares of the sharded step sum to the full launch (K exactly disjoint, gradient to rounding)
+    Ksum = torch.zeros((N, N), dtype=torch.float32, device=gpu)
+    gsum = torch.zeros((N, T, d), dtype=torch.float64, device=gpu)
+    for off in range(8):
+        Kp, gp = ops.gram_sym_partial(Xg, 1.0, off, 8)
+        assert bool(torch.isfinite(Kp).all()) and bool(torch.isfinite(gp).all())
+        Ksum += Kp
+        gsum += gp
+        del Kp, gp
+    assert torch.equal(Ksum, K)
+    assert float((gsum - g.double()).abs().max()) / float(g.abs().max()) < 2e-6
