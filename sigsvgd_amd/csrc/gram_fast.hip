@@ -41,7 +41,8 @@ namespace sigsvgd {
 struct FastArgs {
     const void *X, *Y, *go;
     void *K;
-    double *gacc; // [A][T][d] fp64 accumulation buffer (zeroed by the launcher)
+    double *gacc; // [A][T][d] fp64 accumulation buffer (zeroed by the launcher): row-side sums
+    float *cacc;  // [A][T][d] fp32 buffer for the column-side sums (zeroed by the launcher); NULL: they go to gacc
     int io64, A, B, T, d, JC, symw;
     int tile_offset, tile_stride; // row tiles owned by this launch: offset + k*stride (multi-GPU sharding)
     int owned;                    // number of owned row tiles
@@ -655,10 +656,18 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
         if (GRAD && SYM) {
             for (int e = tid; e < 64 * DPAD; e += NT) {
                 const int n = e / DPAD, c = e % DPAD;
-                double s = 0.0;
+                float s = 0.f;
 #pragma unroll
-                for (int w = 0; w < NW; ++w) s += (double)Gs_all[w * GS_WAVE + e];
-                if (n < T && c < d && s != 0.0) unsafeAtomicAdd(&a.gacc[((size_t)j * T + n) * d + c], s);
+                for (int w = 0; w < NW; ++w) s += Gs_all[w * GS_WAVE + e];
+                if (n < T && c < d && s != 0.f) {
+                    // one fp32 atomic per element and row tile, into a separate fp32 buffer that the finalize kernel
+                    // adds to the fp64 row-side sums (half the bytes of an fp64 atomic at the memory side); the
+                    // sharded partial solve has one caller-owned fp64 buffer for both
+                    if (a.cacc)
+                        unsafeAtomicAdd(&a.cacc[((size_t)j * T + n) * d + c], s);
+                    else
+                        unsafeAtomicAdd(&a.gacc[((size_t)j * T + n) * d + c], (double)s);
+                }
             }
         }
         if (j + 1 < j1) stage_store();
@@ -684,10 +693,10 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
 }
 
 template <typename IO>
-__global__ void finalize_grad_kernel(const double *gacc, IO *gradX, size_t n)
+__global__ void finalize_grad_kernel(const double *gacc, const float *cacc, IO *gradX, size_t n)
 {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < n) gradX[idx] = (IO)gacc[idx];
+    if (idx < n) gradX[idx] = (IO)(gacc[idx] + (double)cacc[idx]);
 }
 
 // ---- host side ---------------------------------------------------------------------------------
@@ -707,7 +716,7 @@ inline size_t queue_bytes(int A) { return ((size_t)(A + 3) / 4 + 1) * sizeof(int
 int fast_workspace_bytes(int A, int B, int T, int d, int want_grad, unsigned flags, size_t *bytes)
 {
     (void)B; (void)flags;
-    *bytes = (want_grad ? (size_t)A * T * d * sizeof(double) + 256 : 0) + queue_bytes(A);
+    *bytes = (want_grad ? (size_t)A * T * d * (sizeof(double) + sizeof(float)) + 256 : 0) + queue_bytes(A);
     return SIGSVGD_OK;
 }
 
@@ -793,13 +802,14 @@ int fast_launch(const GramProblem &p)
     a.symw = (p.flags & SIGSVGD_FLAG_SYM) ? 1 : 0; a.inv_h = p.inv_h; a.JC = 1;
     a.tile_offset = 0; a.tile_stride = 1; a.owned = 1; a.queue = nullptr;
     a.gacc = nullptr;
+    a.cacc = nullptr;
     if (a.symw && p.A != p.B) {
         set_error("sym backward needs A == B");
         return SIGSVGD_E_BADARG;
     }
     const size_t nacc = (size_t)p.A * p.T * p.d;
     {
-        const size_t need = (grad ? nacc * sizeof(double) + 256 : 0) + queue_bytes(p.A);
+        const size_t need = (grad ? nacc * (sizeof(double) + sizeof(float)) + 256 : 0) + queue_bytes(p.A);
         if (!p.ws || p.ws_bytes < need) {
             set_error("fast: workspace %zu B < required %zu B", p.ws_bytes, need);
             return SIGSVGD_E_WORKSPACE;
@@ -807,9 +817,10 @@ int fast_launch(const GramProblem &p)
         unsigned char *base = reinterpret_cast<unsigned char *>((reinterpret_cast<uintptr_t>(p.ws) + 255) & ~(uintptr_t)255);
         if (grad) {
             a.gacc = reinterpret_cast<double *>(base);
-            hipError_t e = hipMemsetAsync(a.gacc, 0, nacc * sizeof(double), p.stream);
+            a.cacc = reinterpret_cast<float *>(base + nacc * sizeof(double));
+            hipError_t e = hipMemsetAsync(a.gacc, 0, nacc * (sizeof(double) + sizeof(float)), p.stream);
             if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(gacc)");
-            base += nacc * sizeof(double);
+            base += nacc * (sizeof(double) + sizeof(float));
         }
         a.queue = reinterpret_cast<int *>(base);
     }
@@ -829,10 +840,10 @@ int fast_launch(const GramProblem &p)
         const int bs = 256;
         const unsigned gs = (unsigned)((nacc + bs - 1) / bs);
         if (p.dtype == SIGSVGD_F64)
-            hipLaunchKernelGGL(finalize_grad_kernel<double>, dim3(gs), dim3(bs), 0, p.stream, a.gacc,
+            hipLaunchKernelGGL(finalize_grad_kernel<double>, dim3(gs), dim3(bs), 0, p.stream, a.gacc, a.cacc,
                                static_cast<double *>(p.gradX_out), nacc);
         else
-            hipLaunchKernelGGL(finalize_grad_kernel<float>, dim3(gs), dim3(bs), 0, p.stream, a.gacc,
+            hipLaunchKernelGGL(finalize_grad_kernel<float>, dim3(gs), dim3(bs), 0, p.stream, a.gacc, a.cacc,
                                static_cast<float *>(p.gradX_out), nacc);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return hip_fail(e, "launch finalize_grad_kernel");
@@ -859,6 +870,7 @@ int fast_sym_partial(const GramProblem &p, int tile_offset, int tile_stride, dou
     a.symw = (p.flags & SIGSVGD_FLAG_SYM) ? 1 : 0; a.inv_h = p.inv_h; a.JC = 1;
     a.tile_offset = tile_offset; a.tile_stride = tile_stride; a.owned = 1;
     a.gacc = grad_partial;
+    a.cacc = nullptr; // one caller-owned fp64 buffer receives both sides
     if (!p.ws || p.ws_bytes < queue_bytes(p.A)) {
         set_error("sym_partial: workspace %zu B < required %zu B", p.ws_bytes, queue_bytes(p.A));
         return SIGSVGD_E_WORKSPACE;
