@@ -654,20 +654,22 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
 #endif
         SIG_STAMP(6)
         if (GRAD && SYM) {
-            for (int e = tid; e < 64 * DPAD; e += NT) {
-                const int n = e / DPAD, c = e % DPAD;
+            // thread e takes element e of the column's [T][d] block, so that the lanes of a wave-instruction address
+            // consecutive dwords (lane -> address is linear: the memory-side atomic unit then merges a wave's adds into
+            // 64-B requests; with the padded [64][DPAD] indexing 7 of 8 lanes were active and every lane was counted
+            // as a request of its own: 48 B written per add in the PMC pass)
+            const float inv_d = 1.0f / (float)d;
+            for (int e = tid; e < T * d; e += NT) {
+                const int n = (int)(((float)e + 0.5f) * inv_d), c = e - n * d; // exact for e < 2^20
                 float s = 0.f;
 #pragma unroll
-                for (int w = 0; w < NW; ++w) s += Gs_all[w * GS_WAVE + e];
-                if (n < T && c < d && s != 0.f) {
-                    // one fp32 atomic per element and row tile, into a separate fp32 buffer that the finalize kernel
-                    // adds to the fp64 row-side sums (half the bytes of an fp64 atomic at the memory side); the
-                    // sharded partial solve has one caller-owned fp64 buffer for both
-                    if (a.cacc)
-                        unsafeAtomicAdd(&a.cacc[((size_t)j * T + n) * d + c], s);
-                    else
-                        unsafeAtomicAdd(&a.gacc[((size_t)j * T + n) * d + c], (double)s);
-                }
+                for (int w = 0; w < NW; ++w) s += Gs_all[w * GS_WAVE + n * DPAD + c];
+                // one fp32 atomic per element and row tile, into a separate fp32 buffer that the finalize kernel
+                // adds to the fp64 row-side sums; the sharded partial solve has one caller-owned fp64 buffer for both
+                if (a.cacc)
+                    unsafeAtomicAdd(&a.cacc[(size_t)j * T * d + e], s);
+                else if (s != 0.f)
+                    unsafeAtomicAdd(&a.gacc[(size_t)j * T * d + e], (double)s);
             }
         }
         if (j + 1 < j1) stage_store();
