@@ -15,6 +15,8 @@
  *                          src/inference/svgd.py:82-83, src/inference/trajectory_svgd.py:84
  *                          optionally fused with the optimizer=None update X - lr*v (svgd.py:115)
  *   sigsvgd_svgd_step      the same with the adaptive_gradient=True scaling fused (svgd.py:110-113)
+ *   sigsvgd_svgd_adam_step the same with the update of the reference's DEFAULT optimizer fused: torch.optim.Adam
+ *                          stepped through a closure that sets X.grad to the velocity (svgd.py:20,100-107)
  *   sigsvgd_vec_sqdist     src/utils/math.py:69-86 pw_dist_sq, :116-144 scaled_pw_dist_sq
  *   sigsvgd_vec_kernel     src/kernels/_kernels.py:64-299 GaussianKernel / ScaledGaussianKernel /
  *                          IMQKernel / ScaledIMQKernel: K and d_K.sum(1) without the [A,B,D] tensor
@@ -42,7 +44,7 @@
 extern "C" {
 #endif
 
-#define SIGSVGD_ABI_VERSION 3
+#define SIGSVGD_ABI_VERSION 4
 
 /* dtype */
 #define SIGSVGD_F32 0
@@ -63,6 +65,13 @@ extern "C" {
 #define SIGSVGD_FLAG_SYM 2u          /* sigkernel sym=True backward weighting: go + go^T (A==B) */
 #define SIGSVGD_FLAG_Y_IS_X 4u       /* caller guarantees Y aliases X (same values): lets the   */
                                      /* library solve each unordered pair once                  */
+#define SIGSVGD_FLAG_WS_CLEAN 16u     /* the caller guarantees that the workspace is ZERO on entry (fresh, or left  */
+                                      /* by an earlier call with this flag); honoured by the register-resident       */
+                                      /* gradient launches (dyadic order 0, T <= 64), which then issue no memset and */
+                                      /* hand the workspace back zeroed (the finalisation kernel clears what the     */
+                                      /* launch used) -- two enqueues less per iteration, and a captured graph of    */
+                                      /* the iteration consists of kernel nodes only.  Other launches ignore it and  */
+                                      /* may leave the workspace dirty.                                              */
 #define SIGSVGD_FLAG_FORCE_GENERIC 8u /* use the coverage kernel (keeps the forward solution in  */
                                       /* HBM): tests, and long paths (65 <= T <= 128) so rough    */
                                       /* that a static-kernel increment exceeds SIGSVGD_STREAM_GMAX:*/
@@ -130,6 +139,18 @@ int sigsvgd_svgd_phi(const float *K, const float *score, const float *grad_k, co
 int sigsvgd_svgd_step(const float *K, const float *score, const float *grad_k, const float *mask,
                       int N, int D, float *v_out, const float *X_in, float *X_out, float lr,
                       float *adagrad_state, void *stream);
+
+/* The same launch with torch.optim.Adam's update (amsgrad=False, weight_decay=0, maximize=False) in the epilogue:
+ *   t = *step_dev + 1;  m = m + (1-beta1)(v - m);  q = beta2 q + (1-beta2) v^2;
+ *   X_out = X_in - lr/(1-beta1^t) * m / (sqrt(q)/sqrt(1-beta2^t) + eps);   then *step_dev = t
+ * exp_avg (m) and exp_avg_sq (q) are [N,D] fp32, updated in place; step_dev is an int on the DEVICE (the bias
+ * corrections are formed in the kernel, so the launch can be replayed from a captured HIP graph); it is
+ * incremented by a one-thread launch behind the update.  lr, beta1, beta2 and eps are doubles as torch holds them
+ * (1 - beta and the bias corrections are formed in fp64 and rounded once, as torch does).  v_out receives the velocity (what the reference stores
+ * in X.grad and in iter_dict["grad"]). */
+int sigsvgd_svgd_adam_step(const float *K, const float *score, const float *grad_k, const float *mask,
+                           int N, int D, float *v_out, const float *X_in, float *X_out, double lr, double beta1,
+                           double beta2, double eps, float *exp_avg, float *exp_avg_sq, int *step_dev, void *stream);
 
 /* ---- vector kernels on particles X[A,D], Y[B,D] ---------------------------------
  * sq[i,j] = max(0, sum_c (XM[i,c] - YM[j,c]) * (X[i,c] - Y[j,c])).  XM = X @ M, YM = Y @ M for a metric

@@ -20,9 +20,9 @@ HEADERS = [os.path.join(_CSRC, "sig_common.h"), os.path.join(_PKG, "..", "includ
 # mirror of include/sigsvgd_hip.h
 F32, F64 = 0, 1
 STATIC_RBF, STATIC_LINEAR = 0, 1
-FLAG_NAIVE_SOLVER, FLAG_SYM, FLAG_Y_IS_X, FLAG_FORCE_GENERIC = 1, 2, 4, 8
+FLAG_NAIVE_SOLVER, FLAG_SYM, FLAG_Y_IS_X, FLAG_FORCE_GENERIC, FLAG_WS_CLEAN = 1, 2, 4, 8, 16
 VEC_GAUSSIAN, VEC_IMQ, VEC_UNIT = 0, 1, 2
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 EXPORTS = [
     "sigsvgd_abi_version",
@@ -33,6 +33,7 @@ EXPORTS = [
     "sigsvgd_gram_sym_partial",
     "sigsvgd_svgd_phi",
     "sigsvgd_svgd_step",
+    "sigsvgd_svgd_adam_step",
     "sigsvgd_vec_sqdist",
     "sigsvgd_vec_kernel",
     "sigsvgd_signature",
@@ -125,6 +126,8 @@ def load():
     L.sigsvgd_svgd_phi.argtypes = [vp, vp, vp, vp, ci, ci, vp, vp, vp, cf, vp]
     L.sigsvgd_svgd_step.restype = ci
     L.sigsvgd_svgd_step.argtypes = [vp, vp, vp, vp, ci, ci, vp, vp, vp, cf, vp, vp]
+    L.sigsvgd_svgd_adam_step.restype = ci
+    L.sigsvgd_svgd_adam_step.argtypes = [vp, vp, vp, vp, ci, ci, vp, vp, vp, cd, cd, cd, cd, vp, vp, vp, vp]
     L.sigsvgd_vec_sqdist.restype = ci
     L.sigsvgd_vec_sqdist.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp, vp]
     L.sigsvgd_vec_kernel.restype = ci

@@ -23,7 +23,9 @@ int hip_fail(hipError_t e, const char *what)
 }
 
 int phi_launch(const float *K, const float *score, const float *grad_k, const float *mask, int N, int D,
-               float *v_out, const float *X_in, float *X_out, float lr, float *adagrad, hipStream_t stream);
+               float *v_out, const float *X_in, float *X_out, float lr, float *adagrad, hipStream_t stream,
+               float *exp_avg = nullptr, float *exp_avg_sq = nullptr, int *step_dev = nullptr, double lr_adam = 0.0,
+               double beta1 = 0.0, double beta2 = 0.0, float eps = 0.f);
 
 int vec_sqdist_launch(const void *X, const void *Y, const void *XM, const void *YM, int A, int B, int D, int dtype,
                       void *sq, hipStream_t stream);
@@ -158,6 +160,22 @@ int sigsvgd_svgd_step(const float *K, const float *score, const float *grad_k, c
 {
     return phi_launch(K, score, grad_k, mask, N, D, v_out, X_in, X_out, lr, adagrad_state,
                       static_cast<hipStream_t>(stream));
+}
+
+int sigsvgd_svgd_adam_step(const float *K, const float *score, const float *grad_k, const float *mask, int N, int D,
+                           float *v_out, const float *X_in, float *X_out, double lr, double beta1, double beta2, double eps,
+                           float *exp_avg, float *exp_avg_sq, int *step_dev, void *stream)
+{
+    if (!exp_avg || !exp_avg_sq || !step_dev || !X_in || !X_out) {
+        set_error("svgd_adam_step: null state / particle pointer");
+        return SIGSVGD_E_BADARG;
+    }
+    if (!(beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0 && eps >= 0.0)) {
+        set_error("svgd_adam_step: bad hyper-parameters beta1=%g beta2=%g eps=%g", beta1, beta2, eps);
+        return SIGSVGD_E_BADARG;
+    }
+    return phi_launch(K, score, grad_k, mask, N, D, v_out, X_in, X_out, (float)lr, nullptr,
+                      static_cast<hipStream_t>(stream), exp_avg, exp_avg_sq, step_dev, lr, beta1, beta2, (float)eps);
 }
 
 int sigsvgd_vec_sqdist(const void *X, const void *Y, const void *XM, const void *YM, int A, int B, int D, int dtype,

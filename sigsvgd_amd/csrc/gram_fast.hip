@@ -694,11 +694,20 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
 #endif
 }
 
+// gradX = row-side (fp64) + column-side (fp32) sums.  clean: also hand the accumulators and the work queue back
+// zeroed, so that the next launch on this workspace needs no memset (SIGSVGD_FLAG_WS_CLEAN).
 template <typename IO>
-__global__ void finalize_grad_kernel(const double *gacc, const float *cacc, IO *gradX, size_t n)
+__global__ void finalize_grad_kernel(double *gacc, float *cacc, IO *gradX, size_t n, int *queue, int nqueue, int clean)
 {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < n) gradX[idx] = (IO)(gacc[idx] + (double)cacc[idx]);
+    if (idx < n) {
+        gradX[idx] = (IO)(gacc[idx] + (double)cacc[idx]);
+        if (clean) {
+            gacc[idx] = 0.0;
+            cacc[idx] = 0.f;
+        }
+    }
+    if (clean && idx < (size_t)nqueue) queue[idx] = 0;
 }
 
 // ---- host side ---------------------------------------------------------------------------------
@@ -745,8 +754,10 @@ int launch_variant(const GramProblem &p, FastArgs &a, bool grad, bool sym)
     a.JC = JC;
     a.owned = owned;
     // the queue lives behind the fp64 accumulation buffer in the caller's workspace
-    hipError_t qe = hipMemsetAsync(a.queue, 0, (size_t)owned * sizeof(int), p.stream);
-    if (qe != hipSuccess) return hip_fail(qe, "hipMemsetAsync(queue)");
+    if (!(grad && (p.flags & SIGSVGD_FLAG_WS_CLEAN) && a.cacc)) { // (clean workspace: zero already, finalize re-zeroes)
+        hipError_t qe = hipMemsetAsync(a.queue, 0, (size_t)owned * sizeof(int), p.stream);
+        if (qe != hipSuccess) return hip_fail(qe, "hipMemsetAsync(queue)");
+    }
 #ifdef SIGSVGD_PHASE_STAMPS
     {
         static unsigned long long *dbg = nullptr;
@@ -820,8 +831,10 @@ int fast_launch(const GramProblem &p)
         if (grad) {
             a.gacc = reinterpret_cast<double *>(base);
             a.cacc = reinterpret_cast<float *>(base + nacc * sizeof(double));
-            hipError_t e = hipMemsetAsync(a.gacc, 0, nacc * (sizeof(double) + sizeof(float)), p.stream);
-            if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(gacc)");
+            if (!(p.flags & SIGSVGD_FLAG_WS_CLEAN)) {
+                hipError_t e = hipMemsetAsync(a.gacc, 0, nacc * (sizeof(double) + sizeof(float)), p.stream);
+                if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(gacc)");
+            }
             base += nacc * (sizeof(double) + sizeof(float));
         }
         a.queue = reinterpret_cast<int *>(base);
@@ -840,13 +853,15 @@ int fast_launch(const GramProblem &p)
     if (rc) return rc;
     if (grad) {
         const int bs = 256;
-        const unsigned gs = (unsigned)((nacc + bs - 1) / bs);
+        const int clean = (p.flags & SIGSVGD_FLAG_WS_CLEAN) ? 1 : 0;
+        const size_t nfin = nacc > (size_t)a.owned ? nacc : (size_t)a.owned;
+        const unsigned gs = (unsigned)((nfin + bs - 1) / bs);
         if (p.dtype == SIGSVGD_F64)
             hipLaunchKernelGGL(finalize_grad_kernel<double>, dim3(gs), dim3(bs), 0, p.stream, a.gacc, a.cacc,
-                               static_cast<double *>(p.gradX_out), nacc);
+                               static_cast<double *>(p.gradX_out), nacc, a.queue, a.owned, clean);
         else
             hipLaunchKernelGGL(finalize_grad_kernel<float>, dim3(gs), dim3(bs), 0, p.stream, a.gacc, a.cacc,
-                               static_cast<float *>(p.gradX_out), nacc);
+                               static_cast<float *>(p.gradX_out), nacc, a.queue, a.owned, clean);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return hip_fail(e, "launch finalize_grad_kernel");
     }

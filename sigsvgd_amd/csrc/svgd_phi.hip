@@ -1,7 +1,9 @@
 // SVGD velocity: v = -((K @ score - grad_k) / N) [* mask], optionally fused with the simple Adagrad
 // scaling of the reference (svgd.py:110-113) and the optimizer=None particle update X_out = X_in - lr * v
-// (reference src/inference/svgd.py:82-83,115;
-// mask: src/inference/trajectory_svgd.py:84).
+// (reference src/inference/svgd.py:82-83,115; mask: src/inference/trajectory_svgd.py:84), or with the update of
+// the reference's DEFAULT optimizer, torch.optim.Adam driven through a closure that sets X.grad = v
+// (svgd.py:20,100-107): exp_avg / exp_avg_sq updated in place, bias corrections from a step counter that lives
+// on the device (so the launch can be replayed from a captured graph), X_out = X_in - lr/bc1 * m / (sqrt(v2)/sqrt(bc2) + eps).
 //
 // The N x N x D product is the only GEMM-shaped piece of the hot path and runs on the fp32 MFMA
 // (v_mfma_f32_16x16x4_f32: exact fp32 FMA chain, same numerics as the reference's fp32 matmul).
@@ -22,11 +24,20 @@ constexpr int PK = 64;  // k per stage (16 per wavefront)
 constexpr int KS = PK + 4; // LDS row strides (floats), padded: 16-B aligned, conflict-light
 constexpr int SS = PN + 16; // = 16 mod 32: the two k rows a 32-lane read touches land on disjoint banks
 
+struct AdamArgs {
+    float *exp_avg, *exp_avg_sq; // [N, D] fp32 state, updated in place; exp_avg == NULL: no Adam
+    const int *step;             // device counter: updates done so far (this launch is update *step + 1)
+    double lr, beta1, beta2;     // doubles as torch holds them: 1 - beta and the bias corrections are formed in fp64
+    float eps;
+};
+
+__global__ void counter_inc_kernel(int *ctr) { *ctr += 1; }
+
 __global__ __launch_bounds__(256) void svgd_phi_kernel(const float *__restrict__ K, const float *__restrict__ S,
                                                        const float *__restrict__ gk, const float *__restrict__ mask,
                                                        int N, int D, float *__restrict__ v_out,
                                                        const float *__restrict__ X_in, float *__restrict__ X_out, float lr,
-                                                       float *__restrict__ adagrad)
+                                                       float *__restrict__ adagrad, AdamArgs adam)
 {
     __shared__ __align__(16) float kt[PM * KS];     // K tile      [row][k]
     __shared__ __align__(16) float st[PK * SS];     // score tile  [k][col]
@@ -123,6 +134,15 @@ __global__ __launch_bounds__(256) void svgd_phi_kernel(const float *__restrict__
     __syncthreads();
     if (wave == 0) {
         const float invN = 1.0f / (float)N;
+        float step_size = lr, inv_sqrt_bc2 = 1.f, omb1 = 0.f, omb2 = 0.f, b2 = 0.f;
+        if (adam.exp_avg) { // torch.optim.Adam (amsgrad=False, weight_decay=0, maximize=False): scalars in fp64 as torch
+            const double t = (double)(*adam.step + 1);
+            step_size = (float)(adam.lr / (1.0 - pow(adam.beta1, t)));
+            inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow(adam.beta2, t)));
+            omb1 = (float)(1.0 - adam.beta1);
+            omb2 = (float)(1.0 - adam.beta2);
+            b2 = (float)adam.beta2;
+        }
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -143,14 +163,22 @@ __global__ __launch_bounds__(256) void svgd_phi_kernel(const float *__restrict__
                             v = v / sqrtf(acc2 + 1e-12f);
                         }
                         v_out[idx] = v;
-                        if (X_out) X_out[idx] = X_in[idx] - lr * v;
+                        if (adam.exp_avg) {
+                            const float m = adam.exp_avg[idx] + omb1 * (v - adam.exp_avg[idx]); // lerp
+                            const float q = b2 * adam.exp_avg_sq[idx] + omb2 * (v * v);
+                            adam.exp_avg[idx] = m;
+                            adam.exp_avg_sq[idx] = q;
+                            X_out[idx] = X_in[idx] - step_size * (m / (sqrtf(q) * inv_sqrt_bc2 + adam.eps));
+                        } else if (X_out)
+                            X_out[idx] = X_in[idx] - lr * v;
                     }
                 }
     }
 }
 
 int phi_launch(const float *K, const float *score, const float *grad_k, const float *mask, int N, int D,
-               float *v_out, const float *X_in, float *X_out, float lr, float *adagrad, hipStream_t stream)
+               float *v_out, const float *X_in, float *X_out, float lr, float *adagrad, hipStream_t stream,
+               float *exp_avg, float *exp_avg_sq, int *step_dev, double lr_adam, double beta1, double beta2, float eps)
 {
     if (N < 1 || D < 1 || !K || !score || !grad_k || !v_out) {
         set_error("svgd_phi: bad arguments N=%d D=%d", N, D);
@@ -160,11 +188,21 @@ int phi_launch(const float *K, const float *score, const float *grad_k, const fl
         set_error("svgd_phi: X_in and X_out must both be given or both be NULL");
         return SIGSVGD_E_BADARG;
     }
+    AdamArgs adam{exp_avg, exp_avg_sq, step_dev, lr_adam, beta1, beta2, eps};
+    if (exp_avg && (!exp_avg_sq || !step_dev || !X_in || adagrad)) {
+        set_error("svgd_adam_step: needs exp_avg, exp_avg_sq, step, X_in/X_out (and no Adagrad state)");
+        return SIGSVGD_E_BADARG;
+    }
     dim3 grid((D + PN - 1) / PN, (N + PM - 1) / PM);
     hipLaunchKernelGGL(svgd_phi_kernel, grid, dim3(256), 0, stream, K, score, grad_k, mask, N, D, v_out, X_in, X_out, lr,
-                       adagrad);
+                       adagrad, adam);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "launch svgd_phi_kernel");
+    if (exp_avg) { // the counter moves only after every workgroup of the update has read it (stream order)
+        hipLaunchKernelGGL(counter_inc_kernel, dim3(1), dim3(1), 0, stream, step_dev);
+        e = hipGetLastError();
+        if (e != hipSuccess) return hip_fail(e, "launch counter_inc_kernel");
+    }
     return SIGSVGD_OK;
 }
 

@@ -5,8 +5,11 @@
 
 What runs where: the dense part of the velocity, v = -((K @ score - grad_k)/N), is one HIP launch
 (`ops.svgd_phi`, fp32 MFMA); with `optimizer_class=None` the same launch also applies the reference's simple
-Adagrad (`adaptive_gradient=True`) and the update X - lr*g.  torch optimizers (Adam by default) are driven
-through the usual closure.  Deliberate differences, none of which changes a result:
+Adagrad (`adaptive_gradient=True`) and the update X - lr*g; with the reference's default optimizer, a plain
+`torch.optim.Adam`, the same launch applies Adam's update (`ops.svgd_adam`: exp_avg / exp_avg_sq and the step
+counter live in an `ops.AdamState` that is mirrored into the torch optimizer's state, so `optimizer.state_dict()`
+and `load_state_dict` keep working, svgd.py:130-133,158).  Other torch optimizers, or Adam with amsgrad /
+weight decay / maximize, are driven through the usual closure.  Deliberate differences, none of which changes a result:
 
   * `iter_dict_device`: "cpu" (default; the reference moves every tensor of the per-iteration dict to the host,
     svgd.py:85-90) or None to leave them on the GPU -- the eager copy of the N x N Gram matrix otherwise
@@ -139,7 +142,53 @@ class SVGD:
             self._fuse_manual_update = None
         return X_new, grad, iter_dict
 
+    # ---- torch.optim.Adam fused into the velocity launch ---------------------------------------------------
+    def _adam_fusable(self, X, optimizer) -> bool:
+        if type(optimizer) is not torch.optim.Adam or type(self)._velocity is not SVGD._velocity:
+            return False
+        if X.device.type != "cuda" or X.dtype != torch.float32 or not X.is_contiguous() or X.dim() < 2:
+            return False
+        if len(optimizer.param_groups) != 1 or len(optimizer.param_groups[0]["params"]) != 1:
+            return False
+        g = optimizer.param_groups[0]
+        if g["params"][0] is not X:
+            return False
+        return not (g.get("amsgrad") or g.get("weight_decay") or g.get("maximize") or g.get("capturable")
+                    or g.get("differentiable") or torch.is_tensor(g["lr"]))
+
+    def _adam_state(self, X, optimizer):
+        """class-owned state of the fused update, created from (and mirrored back into) the torch optimizer"""
+        cached = getattr(self, "_adam_cache", None)
+        g = optimizer.param_groups[0]
+        if cached is None or cached[0] is not optimizer:
+            st = ops.AdamState(X, betas=g["betas"], eps=g["eps"])
+            have = optimizer.state.get(X)
+            if have:  # resumed from a state_dict (svgd.py:130-133)
+                st.exp_avg.copy_(have["exp_avg"].reshape(st.exp_avg.shape))
+                st.exp_avg_sq.copy_(have["exp_avg_sq"].reshape(st.exp_avg_sq.shape))
+                st.t_host = int(have["step"])
+                st.step.fill_(st.t_host)
+            self._adam_cache = cached = (optimizer, st)
+        return cached[1]
+
+    def _fused_adam_step(self, X, grad_log_p, optimizer, kwargs):
+        if self.log_p is None and grad_log_p is None:
+            raise ValueError(_NEEDS_TARGET)
+        k_xx, grad_k = self._kernel_terms(X, kwargs)
+        score, loss = self._score_terms(X, grad_log_p, kwargs)
+        st = self._adam_state(X, optimizer)
+        with torch.no_grad():
+            v, _ = ops.svgd_adam(k_xx, score, grad_k, X, optimizer.param_groups[0]["lr"], st, inplace=True)
+        X.grad = v.reshape(X.shape)
+        optimizer.state[X] = {"step": torch.tensor(float(st.t_host)), "exp_avg": st.exp_avg.view(X.shape),
+                              "exp_avg_sq": st.exp_avg_sq.view(X.shape)}
+        info = self._export({"k_xx": k_xx, "grad_k": grad_k, "loss": loss, **kwargs})
+        info["grad"] = self._grad_entry(X.grad)
+        return X, info
+
     def step(self, X: torch.Tensor, grad_log_p: torch.Tensor = None, optimizer: optim.Optimizer = None, **kwargs):
+        if isinstance(optimizer, torch.optim.Optimizer) and self._adam_fusable(X, optimizer):
+            return self._fused_adam_step(X, grad_log_p, optimizer, kwargs)
         if isinstance(optimizer, torch.optim.Optimizer):
             def closure():  # torch optimizers: the velocity is the "gradient" they descend along
                 optimizer.zero_grad()

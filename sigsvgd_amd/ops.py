@@ -14,6 +14,8 @@ import torch
 from . import _lib
 
 _WS = {}  # (device index, stream) -> uint8 workspace tensor
+_WS_CLEAN = {}  # (device index, stream) -> zero-filled workspace of the register-resident gradient launches, which
+#                 take it zeroed and hand it back zeroed (SIGSVGD_FLAG_WS_CLEAN): no memset per iteration
 
 
 def _require_gpu(*tensors) -> torch.device:
@@ -46,6 +48,21 @@ def _workspace(dev: torch.device, nbytes: int) -> Tuple[Optional[torch.Tensor], 
         ws = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=dev)
         _WS[key] = ws
     return ws, ws.numel()
+
+
+def _clean_workspace(dev: torch.device, nbytes: int) -> Tuple[torch.Tensor, int]:
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _WS_CLEAN.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.zeros(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=dev)
+        _WS_CLEAN[key] = ws
+    return ws, ws.numel()
+
+
+def _fast_path(T: int, d: int, dyadic_order: int, static_kind: int, naive: bool, force_generic: bool) -> bool:
+    """launches the register-resident kernel serves (csrc/gram_fast.hip fast_supported)"""
+    return (dyadic_order == 0 and 3 <= T <= 64 and d <= 16 and static_kind == _lib.STATIC_RBF and not naive
+            and not force_generic)
 
 
 def _io_dtype(t: torch.Tensor) -> int:
@@ -144,7 +161,12 @@ def gram_fwd_bwd(X, Y, inv_h: float, dyadic_order: int = 0, static_kind: int = _
     nbytes = ctypes.c_size_t(0)
     _lib.check(L.sigsvgd_gram_workspace_bytes(A, B, T, d, dyadic_order, 1, flags, ctypes.byref(nbytes)),
                "gram_workspace_bytes")
-    ws, wsn = _workspace(dev, nbytes.value)
+    clean = _fast_path(T, d, dyadic_order, static_kind, naive, force_generic)
+    if clean:  # zero on entry, handed back zeroed: the launch issues no memset
+        flags |= _lib.FLAG_WS_CLEAN
+        ws, wsn = _clean_workspace(dev, nbytes.value)
+    else:
+        ws, wsn = _workspace(dev, nbytes.value)
     K = torch.empty((A, B), dtype=Xc.dtype, device=dev)
     gX = torch.empty((A, T, d), dtype=Xc.dtype, device=dev)
     with torch.cuda.device(dev):
@@ -152,13 +174,16 @@ def gram_fwd_bwd(X, Y, inv_h: float, dyadic_order: int = 0, static_kind: int = _
                                     int(dyadic_order), int(static_kind), flags,
                                     go.data_ptr() if go is not None else None, K.data_ptr(), gX.data_ptr(),
                                     ws.data_ptr() if ws is not None else None, wsn, _stream_ptr(dev))
+    if rc != 0 and clean:  # a failed launch may have left the workspace dirty
+        _WS_CLEAN.pop((dev.index, torch.cuda.current_stream(dev).cuda_stream), None)
     _lib.check(rc, "gram_fwd_bwd")
     if guarded and bool(torch.isnan(gX).any()) and bool(torch.isfinite(Xc).all()) and bool(torch.isfinite(Yc).all()):
         return gram_fwd_bwd(X, Y, inv_h, dyadic_order, static_kind, grad_out, naive, sym, y_is_x, True, False)
     return K, gX
 
 
-def svgd_phi(K, score, grad_k, mask=None, X=None, lr: Optional[float] = None, adagrad_state=None):
+def svgd_phi(K, score, grad_k, mask=None, X=None, lr: Optional[float] = None, adagrad_state=None,
+             inplace: bool = False):
     """v = -((K @ score - grad_k)/N) [* mask]; with X and lr also returns X - lr*v.
 
     All fp32, shapes K [N,N], score/grad_k/mask/X [N, ...] (flattened to [N,D]).
@@ -187,7 +212,12 @@ def svgd_phi(K, score, grad_k, mask=None, X=None, lr: Optional[float] = None, ad
         if lr is None:
             raise ValueError("lr is required with X")
         Xc = f(X)
-        Xn = torch.empty_like(Xc)
+        if inplace:  # every element is read and written by the same thread
+            if Xc.data_ptr() != X.data_ptr():
+                raise ValueError("inplace update needs contiguous float32 particles")
+            Xn = Xc
+        else:
+            Xn = torch.empty_like(Xc)
     ag = None
     if adagrad_state is not None:
         _require_gpu(adagrad_state)
@@ -202,8 +232,57 @@ def svgd_phi(K, score, grad_k, mask=None, X=None, lr: Optional[float] = None, ad
     _lib.check(rc, "svgd_step")
     v = v.reshape(shape)
     if X is not None:
-        return v, Xn.reshape(X.shape)
+        return v, (X if inplace else Xn.reshape(X.shape))
     return v
+
+
+class AdamState:
+    """State of the fused Adam update (torch.optim.Adam semantics): exp_avg / exp_avg_sq [N, D] fp32 and the step
+    counter, all on the device (the counter too, so a captured graph can replay the update)."""
+
+    def __init__(self, like: torch.Tensor, betas=(0.9, 0.999), eps: float = 1e-8):
+        n = like.shape[0]
+        self.exp_avg = torch.zeros((n, like.numel() // n), dtype=torch.float32, device=like.device)
+        self.exp_avg_sq = torch.zeros_like(self.exp_avg)
+        self.step = torch.zeros((), dtype=torch.int32, device=like.device)
+        self.t_host = 0  # host mirror of the counter (no read-back needed to export the state)
+        self.betas, self.eps = (float(betas[0]), float(betas[1])), float(eps)
+
+
+def svgd_adam(K, score, grad_k, X, lr: float, state: AdamState, mask=None, inplace: bool = False):
+    """v = -((K @ score - grad_k)/N) [* mask] and torch.optim.Adam's update of X along it, one launch (plus a
+    one-thread launch that advances the device-side step counter).  Returns (v shaped like score, X_new);
+    inplace=True writes the update into X itself (X must be contiguous fp32) and returns X."""
+    L = _lib.load()
+    dev = _require_gpu(K, score, grad_k, mask, X, state.exp_avg)
+    N = K.shape[0]
+    if K.dim() != 2 or K.shape[1] != N:
+        raise ValueError(f"K must be square, got {tuple(K.shape)}")
+    shape = score.shape
+    f = lambda t: t.detach().to(torch.float32).reshape(N, -1).contiguous()
+    Kc = K.detach().to(torch.float32).contiguous()
+    s, gk, Xc = f(score), f(grad_k), f(X)
+    D = s.shape[1]
+    if gk.shape != s.shape or Xc.shape != s.shape or tuple(state.exp_avg.shape) != (N, D):
+        raise ValueError("score, grad_k, X and the Adam state must share the shape [N, D]")
+    m = None
+    if mask is not None:
+        m = torch.broadcast_to(torch.as_tensor(mask, dtype=torch.float32, device=dev), shape).reshape(N, -1).contiguous()
+    v = torch.empty_like(s)
+    if inplace:
+        if Xc.data_ptr() != X.data_ptr():
+            raise ValueError("inplace Adam update needs contiguous float32 particles")
+        Xn = Xc  # every element is read and written by the same thread
+    else:
+        Xn = torch.empty_like(Xc)
+    with torch.cuda.device(dev):
+        rc = L.sigsvgd_svgd_adam_step(Kc.data_ptr(), s.data_ptr(), gk.data_ptr(), m.data_ptr() if m is not None else None,
+                                      N, D, v.data_ptr(), Xc.data_ptr(), Xn.data_ptr(), float(lr), state.betas[0],
+                                      state.betas[1], state.eps, state.exp_avg.data_ptr(), state.exp_avg_sq.data_ptr(),
+                                      state.step.data_ptr(), _stream_ptr(dev))
+    _lib.check(rc, "svgd_adam_step")
+    state.t_host += 1
+    return v.reshape(shape), (X if inplace else Xn.reshape(X.shape))
 
 
 def gram_sym_partial(X, inv_h: float, tile_offset: int, tile_stride: int, static_kind: int = _lib.STATIC_RBF,
