@@ -5,6 +5,6 @@ sys.path.insert(0, ROOT)
 from sigsvgd_amd import _lib
 out = os.path.abspath(sys.argv[1])
 cmd = [_lib._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", out] + sys.argv[2:]
-cmd += [os.path.join(_lib._CSRC, s) for s in _lib.SOURCES]
+cmd += [os.path.join(_lib._CSRC, s) for s in _lib.SOURCES] + ["-ldl"]
 subprocess.run(cmd, check=True)
 print(out)

@@ -15,7 +15,7 @@ def build():
     from sigsvgd_amd import _lib
 
     cmd = [_lib._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DSIGSVGD_PHASE_STAMPS",
-           "-o", OUT] + [os.path.join(_lib._CSRC, s) for s in _lib.SOURCES]
+           "-o", OUT] + [os.path.join(_lib._CSRC, s) for s in _lib.SOURCES] + ["-ldl"]
     subprocess.run(cmd, check=True)
 
 

@@ -62,7 +62,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB_PATH
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB_PATH]
-    cmd += [os.path.join(_CSRC, s) for s in SOURCES]
+    cmd += [os.path.join(_CSRC, s) for s in SOURCES] + ["-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

@@ -1,6 +1,8 @@
 // extern "C" entry points of libsigsvgd_hip.so (declared in include/sigsvgd_hip.h).
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
+#include <dlfcn.h>
 
 #include "sig_common.h"
 
@@ -65,6 +67,44 @@ static int check_common(const void *X, const void *Y, int A, int B, int T, int d
     return SIGSVGD_OK;
 }
 
+// ---- roctx ranges around the launches (the tracing hook of this path) ------------------------------
+// Enabled with SIGSVGD_ROCTX=1: libroctx64.so is looked up at run time (no link-time dependency), every entry
+// point that enqueues work brackets its launches with roctxRangePush/Pop, so `rocprofv3 --marker-trace` shows
+// which API call a kernel belongs to.  Off by default: zero cost beyond one branch.
+namespace {
+struct Roctx {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx()
+    {
+        const char *on = getenv("SIGSVGD_ROCTX");
+        if (!on || on[0] == '0') return;
+        void *h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("/opt/rocm/lib/libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return;
+        push = reinterpret_cast<int (*)(const char *)>(dlsym(h, "roctxRangePushA"));
+        pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+        if (!push || !pop) push = nullptr, pop = nullptr;
+    }
+};
+struct Range {
+    const Roctx &r;
+    explicit Range(const char *name) : r(instance())
+    {
+        if (r.push) r.push(name);
+    }
+    ~Range()
+    {
+        if (r.push) r.pop();
+    }
+    static const Roctx &instance()
+    {
+        static Roctx x;
+        return x;
+    }
+};
+} // namespace
+
 static int dispatch(const GramProblem &p)
 {
     const int want_grad = p.gradX_out != nullptr;
@@ -109,6 +149,7 @@ int sigsvgd_gram_fwd(const void *X, const void *Y, int A, int B, int T, int d, i
     if (rc) return rc;
     GramProblem p{X, Y, A, B, T, d, dtype, inv_h, dyadic_order, static_kind, flags, nullptr,
                   K_out, nullptr, workspace, workspace_bytes, static_cast<hipStream_t>(stream)};
+    Range range("sigsvgd_gram_fwd");
     return dispatch(p);
 }
 
@@ -128,6 +169,7 @@ int sigsvgd_gram_fwd_bwd(const void *X, const void *Y, int A, int B, int T, int 
     }
     GramProblem p{X, Y, A, B, T, d, dtype, inv_h, dyadic_order, static_kind, flags, grad_out,
                   K_out, gradX_out, workspace, workspace_bytes, static_cast<hipStream_t>(stream)};
+    Range range("sigsvgd_gram_fwd_bwd");
     return dispatch(p);
 }
 
@@ -144,6 +186,7 @@ int sigsvgd_gram_sym_partial(const void *X, int N, int T, int d, int dtype, doub
     }
     GramProblem p{X, X, N, N, T, d, dtype, inv_h, 0, static_kind, flags | SIGSVGD_FLAG_Y_IS_X, grad_out,
                   K_partial, grad_partial, workspace, workspace_bytes, static_cast<hipStream_t>(stream)};
+    Range range("sigsvgd_gram_sym_partial");
     if (!fast_supported(N, N, T, d, 0, static_kind, flags) && stream_supported(N, N, T, d, 0, static_kind, flags))
         return stream_sym_partial(p, tile_offset, tile_stride, grad_partial);
     return fast_sym_partial(p, tile_offset, tile_stride, grad_partial);
@@ -152,12 +195,14 @@ int sigsvgd_gram_sym_partial(const void *X, int N, int T, int d, int dtype, doub
 int sigsvgd_svgd_phi(const float *K, const float *score, const float *grad_k, const float *mask, int N, int D,
                      float *v_out, const float *X_in, float *X_out, float lr, void *stream)
 {
+    Range range("sigsvgd_svgd_phi");
     return phi_launch(K, score, grad_k, mask, N, D, v_out, X_in, X_out, lr, nullptr, static_cast<hipStream_t>(stream));
 }
 
 int sigsvgd_svgd_step(const float *K, const float *score, const float *grad_k, const float *mask, int N, int D,
                       float *v_out, const float *X_in, float *X_out, float lr, float *adagrad_state, void *stream)
 {
+    Range range("sigsvgd_svgd_step");
     return phi_launch(K, score, grad_k, mask, N, D, v_out, X_in, X_out, lr, adagrad_state,
                       static_cast<hipStream_t>(stream));
 }
@@ -174,6 +219,7 @@ int sigsvgd_svgd_adam_step(const float *K, const float *score, const float *grad
         set_error("svgd_adam_step: bad hyper-parameters beta1=%g beta2=%g eps=%g", beta1, beta2, eps);
         return SIGSVGD_E_BADARG;
     }
+    Range range("sigsvgd_svgd_adam_step");
     return phi_launch(K, score, grad_k, mask, N, D, v_out, X_in, X_out, (float)lr, nullptr,
                       static_cast<hipStream_t>(stream), exp_avg, exp_avg_sq, step_dev, lr, beta1, beta2, (float)eps);
 }

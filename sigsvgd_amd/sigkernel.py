@@ -190,6 +190,7 @@ class SigKernel:
         self.dyadic_order = int(dyadic_order)
         self._naive_solver = bool(_naive_solver)
         self.speculate_ones = True
+        self.value_check_min_batch = 32  # below this a launch is latency-bound and the compare would not pay
 
     def compute_Gram(self, X: torch.Tensor, Y: torch.Tensor, sym: bool = False) -> torch.Tensor:
         """K[i,j] = k_sig(X_i, Y_j), X [A,T,d], Y [B,T,d] on a HIP device; same dtype/device as X."""
@@ -197,6 +198,13 @@ class SigKernel:
         y_is_x = (
             Y.data_ptr() == X.data_ptr() and Y.shape == X.shape and Y.stride() == X.stride() and Y.dtype == X.dtype
         )
+        if (not y_is_x and Y.shape == X.shape and Y.dtype == X.dtype and X.shape[0] >= self.value_check_min_batch
+                and bool(torch.equal(X.detach(), Y.detach()))):
+            # The reference's callers pass two BUFFERS with the same values -- `compute_Gram(X.double(),
+            # Y.double())` with Y = x.detach() (src/kernels/_traj_kernels.py:205, src/inference/trajectory_svgd.py:60-62).
+            # One device compare + scalar read-back (tens of microseconds) buys the symmetric solve: each
+            # unordered pair once instead of every ordered pair, i.e. half the launch at these batch sizes.
+            y_is_x = True
         return _SigKernelGram.apply(X, Y, static_kind, inv_h, self.dyadic_order, self._naive_solver, bool(sym),
                                     y_is_x, self.speculate_ones)
 

@@ -180,6 +180,64 @@ def test_graphed_iteration_equals_eager(gpu, update, shape, dyadic):
         assert int(g._adam.step.item()) == 3
 
 
+def test_route_a_value_equal_buffers_take_the_symmetric_solve(gpu):
+    """The reference calls compute_Gram(X.double(), Y.double()) with Y = x.detach(): two buffers, same values
+    (src/kernels/_traj_kernels.py:205).  From 32 particles on the wrapper compares them once and launches the
+    symmetric variant (each unordered pair once); small or different inputs stay on ordered pairs; results agree."""
+    from sigsvgd_amd import ops
+    from sigsvgd_amd.sigkernel import RBFKernel, SigKernel
+    from sigsvgd_amd.utils.synthetic import synthetic_inputs
+
+    seen = []
+    orig_fb, orig_f = ops.gram_fwd_bwd, ops.gram_fwd
+
+    def spy_fb(*a, **k):
+        seen.append(bool(a[8] if len(a) > 8 else k.get("y_is_x", False)))
+        return orig_fb(*a, **k)
+
+    def spy_f(*a, **k):
+        seen.append(bool(k.get("y_is_x", False)))
+        return orig_f(*a, **k)
+
+    ops.gram_fwd_bwd, ops.gram_fwd = spy_fb, spy_f
+    try:
+        sk = SigKernel(RBFKernel(sigma=1.0), dyadic_order=0)
+        X, _ = synthetic_inputs(64, 32, 3)
+        Xg = X.to(gpu).requires_grad_(True)
+        K = sk.compute_Gram(Xg.double(), Xg.detach().double())
+        g = torch.autograd.grad(K.sum(), Xg)[0]
+        assert seen and all(seen), seen
+        seen.clear()
+        K_small = sk.compute_Gram(Xg[:8].double(), Xg[:8].detach().double())
+        assert seen == [False]
+        seen.clear()
+        K_diff = sk.compute_Gram(Xg.double(), (Xg.detach() + 1e-3).double())
+        assert seen == [False]
+    finally:
+        ops.gram_fwd_bwd, ops.gram_fwd = orig_fb, orig_f
+    Kref, gref = ops.gram_fwd_bwd(Xg.detach(), Xg.detach().clone(), 1.0)  # ordered pairs
+    assert rel(K, Kref.double().cpu().numpy()) < 1e-6 and rel(g, gref.double().cpu().numpy()) < TOL
+    assert rel(K_small, Kref[:8, :8].double().cpu().numpy()) < 1e-6 and K_diff.shape == (64, 64)
+
+
+def test_roctx_ranges_can_be_switched_on():
+    """SIGSVGD_ROCTX=1: the entry points bracket their launches with roctx ranges (libroctx64 looked up at run time);
+    the path must keep working with the hook on -- checked in a fresh process because the switch is read once."""
+    import os
+    import subprocess
+    import sys
+
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    code = ("import torch; from sigsvgd_amd import ops; from sigsvgd_amd.utils.synthetic import synthetic_inputs;"
+            "X,s=synthetic_inputs(16,32,3); X=X.cuda(); K,g=ops.gram_fwd_bwd(X,X,1.0,y_is_x=True);"
+            "v=ops.svgd_phi(K,s.cuda(),g); torch.cuda.synchronize(); print('ok', float(K[0,0]))")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SIGSVGD_ROCTX="1", PYTHONPATH=root),
+                       capture_output=True, text=True, timeout=300, cwd=root)
+    assert p.returncode == 0 and "ok" in p.stdout, p.stderr[-1500:]
+
+
 def test_trajectory_svgd_sigkernel_branch_on_gpu(gpu):
     """fp64 upcast / chained autograd through a rollout graph, as DuSt drives it"""
     from sigsvgd_amd.inference import TrajectorySVGD
