@@ -6,13 +6,13 @@
 
 Stored outputs of the notebook: per-timestep particle variance
 [0.052, 0.566, 0.622, 0.587, 1.282, 0.701, 0.672, 0.576, 0.438, 0.100] (cell 9); mean / highest
-log-probability of the final paths -21.15 / -19.67 (cell 12).  They are not a parity fixture: the run is
-unseeded on an unknown device with an older package (`stein_mpc`) and `sigkernel` version, and the two cells
-do not even agree with each other (those variances imply a mean log-probability of about -24.0).  What carries
-over is the qualitative picture, which this script reproduces: the particles stay spread out (the plain
-RBF-SVGD baseline of the notebook collapses to variance 1e-9), with the end points of the paths pinned more
-tightly than the interior.  Measured here (seed 0): variances 0.25 at the ends, 0.87-1.30 inside, mean
-log-probability -27.7 with the notebook's sign convention for grad_k; -20.9 / -19.7 with the plain one.
+log-probability of the final paths -21.15 / -19.67 and "average path length" 3.298 (cell 12).  They are not a
+parity fixture: the run is unseeded on an unknown device with an older package (`stein_mpc`) and `sigkernel`
+version.  Measured with this build over 5 seeds (profiles/r02_notebook_statistics.json,
+scripts/notebook_statistics.py): with the library's own sign of grad_k (score.py:69) -20.87 / -19.41 / 3.14 --
+cell 12's numbers; with cell 9's extra `-1 *` ("TODO: Check if this is needed") -27.66 / -25.6 / 5.63 and the
+variance profile 0.25 at the ends, 0.86..1.29 inside -- the shape of cell 9's profile.  The two stored cells
+therefore come from runs with different signs; tests/test_gpu_api.py pins both against bands.
 
     python examples/sequential_distribution.py [--steps 200] [--seed 0]
 """
@@ -27,7 +27,9 @@ import torch
 from torch.distributions import MultivariateNormal
 
 
-def run(steps: int = 200, seed: int = 0, device: str = "cuda:0"):
+def run(steps: int = 200, seed: int = 0, device: str = "cuda:0", grad_k_sign: float = -1.0):
+    """grad_k_sign: -1 is the notebook's cell 9 (`grad_k = -1 * autograd.grad(k_xx.sum(), x)`, flagged there with
+    "TODO: Check if this is needed"); +1 is the library's own convention (src/inference/score.py:69)."""
     from sigsvgd_amd.inference import SVGD
     from sigsvgd_amd.kernels import SignatureKernel
 
@@ -42,7 +44,7 @@ def run(steps: int = 200, seed: int = 0, device: str = "cuda:0"):
         log_p = target.log_prob(x.flatten(1))
         (grad_log_p,) = torch.autograd.grad(log_p.sum(), x, retain_graph=True)
         k_xx = kernel(x, x)
-        grad_k = -1 * torch.autograd.grad(k_xx.sum(), x)[0]
+        grad_k = grad_k_sign * torch.autograd.grad(k_xx.sum(), x)[0]
         return grad_log_p, {"k_xx": k_xx.detach(), "grad_k": grad_k.detach(), "loss": -log_p}
 
     particles = init.clone()
@@ -53,6 +55,8 @@ def run(steps: int = 200, seed: int = 0, device: str = "cuda:0"):
         "variance_per_timestep": particles.var(dim=[0, 2]).tolist(),
         "mean_log_prob": float(log_probs.mean()),
         "max_log_prob": float(log_probs.max()),
+        # cell 12's "average path length": norm of the difference of CONSECUTIVE PARTICLES, as the notebook computes it
+        "avg_path_length_cell12": float((particles[1:] - particles[:-1]).norm(dim=[1, 2]).mean()),
         "moved": not torch.allclose(particles, init),
     }
 
@@ -61,8 +65,9 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--sign", type=float, default=-1.0, help="sign applied to grad_k (-1: notebook cell 9, +1: score.py:69)")
     args = ap.parse_args()
-    out = run(args.steps, args.seed)
+    out = run(args.steps, args.seed, grad_k_sign=args.sign)
     print("variance per timestep:", [round(v, 3) for v in out["variance_per_timestep"]])
     print("mean / highest log-probability:", round(out["mean_log_prob"], 2), "/", round(out["max_log_prob"], 2))
     print("reference notebook:            [0.052, 0.566, 0.622, 0.587, 1.282, 0.701, 0.672, 0.576, 0.438, 0.1]  -21.15 / -19.67")

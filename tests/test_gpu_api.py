@@ -475,9 +475,19 @@ def test_fused_adagrad_step_matches_torch(gpu):
         ops.svgd_phi(K.to(gpu), s.to(gpu), gk.to(gpu), adagrad_state=torch.zeros(N, D + 1, device=gpu))
 
 
-def test_reference_notebook_experiment_runs_end_to_end(gpu):
-    """examples/sequential_distribution.py: the reference's stored sig-kernel SVGD experiment (N=100, T=10, d=2,
-    dyadic order 4, Adam) through SignatureKernel + SVGD.optimize on the GPU; qualitative outcome only."""
+def test_reference_notebook_experiment_statistics(gpu):
+    """The only end-to-end signature-kernel numbers the reference stores
+    (examples/script_sequential_distribution.ipynb; N=100, T=10, d=2, SignatureKernel(h=5, depth=4), Adam 0.05 x 200):
+        cell 12: mean / highest log-probability of the final paths -21.15 / -19.67, "average path length" 3.298
+        cell 9 : per-timestep variance 0.05..0.10 at the two ends, 0.44..1.28 inside
+    The notebook's run is unseeded on an unknown device and its cell 9 multiplies grad_k by -1 with the remark
+    "TODO: Check if this is needed", so this is a statistical pin (3 seeds, bands stated here), not a parity
+    fixture; the 5-seed table of both conventions is committed as profiles/r02_notebook_statistics.json:
+        sign +1 (the library's own convention, src/inference/score.py:69): -20.87 +- 0.06 / -19.41 / 3.14
+            -> reproduces cell 12; variances ~0.25 at every timestep
+        sign -1 (cell 9 as written): -27.66 / -25.6 / 5.63; variances 0.25 at the ends, 0.86..1.29 inside
+            -> reproduces the SHAPE of cell 9's profile (ends pinned, interior spread, maximum mid-path)
+    i.e. the notebook's two stored cells come from runs with different signs."""
     import importlib.util
     import os
 
@@ -485,8 +495,17 @@ def test_reference_notebook_experiment_runs_end_to_end(gpu):
     spec = importlib.util.spec_from_file_location("sequential_distribution", path)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    out = mod.run(steps=60, seed=1, device=str(gpu))
-    var = np.asarray(out["variance_per_timestep"])
-    assert out["moved"] and np.isfinite(var).all() and np.isfinite(out["mean_log_prob"])
-    assert var.min() > 1e-3            # no collapse (the RBF baseline of the notebook ends at 1e-9)
-    assert var[[0, -1]].max() < var[2:-2].min()  # path ends pinned more tightly than the interior
+    plus = [mod.run(steps=200, seed=s, device=str(gpu), grad_k_sign=+1.0) for s in range(3)]
+    mean_lp = np.mean([r["mean_log_prob"] for r in plus])
+    max_lp = np.mean([r["max_log_prob"] for r in plus])
+    length = np.mean([r["avg_path_length_cell12"] for r in plus])
+    assert all(r["moved"] for r in plus)
+    assert abs(mean_lp - (-21.15)) < 0.6, mean_lp     # notebook cell 12: -21.15 (measured here -20.87)
+    assert abs(max_lp - (-19.67)) < 0.9, max_lp       # notebook cell 12: -19.67 (measured here -19.4)
+    assert abs(length - 3.298) < 0.45, length         # notebook cell 12: 3.298  (measured here 3.14)
+    minus = [mod.run(steps=200, seed=s, device=str(gpu), grad_k_sign=-1.0) for s in range(3)]
+    var = np.mean([r["variance_per_timestep"] for r in minus], axis=0)
+    assert np.isfinite(var).all() and var.min() > 1e-2       # no collapse (the notebook's RBF baseline ends at 1e-9)
+    assert var[[0, -1]].max() < 0.5 * var[1:-1].min()        # ends pinned more tightly than the interior (cell 9)
+    assert 0.4 < var[1:-1].min() and var[1:-1].max() < 1.5   # interior variances in cell 9's range 0.44..1.28
+    assert 3 <= int(np.argmax(var)) <= 6                     # maximum mid-path (cell 9: t = 4)
