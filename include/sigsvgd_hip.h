@@ -65,6 +65,10 @@ extern "C" {
 #define SIGSVGD_FLAG_SYM 2u          /* sigkernel sym=True backward weighting: go + go^T (A==B) */
 #define SIGSVGD_FLAG_Y_IS_X 4u       /* caller guarantees Y aliases X (same values): lets the   */
                                      /* library solve each unordered pair once                  */
+#define SIGSVGD_FLAG_STORED_FORWARD 32u /* long paths (65 <= T <= 128): use the banded kernel, which keeps the forward     */
+                                       /* solution (gram_band.hip) instead of regenerating it: no limit on the roughness  */
+                                       /* of the paths, at 2-3x the time of the streaming kernel on smooth ones.  This is  */
+                                       /* where callers send the launches the streaming kernel declined (NaN gradients).   */
 #define SIGSVGD_FLAG_WS_CLEAN 16u     /* the caller guarantees that the workspace is ZERO on entry (fresh, or left  */
                                       /* by an earlier call with this flag); honoured by the register-resident       */
                                       /* gradient launches (dyadic order 0, T <= 64), which then issue no memset and */

@@ -90,7 +90,7 @@ def _prep_paths(X: torch.Tensor, Y: torch.Tensor):
     return X.detach().contiguous(), Y.detach().contiguous()
 
 
-def _flags(naive: bool, sym: bool, y_is_x: bool, force_generic: bool) -> int:
+def _flags(naive: bool, sym: bool, y_is_x: bool, force_generic: bool, stored_forward: bool = False) -> int:
     f = 0
     if naive:
         f |= _lib.FLAG_NAIVE_SOLVER
@@ -100,6 +100,8 @@ def _flags(naive: bool, sym: bool, y_is_x: bool, force_generic: bool) -> int:
         f |= _lib.FLAG_Y_IS_X
     if force_generic:
         f |= _lib.FLAG_FORCE_GENERIC
+    if stored_forward:
+        f |= _lib.FLAG_STORED_FORWARD
     return f
 
 
@@ -138,26 +140,28 @@ def _is_streaming_shape(T: int, d: int, dyadic_order: int, static_kind: int, nai
 def gram_fwd_bwd(X, Y, inv_h: float, dyadic_order: int = 0, static_kind: int = _lib.STATIC_RBF,
                  grad_out: Optional[torch.Tensor] = None, naive: bool = False, sym: bool = False,
                  y_is_x: bool = False, force_generic: bool = False,
-                 check_regime: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
+                 check_regime: bool = True, stored_forward: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
     """(K[A,B], gradX[A,T,d]) with gradX = d sum(grad_out*K)/dX (first slot); grad_out None = ones.
 
     check_regime: long paths (65 <= T <= 128) run on the streaming kernel, which regenerates the forward
     solution backwards and returns NaN gradients for the pairs whose increments exceed STREAM_GMAX (very
     rough paths, typically a path against itself).  With check_regime the result is inspected (one scalar
-    read-back) and, if the guard fired on finite inputs, the launch is repeated on the coverage kernel,
-    which keeps the forward solution.  Skipped for T <= 64."""
+    read-back) and, if the guard fired on finite inputs, the launch is repeated on the banded kernel
+    (`stored_forward=True`, csrc/gram_band.hip), which keeps the forward solution and has no such limit --
+    2-3x the streaming kernel's time, not the 30x of the coverage kernel.  Skipped for T <= 64."""
     L = _lib.load()
     dev = _require_gpu(X, Y, grad_out)
     Xc, Yc = _prep_paths(X, Y)
     A, T, d = Xc.shape
     B = Yc.shape[0]
-    guarded = check_regime and not force_generic and _is_streaming_shape(T, d, dyadic_order, static_kind, naive)
+    guarded = (check_regime and not force_generic and not stored_forward
+               and _is_streaming_shape(T, d, dyadic_order, static_kind, naive))
     go = None
     if grad_out is not None:
         if tuple(grad_out.shape) != (A, B):
             raise ValueError(f"grad_out must be [{A},{B}], got {tuple(grad_out.shape)}")
         go = grad_out.detach().to(Xc.dtype).contiguous()
-    flags = _flags(naive, sym, y_is_x, force_generic)
+    flags = _flags(naive, sym, y_is_x, force_generic, stored_forward)
     nbytes = ctypes.c_size_t(0)
     _lib.check(L.sigsvgd_gram_workspace_bytes(A, B, T, d, dyadic_order, 1, flags, ctypes.byref(nbytes)),
                "gram_workspace_bytes")
@@ -178,8 +182,22 @@ def gram_fwd_bwd(X, Y, inv_h: float, dyadic_order: int = 0, static_kind: int = _
         _WS_CLEAN.pop((dev.index, torch.cuda.current_stream(dev).cuda_stream), None)
     _lib.check(rc, "gram_fwd_bwd")
     if guarded and bool(torch.isnan(gX).any()) and bool(torch.isfinite(Xc).all()) and bool(torch.isfinite(Yc).all()):
-        return gram_fwd_bwd(X, Y, inv_h, dyadic_order, static_kind, grad_out, naive, sym, y_is_x, True, False)
+        _warn_rough_once()
+        # ordered pairs on the banded kernel (its symmetric variant is the slower one at present)
+        return gram_fwd_bwd(X, Y, inv_h, dyadic_order, static_kind, grad_out, naive, sym, False, False, False, True)
     return K, gX
+
+
+_ROUGH_WARNED = [False]
+
+
+def _warn_rough_once():
+    if not _ROUGH_WARNED[0]:
+        _ROUGH_WARNED[0] = True
+        import warnings
+
+        warnings.warn("sigsvgd_amd: the long-path streaming kernel declined pairs with very rough increments; such "
+                      "launches are repeated on the stored-forward kernel (2-3x slower)", RuntimeWarning)
 
 
 def svgd_phi(K, score, grad_k, mask=None, X=None, lr: Optional[float] = None, adagrad_state=None,

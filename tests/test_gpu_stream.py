@@ -120,3 +120,25 @@ def test_stream_symmetric_large_property(gpu):
     assert _rel(K.cpu().numpy(), Ko.double().cpu().numpy()) < 1e-6
     assert _rel(g.cpu().numpy(), g_o.double().cpu().numpy()) < 1e-5
     assert torch.isfinite(g).all()
+
+
+@pytest.mark.parametrize("A,B,T,d,sym,scale", [(2, 3, 128, 14, False, 0.05), (5, 5, 128, 14, True, 0.05), (3, 2, 65, 3, False, 0.05),
+                                               (4, 4, 100, 7, True, 0.05), (6, 6, 66, 2, True, 0.05), (4, 4, 128, 14, True, 0.15),
+                                               (3, 5, 97, 5, False, 0.3)])
+def test_banded_stored_forward_kernel(gpu, A, B, T, d, sym, scale):
+    """gram_band.hip (SIGSVGD_FLAG_STORED_FORWARD): the long-path kernel that keeps the forward solution, on smooth AND
+    rough paths (scale 0.15 / 0.3: increments far beyond what the streaming kernel accepts), ordered and symmetric,
+    against the C oracle; K also from the forward-only launch of the default kernel."""
+    from sigsvgd_amd import ops
+
+    rng = np.random.default_rng(7)
+    X = np.cumsum(scale * rng.standard_normal((A, T, d)), axis=1).astype(np.float32)
+    Y = X if sym else np.cumsum(scale * rng.standard_normal((B, T, d)), axis=1).astype(np.float32)
+    Kref, gref = C.gram_fwd_bwd(X, Y, 1.0, 0)
+    Xg, Yg = torch.as_tensor(X, device=gpu), torch.as_tensor(Y, device=gpu)
+    K, g = ops.gram_fwd_bwd(Xg, Xg if sym else Yg, 1.0, y_is_x=sym, stored_forward=True)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(g).all())
+    assert _rel(K.cpu().numpy(), Kref) < TOL and _rel(g.cpu().numpy(), gref) < TOL
+    if sym:
+        assert np.array_equal(K.cpu().numpy(), K.cpu().numpy().T)
