@@ -20,6 +20,8 @@
  *   sigsvgd_vec_sqdist     src/utils/math.py:69-86 pw_dist_sq, :116-144 scaled_pw_dist_sq
  *   sigsvgd_vec_kernel     src/kernels/_kernels.py:64-299 GaussianKernel / ScaledGaussianKernel /
  *                          IMQKernel / ScaledIMQKernel: K and d_K.sum(1) without the [A,B,D] tensor
+ *   sigsvgd_obstacle_cost  batch_cost_fn of examples/script_planning_obstacle_field.py:113-126 (spline samples,
+ *                          obstacle field, path length) and its gradient w.r.t. the knots (torch autograd there)
  *   sigsvgd_signature      signatory.signature(path, depth, basepoint) [third-party, absent] as
  *                          called by PathSigKernel, src/kernels/_traj_kernels.py:124-125
  *
@@ -44,7 +46,7 @@
 extern "C" {
 #endif
 
-#define SIGSVGD_ABI_VERSION 4
+#define SIGSVGD_ABI_VERSION 5
 
 /* dtype */
 #define SIGSVGD_F32 0
@@ -173,6 +175,19 @@ int sigsvgd_vec_sqdist(const void *X, const void *Y, const void *XM, const void 
 int sigsvgd_vec_kernel(const void *sq, const void *XM, const void *YM, const void *grad_out, int A, int B,
                        int D, int dtype, int kind, double inv_h2, double grad_scale, void *K_out,
                        void *dK_out, void *stream);
+
+/* ---- trajectory cost in front of the path -----------------------------------------------
+ * The reference's planning cost, examples/script_planning_obstacle_field.py:113-126, with its analytic gradient:
+ *   knots_i = [start, x_i[0..knots-1], target]  ->  traj_i = basis[samples, knots+2] @ knots_i   (natural cubic
+ *   spline samples for fixed knot times, :18-23; pass the identity for use_splines=False)
+ *   cost_i  = w_obstacle * sum_t p(traj_i[t]) + || w_length * (traj_i[1:] - traj_i[:-1]) ||_F
+ *   p(z)    = sum_m exp(log_weights[m]) prod_c Normal(z_c; mean[m,c], std[m,c])   (the script's obstacle field, :363-370)
+ * Outputs: cost[N], traj[N,samples,d] (nullable), grad_x[N,knots,d] = d cost_i / d x_i (nullable; samples <= 128).
+ * All fp32; d <= 16, knots + 2 <= 64, samples <= 1024. */
+int sigsvgd_obstacle_cost(const float *x, int N, int knots, int d, const float *start, const float *target,
+                          const float *basis, int samples, const float *log_weights, const float *mean, const float *std,
+                          int components, float w_obstacle, float w_length, float *cost, float *traj, float *grad_x,
+                          void *stream);
 
 /* ---- truncated path signature ----------------------------------------------------
  * out[N, C + C^2 + ... + C^depth] = signature of the piecewise-linear path X[N,L,C] (levels

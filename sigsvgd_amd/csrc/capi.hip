@@ -34,6 +34,9 @@ int vec_sqdist_launch(const void *X, const void *Y, const void *XM, const void *
 int vec_kgrad_launch(const void *sq, const void *XM, const void *YM, const void *go, int A, int B, int D, int dtype,
                      int kind, double inv_h2, double grad_scale, void *K, void *dK, hipStream_t stream);
 long long signature_channels(int C, int depth);
+int obstacle_cost_launch(const float *x, int N, int Kx, int d, const float *start, const float *target, const float *basis,
+                         int Tt, const float *logw, const float *mean, const float *stdv, int M, float w_obst, float w_len,
+                         float *cost, float *traj, float *grad_x, hipStream_t stream);
 int signature_launch(const void *X, int N, int L, int C, int depth, int basepoint, int dtype, void *out,
                      hipStream_t stream);
 
@@ -271,6 +274,16 @@ int sigsvgd_vec_kernel(const void *sq, const void *XM, const void *YM, const voi
     }
     return vec_kgrad_launch(sq, XM, YM, grad_out, A, B, D, dtype, kind, inv_h2, grad_scale, K_out, dK_out,
                             static_cast<hipStream_t>(stream));
+}
+
+int sigsvgd_obstacle_cost(const float *x, int N, int knots, int d, const float *start, const float *target,
+                          const float *basis, int samples, const float *log_weights, const float *mean, const float *std,
+                          int components, float w_obstacle, float w_length, float *cost, float *traj, float *grad_x,
+                          void *stream)
+{
+    Range range("sigsvgd_obstacle_cost");
+    return obstacle_cost_launch(x, N, knots, d, start, target, basis, samples, log_weights, mean, std, components,
+                                w_obstacle, w_length, cost, traj, grad_x, static_cast<hipStream_t>(stream));
 }
 
 int sigsvgd_signature(const void *X, int N, int L, int C, int depth, int basepoint, int dtype, void *out,

@@ -429,3 +429,39 @@ def signature(X, depth: int, basepoint: bool = False) -> torch.Tensor:
                                  _stream_ptr(dev))
     _lib.check(rc, "signature")
     return out
+
+
+def obstacle_cost(x, start, target, basis, log_weights, mean, std, w_obstacle: float = 1.0, w_length: float = 1.0,
+                  want_traj: bool = True, want_grad: bool = True):
+    """Planning cost of the reference's obstacle-field script on the device with its analytic gradient
+    (`sigsvgd_obstacle_cost`; examples/script_planning_obstacle_field.py:113-126).
+
+    x [N, knots, d] interior knots, start/target [d], basis [samples, knots + 2], mixture log_weights [M]
+    (normalised), mean/std [M, d].  Returns (cost [N], traj [N, samples, d] or None, d cost / d x or None)."""
+    L = _lib.load()
+    dev = _require_gpu(x, basis, mean, std, log_weights, start, target)
+    if x.dim() != 3:
+        raise ValueError(f"knots must be [batch, knots, channels]; got {tuple(x.shape)}")
+    N, Kx, d = x.shape
+    if N == 0:
+        raise ValueError("empty batch")
+    f = lambda t: t.detach().to(torch.float32).contiguous()
+    xc, bc, mc, sc, lw, st, tg = f(x), f(basis), f(mean), f(std), f(log_weights), f(start).reshape(-1), f(target).reshape(-1)
+    if bc.dim() != 2 or bc.shape[1] != Kx + 2:
+        raise ValueError(f"basis must be [samples, {Kx + 2}]; got {tuple(bc.shape)}")
+    if mc.shape != sc.shape or mc.dim() != 2 or mc.shape[1] != d or lw.numel() != mc.shape[0]:
+        raise ValueError(f"mixture mean/std must be [components, {d}] with one log-weight each; got {tuple(mc.shape)}, "
+                         f"{tuple(sc.shape)}, {tuple(lw.shape)}")
+    if st.numel() != d or tg.numel() != d:
+        raise ValueError(f"start and target poses must have {d} channels")
+    Tt = bc.shape[0]
+    cost = torch.empty(N, dtype=torch.float32, device=dev)
+    traj = torch.empty((N, Tt, d), dtype=torch.float32, device=dev) if want_traj else None
+    grad = torch.empty((N, Kx, d), dtype=torch.float32, device=dev) if want_grad else None
+    with torch.cuda.device(dev):
+        rc = L.sigsvgd_obstacle_cost(xc.data_ptr(), N, Kx, d, st.data_ptr(), tg.data_ptr(), bc.data_ptr(), Tt,
+                                     lw.data_ptr(), mc.data_ptr(), sc.data_ptr(), mc.shape[0], float(w_obstacle),
+                                     float(w_length), cost.data_ptr(), traj.data_ptr() if want_traj else None,
+                                     grad.data_ptr() if want_grad else None, _stream_ptr(dev))
+    _lib.check(rc, "obstacle_cost")
+    return cost, traj, grad

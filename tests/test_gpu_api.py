@@ -509,3 +509,81 @@ def test_reference_notebook_experiment_statistics(gpu):
     assert var[[0, -1]].max() < 0.5 * var[1:-1].min()        # ends pinned more tightly than the interior (cell 9)
     assert 0.4 < var[1:-1].min() and var[1:-1].max() < 1.5   # interior variances in cell 9's range 0.44..1.28
     assert 3 <= int(np.argmax(var)) <= 6                     # maximum mid-path (cell 9: t = 4)
+
+
+# ---- the planning cost in front of the path (sigsvgd_obstacle_cost) --------------------------------------------
+@pytest.mark.parametrize("N,Kx,d,M,Tt,use_splines", [(20, 5, 2, 10, 100, True), (7, 1, 3, 1, 17, True),
+                                                     (33, 10, 7, 50, 128, True), (5, 6, 2, 4, 8, False),
+                                                     (3, 0, 2, 2, 64, True)])
+def test_obstacle_cost_kernel_against_the_oracle(gpu, N, Kx, d, M, Tt, use_splines):
+    """HIP cost / trajectories / gradient against the fp64 restatement of script_planning_obstacle_field.py:113-126
+    (torch.distributions field + scipy natural spline + autograd)."""
+    from oracle import cost_oracle as CO
+    from sigsvgd_amd.costs import ObstacleFieldCost
+
+    g = torch.Generator().manual_seed(N * 131 + Kx)
+    mean = 0.5 + 4.0 * torch.rand(M, d, generator=g)
+    std = 0.2 + 0.5 * torch.rand(M, d, generator=g)
+    wts = 0.5 + torch.rand(M, generator=g)
+    start, target = 0.5 * torch.rand(d, generator=g), 4.5 + 0.5 * torch.rand(d, generator=g)
+    x = torch.linspace(0.5, 4.5, Kx)[None, :, None] + 0.4 * torch.randn(N, Kx, d, generator=g)
+    if not use_splines:
+        Tt = Kx + 2
+    w = (1.3, 0.8)
+    cref, tref, gref = CO.cost_and_grad(x, wts, mean, std, start, target, Tt, w, use_splines)
+    cost_fn = ObstacleFieldCost(wts.to(gpu), mean.to(gpu), std.to(gpu), start, target, Tt, w, use_splines)
+    xg = x.to(gpu).requires_grad_(True)
+    cost, aux = cost_fn(xg)
+    (gx,) = torch.autograd.grad(-cost.sum(), xg)
+    rel = lambda a, b: float(np.abs(a.detach().cpu().numpy() - b).max() / max(np.abs(b).max(), 1e-30))
+    assert rel(aux["trajectories"], tref) < 2e-6
+    assert rel(cost, cref) < 1e-5
+    if Kx:
+        assert rel(gx, -gref) < 1e-5
+    c2, t2, score = cost_fn.cost_and_score(x.to(gpu))
+    assert torch.equal(c2, cost.detach()) and torch.equal(t2, aux["trajectories"])
+    if Kx:
+        assert torch.equal(score, gx)
+
+
+def test_obstacle_cost_in_the_score_estimator(gpu):
+    """The device cost plugs into ScoreEstimator as the script's cost_fn does (grad_log_p = -d cost / d x)."""
+    from oracle import cost_oracle as CO
+    from sigsvgd_amd.costs import ObstacleFieldCost
+    from sigsvgd_amd.inference import ScoreEstimator
+
+    g = torch.Generator().manual_seed(5)
+    mean, std, wts = 0.5 + 4 * torch.rand(8, 2, generator=g), 0.3 * torch.ones(8, 2), torch.ones(8)
+    start, target = torch.tensor([0.25, 0.75]), torch.tensor([4.75, 4.5])
+    x = (torch.linspace(0.5, 4.5, 5)[None, :, None] + 0.4 * torch.randn(16, 5, 2, generator=g)).to(gpu)
+    cost_fn = ObstacleFieldCost(wts.to(gpu), mean.to(gpu), std.to(gpu), start, target)
+    est = ScoreEstimator(None, cost_fn, {}, ctx={"device": gpu})
+    grad_log_p, dct = est.sgd_score(x.requires_grad_(True))
+    _, _, gref = CO.cost_and_grad(x.detach().cpu(), wts, mean, std, start, target)
+    assert float(np.abs(grad_log_p.cpu().numpy() + gref).max() / np.abs(gref).max()) < 1e-5
+    assert dct["trajectories"].shape == (16, 100, 2)
+
+
+def test_obstacle_cost_rejects_unsupported_shapes(gpu):
+    from sigsvgd_amd import ops
+
+    z = lambda *s: torch.zeros(*s, device=gpu)
+    with pytest.raises(RuntimeError, match="unsupported shape"):
+        ops.obstacle_cost(z(2, 3, 17), z(17), z(17), z(10, 5), z(1), z(1, 17), 1 + z(1, 17))
+    with pytest.raises(RuntimeError, match="gradient output supports"):
+        ops.obstacle_cost(z(2, 3, 2), z(2), z(2), z(200, 5), z(1), z(1, 2), 1 + z(1, 2))
+    with pytest.raises(ValueError, match="basis must be"):
+        ops.obstacle_cost(z(2, 3, 2), z(2), z(2), z(10, 4), z(1), z(1, 2), 1 + z(1, 2))
+
+
+def test_planning_example_runs_on_the_device_and_lowers_the_cost(gpu):
+    import importlib.util
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "planning_obstacle_field.py")
+    spec = importlib.util.spec_from_file_location("planning_obstacle_field", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = mod.run(steps=60, n_obst=10, seed=0, device=str(gpu))
+    assert out["trajectories"].shape == (20, 100, 2) and bool(torch.isfinite(out["trajectories"]).all())
+    assert out["cost_final"] < out["cost_initial"]
