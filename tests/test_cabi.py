@@ -47,9 +47,9 @@ def test_abi_version(lib):
 
 def test_workspace_query_is_host_only(lib):
     n = ctypes.c_size_t(123)
-    # fast path (n=0, T<=64): fp64 accumulation buffer A*T*d*8 (+ alignment slack)
+    # fast path (n=0, T<=64): fp64 row-side + fp32 column-side accumulators A*T*d*(8+4) (+ queue and alignment slack)
     assert lib.sigsvgd_gram_workspace_bytes(1024, 1024, 64, 7, 0, 1, 0, ctypes.byref(n)) == 0
-    assert 1024 * 64 * 7 * 8 <= n.value <= 1024 * 64 * 7 * 8 + 8192
+    assert 1024 * 64 * 7 * 12 <= n.value <= 1024 * 64 * 7 * 12 + 8192
     # forward only: just the work-queue counters
     assert lib.sigsvgd_gram_workspace_bytes(1024, 1024, 64, 7, 0, 0, 0, ctypes.byref(n)) == 0 and 0 < n.value <= 4096
     # generic path (dyadic refinement): partial slabs + per-workgroup forward-solution scratch
