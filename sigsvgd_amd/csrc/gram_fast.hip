@@ -146,91 +146,116 @@ __device__ __forceinline__ float add_rol1(float acc, float v)
 __device__ __forceinline__ float dpp_shr1_zero(float v) { return __int_as_float(dpp_shr1_z(__float_as_int(v))); }
 
 // ---- one step of a PDE sweep, hand-scheduled (fp32 difference form, see phase 2 in the kernel) ------------------
-// Every vector instruction of a step is listed here because three properties of the step are scheduling
-// properties: (1) no scalar instruction inside the sweep -- measured on MI355X (scripts/micro/valu_model.hip) a
-// scalar instruction between vector ones costs the wave ~8 cycles, so the EXEC save/restore hipcc wraps around an
-// `if (active)` body cost as much as three vector instructions per step; inactive lanes are handled with two
-// v_cndmask instead (a zero increment leaves V, hence the row, unchanged; a lane whose row has not started keeps
-// K = 1 on its own because its upper neighbour still holds 1; a finished lane's value is never read again);
-// (2) the compare and the counter update sit between the previous step's write of `cur` and the DPP read of it
-// (2 wait states: the gfx9 VALU-write -> DPP-read hazard, which hipcc does not pad inside asm);
-// (3) the two independent instructions are placed inside the dependent chain dpp -> t -> w -> y -> V -> cur.
-//   cnt: sigma - (first active sigma of this lane), compared unsigned against P (the number of cells per row).
-// Eight steps form ONE asm statement (hipcc pads every asm statement with an `s_nop 0`, an issue slot of its own).
-#define SIG_FWD_STEP(UP, DIAG, G, KSL)                                                        \
-    "v_cmp_gt_u32 vcc, %[P], %[cnt]\n\t"                                                      \
-    "v_add_u32 %[cnt], 1, %[cnt]\n\t"                                                         \
+// Every instruction of a step is listed here because the properties that make it fast are scheduling properties.
+// Lanes outside the grid on a step (about half of them, averaged over a sweep) are switched off through EXEC, not
+// through v_cmp / v_cndmask: the window of active lanes of anti-diagonal sigma, rows max(0, sigma-P+1) ..
+// min(sigma, P-1), is a 64-bit constant per (P, sigma), read from a table in constant memory with scalar loads
+// (SWEEP_MASK below) and moved into EXEC with one s_mov_b64.  Measured on MI355X at the kernel's occupancy
+// (scripts/micro/exec_step.hip, two waves per SIMD): the v_cmp + 2 x v_cndmask step (11 VALU) 20.2 ns per step and
+// wave, the EXEC step (8 VALU + 2 SALU) 10.4-11.0 ns -- the scalar moves issue in the shadow of the other wave's
+// vector instructions, while the VCC round trip of the compare form stalls the chain far beyond its three
+// instructions.  Per step:
+//   s_mov exec,-1 ; DPP shift of `cur` into UP for EVERY lane (lane l reads l-1; a lane that has not started reads the
+//     1.0 its neighbour still holds, so its diagonal operand is right when it starts; lane 0 keeps the boundary 1.0)
+//   s_mov exec,window ; the stencil in difference form (5 VALU), the K_fwd slot store, only for lanes inside the grid:
+//     a lane before its row starts keeps cur = 1, a finished lane keeps its last value (lane P-1: K[P,P]), and a
+//     slot without a grid cell is never written (phase 4 relies on their zeros).
+// The instruction after `v_add cur` and the s_mov are the 2 wait states of the gfx9 VALU-write -> DPP-read hazard
+// (hipcc does not pad inside asm; scripts/check_dpp_hazards.py checks the built library).
+// Eight steps form ONE asm statement (hipcc pads every asm statement with an `s_nop 0`, an issue slot of its own);
+// EXEC is all ones again when the statement ends (the code around it may reload spilled registers).
+struct SweepMasks {
+    unsigned long long m[64][128]; // [P][sigma]
+    constexpr SweepMasks() : m()
+    {
+        for (int P = 1; P < 64; ++P)
+            for (int s = 0; s <= 2 * P - 2; ++s) {
+                const int lo = s - P + 1 > 0 ? s - P + 1 : 0, hi = s < P - 1 ? s : P - 1;
+                unsigned long long w = 0;
+                for (int l = lo; l <= hi; ++l) w |= 1ull << l;
+                m[P][s] = w;
+            }
+    }
+};
+__constant__ const SweepMasks SWEEP_MASK = SweepMasks();
+
+#define SIG_FWD_STEP(UP, DIAG, G, KSL, M)                                                     \
+    "s_mov_b64 exec, -1\n\t"                                                                  \
     "v_mov_b32_dpp %[" UP "], %[cur] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"               \
-    "v_cndmask_b32 %[ge], 0, %[" G "], vcc\n\t"                                               \
+    "s_mov_b64 exec, %[" M "]\n\t"                                                            \
     "v_add_f32 %[t], %[cur], %[" UP "]\n\t"                                                   \
     "v_mul_f32 %[y], %[r3], %[t]\n\t"                                                         \
     "v_add_f32 %[t], %[t], %[" DIAG "]\n\t"                                                   \
-    "v_fmac_f32 %[y], %[t], %[ge]\n\t" KSL "v_fmac_f32 %[V], %[ge], %[y]\n\t"                \
-    "v_add_f32 %[cur], %[" UP "], %[V]\n\t"
-#define SIG_FWD_KSL(DIAG, K) "v_cndmask_b32 %[" K "], %[" K "], %[" DIAG "], vcc\n\t"
-#define SIG_REV_STEP(DN, DDIAG, G, K)                                                         \
-    "v_cmp_gt_u32 vcc, %[P], %[cnt]\n\t"                                                      \
-    "v_add_u32 %[cnt], -1, %[cnt]\n\t"                                                        \
+    "v_fmac_f32 %[y], %[t], %[" G "]\n\t"                                                     \
+    "v_fmac_f32 %[V], %[" G "], %[y]\n\t"                                                     \
+    "v_add_f32 %[cur], %[" UP "], %[V]\n\t" KSL
+#define SIG_FWD_KSL(DIAG, K) "v_mov_b32 %[" K "], %[" DIAG "]\n\t"
+#define SIG_FWD_NOKSL "s_nop 0\n\t"
+#define SIG_REV_STEP(DN, DDIAG, G, K, M)                                                      \
+    "s_mov_b64 exec, -1\n\t"                                                                  \
     "v_mov_b32_dpp %[" DN "], %[cur] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"               \
-    "v_cndmask_b32 %[ge], 0, %[" G "], vcc\n\t"                                               \
+    "s_mov_b64 exec, %[" M "]\n\t"                                                            \
     "v_add_f32 %[t], %[cur], %[" DN "]\n\t"                                                   \
     "v_mul_f32 %[y], %[r3], %[t]\n\t"                                                         \
     "v_add_f32 %[t], %[t], %[" DDIAG "]\n\t"                                                  \
-    "v_fmac_f32 %[y], %[t], %[ge]\n\t"                                                        \
-    "v_mul_f32 %[sv], %[" K "], %[" DDIAG "]\n\t"                                             \
-    "v_fmac_f32 %[V], %[ge], %[y]\n\t"                                                        \
-    "v_cndmask_b32 %[" K "], %[" K "], %[sv], vcc\n\t"                                        \
-    "v_add_f32 %[cur], %[" DN "], %[V]\n\t"
+    "v_fmac_f32 %[y], %[t], %[" G "]\n\t"                                                     \
+    "v_fmac_f32 %[V], %[" G "], %[y]\n\t"                                                     \
+    "v_add_f32 %[cur], %[" DN "], %[V]\n\t"                                                   \
+    "v_mul_f32 %[" K "], %[" K "], %[" DDIAG "]\n\t"
 
-// steps k0 .. k0+7 of the forward sweep (k0 even): g, ksl point at slots k0..k0+7
+// steps sigma0 .. sigma0+7 of the forward sweep (sigma0 even): g, ksl point at slots sigma0 & 63 ..; mk at the
+// windows of sigma0 ..
 template <bool STORE>
 __device__ __forceinline__ void sweep_fwd8(float &cur, float &upA, float &upB, float &V, const float *g, float *ksl,
-                                           int &cnt, const int P, const float r3)
+                                           const unsigned long long *mk, const float r3)
 {
-    float ge, t, y;
+    float t, y;
+    const unsigned long long m0 = mk[0], m1 = mk[1], m2 = mk[2], m3 = mk[3], m4 = mk[4], m5 = mk[5], m6 = mk[6], m7 = mk[7];
     if (STORE)
-        asm volatile(SIG_FWD_STEP("upA", "upB", "g0", SIG_FWD_KSL("upB", "k0"))
-                     SIG_FWD_STEP("upB", "upA", "g1", SIG_FWD_KSL("upA", "k1"))
-                     SIG_FWD_STEP("upA", "upB", "g2", SIG_FWD_KSL("upB", "k2"))
-                     SIG_FWD_STEP("upB", "upA", "g3", SIG_FWD_KSL("upA", "k3"))
-                     SIG_FWD_STEP("upA", "upB", "g4", SIG_FWD_KSL("upB", "k4"))
-                     SIG_FWD_STEP("upB", "upA", "g5", SIG_FWD_KSL("upA", "k5"))
-                     SIG_FWD_STEP("upA", "upB", "g6", SIG_FWD_KSL("upB", "k6"))
-                     SIG_FWD_STEP("upB", "upA", "g7", SIG_FWD_KSL("upA", "k7"))
-                     : [cur] "+v"(cur), [upA] "+v"(upA), [upB] "+v"(upB), [V] "+v"(V), [cnt] "+v"(cnt),
-                       [ge] "=&v"(ge), [t] "=&v"(t), [y] "=&v"(y), [k0] "+v"(ksl[0]), [k1] "+v"(ksl[1]),
-                       [k2] "+v"(ksl[2]), [k3] "+v"(ksl[3]), [k4] "+v"(ksl[4]), [k5] "+v"(ksl[5]), [k6] "+v"(ksl[6]),
-                       [k7] "+v"(ksl[7])
+        asm volatile(SIG_FWD_STEP("upA", "upB", "g0", SIG_FWD_KSL("upB", "k0"), "m0")
+                     SIG_FWD_STEP("upB", "upA", "g1", SIG_FWD_KSL("upA", "k1"), "m1")
+                     SIG_FWD_STEP("upA", "upB", "g2", SIG_FWD_KSL("upB", "k2"), "m2")
+                     SIG_FWD_STEP("upB", "upA", "g3", SIG_FWD_KSL("upA", "k3"), "m3")
+                     SIG_FWD_STEP("upA", "upB", "g4", SIG_FWD_KSL("upB", "k4"), "m4")
+                     SIG_FWD_STEP("upB", "upA", "g5", SIG_FWD_KSL("upA", "k5"), "m5")
+                     SIG_FWD_STEP("upA", "upB", "g6", SIG_FWD_KSL("upB", "k6"), "m6")
+                     SIG_FWD_STEP("upB", "upA", "g7", SIG_FWD_KSL("upA", "k7"), "m7")
+                     "s_mov_b64 exec, -1\n\t"
+                     : [cur] "+v"(cur), [upA] "+v"(upA), [upB] "+v"(upB), [V] "+v"(V), [t] "=&v"(t), [y] "=&v"(y),
+                       [k0] "+v"(ksl[0]), [k1] "+v"(ksl[1]), [k2] "+v"(ksl[2]), [k3] "+v"(ksl[3]), [k4] "+v"(ksl[4]),
+                       [k5] "+v"(ksl[5]), [k6] "+v"(ksl[6]), [k7] "+v"(ksl[7])
                      : [g0] "v"(g[0]), [g1] "v"(g[1]), [g2] "v"(g[2]), [g3] "v"(g[3]), [g4] "v"(g[4]), [g5] "v"(g[5]),
-                       [g6] "v"(g[6]), [g7] "v"(g[7]), [P] "s"(P), [r3] "s"(r3)
-                     : "vcc");
+                       [g6] "v"(g[6]), [g7] "v"(g[7]), [r3] "s"(r3), [m0] "s"(m0), [m1] "s"(m1), [m2] "s"(m2),
+                       [m3] "s"(m3), [m4] "s"(m4), [m5] "s"(m5), [m6] "s"(m6), [m7] "s"(m7));
     else
-        asm volatile(SIG_FWD_STEP("upA", "upB", "g0", "") SIG_FWD_STEP("upB", "upA", "g1", "")
-                     SIG_FWD_STEP("upA", "upB", "g2", "") SIG_FWD_STEP("upB", "upA", "g3", "")
-                     SIG_FWD_STEP("upA", "upB", "g4", "") SIG_FWD_STEP("upB", "upA", "g5", "")
-                     SIG_FWD_STEP("upA", "upB", "g6", "") SIG_FWD_STEP("upB", "upA", "g7", "")
-                     : [cur] "+v"(cur), [upA] "+v"(upA), [upB] "+v"(upB), [V] "+v"(V), [cnt] "+v"(cnt),
-                       [ge] "=&v"(ge), [t] "=&v"(t), [y] "=&v"(y)
+        asm volatile(SIG_FWD_STEP("upA", "upB", "g0", SIG_FWD_NOKSL, "m0") SIG_FWD_STEP("upB", "upA", "g1", SIG_FWD_NOKSL, "m1")
+                     SIG_FWD_STEP("upA", "upB", "g2", SIG_FWD_NOKSL, "m2") SIG_FWD_STEP("upB", "upA", "g3", SIG_FWD_NOKSL, "m3")
+                     SIG_FWD_STEP("upA", "upB", "g4", SIG_FWD_NOKSL, "m4") SIG_FWD_STEP("upB", "upA", "g5", SIG_FWD_NOKSL, "m5")
+                     SIG_FWD_STEP("upA", "upB", "g6", SIG_FWD_NOKSL, "m6") SIG_FWD_STEP("upB", "upA", "g7", SIG_FWD_NOKSL, "m7")
+                     "s_mov_b64 exec, -1\n\t"
+                     : [cur] "+v"(cur), [upA] "+v"(upA), [upB] "+v"(upB), [V] "+v"(V), [t] "=&v"(t), [y] "=&v"(y)
                      : [g0] "v"(g[0]), [g1] "v"(g[1]), [g2] "v"(g[2]), [g3] "v"(g[3]), [g4] "v"(g[4]), [g5] "v"(g[5]),
-                       [g6] "v"(g[6]), [g7] "v"(g[7]), [P] "s"(P), [r3] "s"(r3)
-                     : "vcc");
+                       [g6] "v"(g[6]), [g7] "v"(g[7]), [r3] "s"(r3), [m0] "s"(m0), [m1] "s"(m1), [m2] "s"(m2),
+                       [m3] "s"(m3), [m4] "s"(m4), [m5] "s"(m5), [m6] "s"(m6), [m7] "s"(m7));
 }
-// steps k0+7 .. k0 of the reverse sweep (descending; k0 even): lower neighbour through wave_shl, S = K_fwd * U[l+1][q+1]
-// replaces K_fwd in its slot
+// steps sigma0+7 .. sigma0 of the reverse sweep (descending; sigma0 even): lower neighbour through wave_shl,
+// S = K_fwd * U[l+1][q+1] replaces K_fwd in its slot
 __device__ __forceinline__ void sweep_rev8(float &cur, float &dnA, float &dnB, float &V, const float *g, float *ksl,
-                                           int &cnt, const int P, const float r3)
+                                           const unsigned long long *mk, const float r3)
 {
-    float ge, t, y, sv;
-    asm volatile(SIG_REV_STEP("dnA", "dnB", "g7", "k7") SIG_REV_STEP("dnB", "dnA", "g6", "k6")
-                 SIG_REV_STEP("dnA", "dnB", "g5", "k5") SIG_REV_STEP("dnB", "dnA", "g4", "k4")
-                 SIG_REV_STEP("dnA", "dnB", "g3", "k3") SIG_REV_STEP("dnB", "dnA", "g2", "k2")
-                 SIG_REV_STEP("dnA", "dnB", "g1", "k1") SIG_REV_STEP("dnB", "dnA", "g0", "k0")
-                 : [cur] "+v"(cur), [dnA] "+v"(dnA), [dnB] "+v"(dnB), [V] "+v"(V), [cnt] "+v"(cnt), [ge] "=&v"(ge),
-                   [t] "=&v"(t), [y] "=&v"(y), [sv] "=&v"(sv), [k0] "+v"(ksl[0]), [k1] "+v"(ksl[1]), [k2] "+v"(ksl[2]),
-                   [k3] "+v"(ksl[3]), [k4] "+v"(ksl[4]), [k5] "+v"(ksl[5]), [k6] "+v"(ksl[6]), [k7] "+v"(ksl[7])
+    float t, y;
+    const unsigned long long m0 = mk[0], m1 = mk[1], m2 = mk[2], m3 = mk[3], m4 = mk[4], m5 = mk[5], m6 = mk[6], m7 = mk[7];
+    asm volatile(SIG_REV_STEP("dnA", "dnB", "g7", "k7", "m7") SIG_REV_STEP("dnB", "dnA", "g6", "k6", "m6")
+                 SIG_REV_STEP("dnA", "dnB", "g5", "k5", "m5") SIG_REV_STEP("dnB", "dnA", "g4", "k4", "m4")
+                 SIG_REV_STEP("dnA", "dnB", "g3", "k3", "m3") SIG_REV_STEP("dnB", "dnA", "g2", "k2", "m2")
+                 SIG_REV_STEP("dnA", "dnB", "g1", "k1", "m1") SIG_REV_STEP("dnB", "dnA", "g0", "k0", "m0")
+                 "s_mov_b64 exec, -1\n\t"
+                 : [cur] "+v"(cur), [dnA] "+v"(dnA), [dnB] "+v"(dnB), [V] "+v"(V), [t] "=&v"(t), [y] "=&v"(y),
+                   [k0] "+v"(ksl[0]), [k1] "+v"(ksl[1]), [k2] "+v"(ksl[2]), [k3] "+v"(ksl[3]), [k4] "+v"(ksl[4]),
+                   [k5] "+v"(ksl[5]), [k6] "+v"(ksl[6]), [k7] "+v"(ksl[7])
                  : [g0] "v"(g[0]), [g1] "v"(g[1]), [g2] "v"(g[2]), [g3] "v"(g[3]), [g4] "v"(g[4]), [g5] "v"(g[5]),
-                   [g6] "v"(g[6]), [g7] "v"(g[7]), [P] "s"(P), [r3] "s"(r3)
-                 : "vcc");
+                   [g6] "v"(g[6]), [g7] "v"(g[7]), [r3] "s"(r3), [m0] "s"(m0), [m1] "s"(m1), [m2] "s"(m2), [m3] "s"(m3),
+                   [m4] "s"(m4), [m5] "s"(m5), [m6] "s"(m6), [m7] "s"(m7));
 }
 
 // [slot][lane] image of G (then R*G) with row stride 65 floats: every in-sweep access is
@@ -262,7 +287,7 @@ __device__ __forceinline__ void store_any(void *base, size_t idx, double v, int 
 // LP: the last of the DPAD channels is padding (d == DPAD - 1, e.g. the 7-DoF arm at DPAD = 8): its FMA in the
 // static kernel and its travelling column sum are dropped.
 template <int DPAD, int NW, bool GRAD, bool SYM, bool LP>
-__global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(GRAD ? 1 : (DPAD == 4 ? 3 : 2), GRAD ? 2 : (DPAD == 4 ? 3 : 2)))) void gram_fast_kernel(FastArgs a)
 {
     constexpr int DC = LP ? DPAD - 1 : DPAD; // channels that can be non-zero
     constexpr int NT = NW * 64;
@@ -295,18 +320,15 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
     const int nJ = (a.B + a.JC - 1) / a.JC;
     int i = 0, j0 = 0, j1 = 0;
     bool row_ok = false;
-    const int lane_q = (lane < P) ? lane : 0x40000000; // rows without PDE cells never pass the range test below
     float *Gs = Gs_all + (GRAD ? wave * GS_WAVE : 0);
     const double inv_h = a.inv_h;
     const float m2h = (float)(-2.0 * inv_h * 3.46410161513775459); // the G image holds G / sqrt(12)
 
     // K_fwd, then S = K_fwd * U, of this lane's row, one slot per anti-diagonal (slot = (column + lane) & 63).
-    // Declared (and zeroed) once per kernel: the sweeps write a slot only while its cell is inside the grid, so
-    // the slots without a grid cell (column >= P or lane >= P) hold 0 for the whole launch and the phase-4 pass
-    // can read all 64 slots unmasked.
+    // Zeroed per pair right before the forward sweep (64 moves, 0.5 % of a pair): the sweeps write a slot only while
+    // its cell is inside the grid, so the slots without a grid cell (column >= P or lane >= P) read 0 in the phase-4
+    // pass, which takes all 64 slots unmasked -- and the 64 registers are free during staging and phase 1.
     float Ksl[64];
-#pragma unroll
-    for (int k = 0; k < 64; ++k) Ksl[k] = 0.f;
     double gacc[DPAD]; // per-lane fp64 accumulators of d sum_j w_ij k(x_i, y_j) / d x_i[lane, c]
     double xraw[DPAD]; // raw row of x_i owned by this lane (fp64 copy of the fp32/fp64 input; exact)
 
@@ -470,6 +492,7 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
                         // lane l+1 holds the same column difference one iteration later
                         const double nb = dpp_shl1_zero(rd);
                         Dsl[(t - 2) & 63] = (float)(nb - rdprev);
+                        asm volatile("" : "+v"(Dsl[(t - 2) & 63])); // formed HERE: hipcc otherwise sinks the fp64 difference to the sweep
                     }
                     rdprev = rd;
                     __builtin_amdgcn_sched_barrier(0); // one column per scheduling region: bounds live ranges
@@ -493,14 +516,18 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
                 // ends), so it needs no copy.
                 float cur = 1.f, upA = 1.f, upB = 1.f, V = 0.f;
                 const int smax = 2 * P - 2;
+                if (GRAD) {
+#pragma unroll
+                    for (int k = 0; k < 64; ++k) Ksl[k] = 0.f;
+                }
                 for (int rnd = 0; rnd < 2; ++rnd) {
                     if (rnd * 64 > smax) break;
                     float r3 = 1.7320508075688772f;
                     asm volatile("" : "+s"(r3)); // opaque per round: nothing of the step is round-invariant
-                    int cnt = rnd * 64 - lane_q; // sigma - lane at k = 0 (rows without cells: never < P)
+                    const unsigned long long *mk = SWEEP_MASK.m[P] + rnd * 64; // EXEC windows of this round
 #pragma unroll
                     for (int k0 = 0; k0 < 64; k0 += 8) // Ksl[k] <- K[l, q]
-                        sweep_fwd8<GRAD>(cur, upA, upB, V, &Dsl[k0], &Ksl[k0], cnt, P, r3);
+                        sweep_fwd8<GRAD>(cur, upA, upB, V, &Dsl[k0], &Ksl[k0], mk + k0, r3);
                 }
                 if (lane == P - 1) { // this lane's last value is K[P, P]
                     store_any(a.K, (size_t)i * a.B + j, (double)cur, io64);
@@ -578,11 +605,11 @@ __global__ __launch_bounds__(NW * 64) void gram_fast_kernel(FastArgs a)
                     asm volatile("" : "+v"(yfrow), "+v"(gsoff));
                     float r3 = 1.7320508075688772f;
                     asm volatile("" : "+s"(r3));
-                    int cnt = rnd * 64 + 63 - lane_q;
+                    const unsigned long long *mk = SWEEP_MASK.m[P] + rnd * 64;
                     // same difference form, V = U[l][q] - U[l+1][q] carried towards smaller q; `down` alternates between
                     // two registers like `up` (the diagonal neighbour U[l+1][q+1] is the lower neighbour one step ago)
 #pragma unroll
-                    for (int k0 = 56; k0 >= 0; k0 -= 8) sweep_rev8(cur, downA, downB, V, &Dsl[k0], &Ksl[k0], cnt, P, r3);
+                    for (int k0 = 56; k0 >= 0; k0 -= 8) sweep_rev8(cur, downA, downB, V, &Dsl[k0], &Ksl[k0], mk + k0, r3);
                 }
 
                 SIG_STAMP(3)
@@ -767,7 +794,7 @@ int launch_variant(const GramProblem &p, FastArgs &a, bool grad, bool sym)
     }
 #endif
     const long long total = nblocks(JC);
-    const long long resident = 256LL * (grad ? 1 : 3); // workgroups the chip holds at once (LDS / VGPR bound)
+    const long long resident = 256LL * (grad ? 1 : (NW == 4 ? (DPAD == 4 ? 3 : 2) : 1)); // workgroups the chip holds at once (LDS / VGPR bound)
     dim3 grid((unsigned)(total < resident ? total : resident), 1);
     dim3 block(NW * 64);
     constexpr bool HAS_LP = DPAD <= 8; // the d == DPAD - 1 instantiations exist for the 4- and 8-channel layouts
