@@ -38,7 +38,9 @@ if __name__ == "__main__":
     X, _ = synthetic_inputs(n, t, d)
     Xg = X.cuda()
     for _ in range(3):
-        if mode == "sym":
+        if t > 64:
+            ops.gram_fwd_bwd(Xg, Xg, 1.0, 0, y_is_x=(mode == "sym"), stored_forward=True)
+        elif mode == "sym":
             ops.gram_fwd_bwd(Xg, Xg, 1.0, 0, y_is_x=True)
         elif mode == "ordered":
             ops.gram_fwd_bwd(Xg, Xg, 1.0, 0)

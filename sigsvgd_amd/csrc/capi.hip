@@ -117,8 +117,8 @@ static int dispatch(const GramProblem &p)
     // long paths: the streaming kernel by default (fastest on smooth paths, refuses rough pairs with NaN gradients);
     // SIGSVGD_FLAG_STORED_FORWARD selects the banded kernel, which keeps the forward solution (any roughness)
     if (!(p.flags & SIGSVGD_FLAG_FORCE_GENERIC) && (p.flags & SIGSVGD_FLAG_STORED_FORWARD) &&
-        band_supported(p.A, p.B, p.T, p.d, p.n, p.kind, p.flags))
-        return band_launch(p);
+        quad_supported(p.A, p.B, p.T, p.d, p.n, p.kind, p.flags))
+        return getenv("SIGSVGD_BAND") ? band_launch(p) : quad_launch(p);
     if (!(p.flags & SIGSVGD_FLAG_FORCE_GENERIC) && stream_supported(p.A, p.B, p.T, p.d, p.n, p.kind, p.flags))
         return stream_launch(p);
     return generic_launch(p);
@@ -196,8 +196,8 @@ int sigsvgd_gram_sym_partial(const void *X, int N, int T, int d, int dtype, doub
                   K_partial, grad_partial, workspace, workspace_bytes, static_cast<hipStream_t>(stream)};
     Range range("sigsvgd_gram_sym_partial");
     if (!fast_supported(N, N, T, d, 0, static_kind, flags) && (flags & SIGSVGD_FLAG_STORED_FORWARD) &&
-        band_supported(N, N, T, d, 0, static_kind, flags))
-        return band_sym_partial(p, tile_offset, tile_stride, grad_partial);
+        quad_supported(N, N, T, d, 0, static_kind, flags))
+        return quad_sym_partial(p, tile_offset, tile_stride, grad_partial);
     if (!fast_supported(N, N, T, d, 0, static_kind, flags) && stream_supported(N, N, T, d, 0, static_kind, flags))
         return stream_sym_partial(p, tile_offset, tile_stride, grad_partial);
     return fast_sym_partial(p, tile_offset, tile_stride, grad_partial);

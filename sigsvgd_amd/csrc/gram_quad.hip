@@ -1,0 +1,850 @@
+// Signature-kernel Gram forward/backward for LONG paths: dyadic order 0, 65 <= T <= 128, d <= 16, RBF,
+// second-order stencil (BASELINE.json config C5: T = 128, d = 14).  STORED forward solution (nothing is regenerated
+// backwards, so there is no limit on how rough the paths may be), at the register budget and occupancy of the
+// 64-point kernel (gram_fast.hip): two wavefronts per SIMD, 64 + 64 slot registers.
+//
+// Mapping: one wavefront per trajectory pair.  The (T-1)^2 cell grid is cut into 2 x 2 QUADRANTS of <= 64 x 64 cells;
+// in quadrant (b, h) lane l owns cell row 64 b + l and sweeps the cell columns 64 h .. 64 h + 63 anti-diagonal by
+// anti-diagonal exactly as gram_fast.hip does (slot = (column + lane) & 63 for the increments D / sqrt(12) and for
+// K_fwd -> S = K_fwd * U; fp32 difference form; lanes outside the grid switched off through EXEC windows).  What is
+// new is the boundary of a quadrant:
+//   * left / right: a row's running values (K, V) simply continue from quadrant (b, 0) into (b, 1) -- they live in
+//     the lane; the neighbour row's corner value arrives through the same DPP shift that serves a lane that has not
+//     started yet (its neighbour still holds the final value of the previous quadrant);
+//   * top / bottom: lane 63 of band 0 files K[64][.] in LDS while it sweeps (one ds_write per step, through a
+//     per-lane address: every other lane writes to a dummy cell), lane 0 of band 1 takes it from there: the
+//     boundary value of the NEXT step is moved into the shift destination at the end of each step (it is `old` of
+//     the next DPP shift, which has no source for lane 0).  Mirror image for U[64][.] in the reverse sweep.
+// Only ONE quadrant's D and S are live at a time, so the forward solution of a quadrant must exist when its
+// reverse sweep runs: the schedule recomputes (static kernel + forward sweep) instead of storing
+//     band 0:  (0,0) (0,1)                                  forward only: leaves K[64][.]
+//     band 1:  (1,0) (1,1)* (1,0)*                          * = reverse sweep + gradient pass follow the forward sweep
+//     band 0:  (0,0) (0,1)* (0,0)*
+// i.e. 8 static-kernel + forward-sweep quadrant passes, 4 reverse sweeps, 4 gradient passes per pair (the minimum is
+// 4 / 4 / 4; holding everything would take 4 x 128 slot registers or 100 KB of LDS per pair).
+// The gradient pass is the 4-corner scatter of gram_fast.hip, with the static kernel re-evaluated in fp32 from the
+// centred coordinates (no G image: LDS stays small enough for 8 wavefronts).  Points on the seams between
+// quadrants need S from both sides and are done separately: point column 64 (and 0) per band from three captured
+// values per lane, point row 64 per pair from the two S rows next to it (one dense pass).
+// Column-side sums (Y is X) ride travelling accumulators (one v_add_f32_dpp wave_ror:1 per channel and step) and join a
+// [column][channel] image in LDS once per quadrant.
+//
+// Reference semantics: sigkernel _SigKernelGram.forward/backward [RECALLED, SURVEY.md App. A];
+// static kernel src/kernels/_traj_kernels.py:176-195.
+#include "sig_common.h"
+
+namespace sigsvgd {
+
+struct QuadArgs {
+    const void *X, *Y, *go;
+    void *K;
+    double *gacc; // [A][T][d] fp64, zeroed by the launcher (or the caller's accumulating buffer: partial solve)
+    int io64, A, B, T, d, JC, symw;
+    int tile_offset, tile_stride; // row tiles tile_offset + k * tile_stride are solved (sharded partial solve)
+    double inv_h;
+#ifdef SIGSVGD_PHASE_STAMPS
+    unsigned long long *stamps; // diagnostic build only (scripts/dev/phase_stamps.py): shader-clock totals per phase
+#endif
+};
+
+#ifdef SIGSVGD_PHASE_STAMPS
+#define SIG_QSTAMP(i)                                                        \
+    {                                                                        \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();        \
+        ph_[i] += now_ - tlast_;                                             \
+        tlast_ = now_;                                                       \
+    }
+#else
+#define SIG_QSTAMP(i)
+#endif
+
+namespace {
+constexpr int QNW = 8; // wavefronts (rows i) per workgroup
+using qf32x2 = __attribute__((ext_vector_type(2))) float;
+
+// EXEC windows: lanes max(0, sigma - n + 1) .. min(sigma, 63) are inside a quadrant of n cell columns on
+// anti-diagonal sigma (AND-ed with the quadrant's row mask in the step)
+struct QuadMasks {
+    unsigned long long m[65][128];
+    constexpr QuadMasks() : m()
+    {
+        for (int n = 1; n <= 64; ++n)
+            for (int s = 0; s <= n + 62; ++s) {
+                const int lo = s - n + 1 > 0 ? s - n + 1 : 0, hi = s < 63 ? s : 63;
+                unsigned long long w = 0;
+                for (int l = lo; l <= hi; ++l) w |= 1ull << l;
+                m[n][s] = w;
+            }
+    }
+};
+__constant__ const QuadMasks QUAD_MASK = QuadMasks();
+
+__device__ __forceinline__ double q_ldany(const void *b, size_t i, int io64)
+{
+    return io64 ? static_cast<const double *>(b)[i] : (double)static_cast<const float *>(b)[i];
+}
+__device__ __forceinline__ void q_stany(void *b, size_t i, double v, int io64)
+{
+    if (io64)
+        static_cast<double *>(b)[i] = v;
+    else
+        static_cast<float *>(b)[i] = (float)v;
+}
+// lane l <- lane l+1; lane 63 keeps `old` (compiler-visible DPP: hipcc pads its hazards)
+__device__ __forceinline__ double q_shl_keep(double v, double old)
+{
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), 0x130, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), 0x130, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float q_shr_zero(float v) // lane l <- lane l-1, lane 0 gets 0
+{
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x138, 0xF, 0xF, true));
+}
+// rotate-and-add in one VALU instruction: returns acc[lane-1] + v (lane 0 reads lane 63)
+__device__ __forceinline__ float q_add_ror1(float acc, float v)
+{
+    float out;
+    asm("v_add_f32_dpp %0, %1, %2 wave_ror:1 row_mask:0xf bank_mask:0xf" : "=v"(out) : "v"(acc), "v"(v));
+    return out;
+}
+
+// ---- four steps of a sweep (cf. gram_fast.hip for the scheduling rules).  Per step: DPP shift under full EXEC, the
+// stencil under the window, then -- still under the window -- the K_fwd slot store (forward) / S product (reverse),
+// the boundary value of the NEXT step into the register the next shift writes (lane 0 / 63 keeps it: no DPP source),
+// and the hand-over store.  The three trailing instructions are also the wait states between the write of `cur` /
+// of the shift destination and the next DPP instruction.
+#define SIG_Q_FWD(UP, DIAG, G, K, M, BN)                                                      \
+    "s_mov_b64 exec, -1\n\t"                                                                  \
+    "v_mov_b32_dpp %[" UP "], %[cur] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"               \
+    "s_and_b64 exec, %[" M "], %[rows]\n\t"                                                   \
+    "v_add_f32 %[t], %[cur], %[" UP "]\n\t"                                                   \
+    "v_mul_f32 %[y], %[r3], %[t]\n\t"                                                         \
+    "v_add_f32 %[t], %[t], %[" DIAG "]\n\t"                                                   \
+    "v_fmac_f32 %[y], %[t], %[" G "]\n\t"                                                     \
+    "v_fmac_f32 %[V], %[" G "], %[y]\n\t"                                                     \
+    "v_add_f32 %[cur], %[" UP "], %[V]\n\t"                                                   \
+    "v_mov_b32 %[" K "], %[" DIAG "]\n\t"                                                     \
+    "v_mov_b32 %[" DIAG "], %[" BN "]\n\t"                                                    \
+    "ds_write_b32 %[ha], %[cur]\n\t"                                                          \
+    "v_add_u32 %[ha], %[hinc], %[ha]\n\t"
+#define SIG_Q_REV(DN, DDIAG, G, K, M, BN)                                                     \
+    "s_mov_b64 exec, -1\n\t"                                                                  \
+    "v_mov_b32_dpp %[" DN "], %[cur] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"               \
+    "s_and_b64 exec, %[" M "], %[rows]\n\t"                                                   \
+    "v_add_f32 %[t], %[cur], %[" DN "]\n\t"                                                   \
+    "v_mul_f32 %[y], %[r3], %[t]\n\t"                                                         \
+    "v_add_f32 %[t], %[t], %[" DDIAG "]\n\t"                                                  \
+    "v_fmac_f32 %[y], %[t], %[" G "]\n\t"                                                     \
+    "v_fmac_f32 %[V], %[" G "], %[y]\n\t"                                                     \
+    "v_add_f32 %[cur], %[" DN "], %[V]\n\t"                                                   \
+    "v_mul_f32 %[" K "], %[" K "], %[" DDIAG "]\n\t"                                          \
+    "v_mov_b32 %[" DDIAG "], %[" BN "]\n\t"                                                   \
+    "ds_write_b32 %[ha], %[cur]\n\t"                                                          \
+    "v_add_u32 %[ha], %[hinc], %[ha]\n\t"
+
+// steps sigma0 .. sigma0+3 (sigma0 a multiple of 4); bn[u]: boundary value of step sigma0+u+1
+__device__ __forceinline__ void quad_fwd4(float &cur, float &upA, float &upB, float &V, const float *g, float *ksl,
+                                          const unsigned long long *mk, const unsigned long long rows, const float *bn,
+                                          int &ha, const int hinc, const float r3)
+{
+    float t, y;
+    const unsigned long long m0 = mk[0], m1 = mk[1], m2 = mk[2], m3 = mk[3];
+    asm volatile(SIG_Q_FWD("upA", "upB", "g0", "k0", "m0", "b0") SIG_Q_FWD("upB", "upA", "g1", "k1", "m1", "b1")
+                 SIG_Q_FWD("upA", "upB", "g2", "k2", "m2", "b2") SIG_Q_FWD("upB", "upA", "g3", "k3", "m3", "b3")
+                 "s_mov_b64 exec, -1\n\t"
+                 : [cur] "+v"(cur), [upA] "+v"(upA), [upB] "+v"(upB), [V] "+v"(V), [ha] "+v"(ha), [t] "=&v"(t),
+                   [y] "=&v"(y), [k0] "+v"(ksl[0]), [k1] "+v"(ksl[1]), [k2] "+v"(ksl[2]), [k3] "+v"(ksl[3])
+                 : [g0] "v"(g[0]), [g1] "v"(g[1]), [g2] "v"(g[2]), [g3] "v"(g[3]), [b0] "v"(bn[0]), [b1] "v"(bn[1]),
+                   [b2] "v"(bn[2]), [b3] "v"(bn[3]), [m0] "s"(m0), [m1] "s"(m1), [m2] "s"(m2), [m3] "s"(m3),
+                   [rows] "s"(rows), [hinc] "v"(hinc), [r3] "s"(r3)
+                 : "memory", "scc");
+}
+// steps sigma0+3 .. sigma0 (descending); bn[u]: boundary value of the step after the u-th one executed
+__device__ __forceinline__ void quad_rev4(float &cur, float &dnA, float &dnB, float &V, const float *g, float *ksl,
+                                          const unsigned long long *mk, const unsigned long long rows, const float *bn,
+                                          int &ha, const int hinc, const float r3)
+{
+    float t, y;
+    const unsigned long long m0 = mk[0], m1 = mk[1], m2 = mk[2], m3 = mk[3];
+    asm volatile(SIG_Q_REV("dnA", "dnB", "g3", "k3", "m3", "b0") SIG_Q_REV("dnB", "dnA", "g2", "k2", "m2", "b1")
+                 SIG_Q_REV("dnA", "dnB", "g1", "k1", "m1", "b2") SIG_Q_REV("dnB", "dnA", "g0", "k0", "m0", "b3")
+                 "s_mov_b64 exec, -1\n\t"
+                 : [cur] "+v"(cur), [dnA] "+v"(dnA), [dnB] "+v"(dnB), [V] "+v"(V), [ha] "+v"(ha), [t] "=&v"(t),
+                   [y] "=&v"(y), [k0] "+v"(ksl[0]), [k1] "+v"(ksl[1]), [k2] "+v"(ksl[2]), [k3] "+v"(ksl[3])
+                 : [g0] "v"(g[0]), [g1] "v"(g[1]), [g2] "v"(g[2]), [g3] "v"(g[3]), [b0] "v"(bn[0]), [b1] "v"(bn[1]),
+                   [b2] "v"(bn[2]), [b3] "v"(bn[3]), [m0] "s"(m0), [m1] "s"(m1), [m2] "s"(m2), [m3] "s"(m3),
+                   [rows] "s"(rows), [hinc] "v"(hinc), [r3] "s"(r3)
+                 : "memory", "scc");
+}
+} // namespace
+
+template <int DPAD, bool GRAD, bool SYM>
+__global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void gram_quad_kernel(QuadArgs a)
+{
+    constexpr int NT = QNW * 64;
+    constexpr int CS = DPAD + 1;  // row stride of the column-side image (odd: lanes on distinct banks)
+    constexpr int YDS = DPAD + 2; // fp64 row: coordinates, [DPAD] = -log2(e)/h * |y~|^2
+    constexpr int YFS = (DPAD == 4) ? 12 : DPAD + 4; // fp32 row
+    // point column n = 64 h + c is stored at rows 128 h + c and 128 h + 64 + c: the skewed row (t - lane) & 63 of
+    // half h is then base(h, lane) + t * stride
+    __shared__ __align__(16) double yd[256 * YDS];
+    __shared__ __align__(16) float yf[GRAD ? 256 * YFS : 4];
+    __shared__ double yref[DPAD];
+    __shared__ float colacc[(GRAD && SYM) ? 128 * CS : 4];
+    constexpr int HN = 136; // hand-over rows: entries 0 .. 129 are read
+    __shared__ float ones[HN];
+    __shared__ float hK_all[QNW * HN], hU_all[QNW * HN], hdummy_all[QNW * 64];
+    __shared__ double g64_all[QNW * 128], rdh_all[QNW * 128];
+    __shared__ float srow_all[GRAD ? QNW * 256 : 4];
+    __shared__ float x64_all[GRAD ? QNW * (DPAD + 2) : 4];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int T = a.T, d = a.d, P = T - 1, io64 = a.io64;
+    const int nrows1 = P - 64; // cell rows of band 1 = cell columns of half 1 (0 .. 63)
+    // grid decode: ordered launches 2-D (column chunk, owned row tile); symmetric launches 1-D over the chunks that
+    // reach the diagonal of their row tile
+    int ty = blockIdx.y, cx = blockIdx.x;
+    if (SYM) {
+        const int nJ = (a.B + a.JC - 1) / a.JC;
+        int rem = blockIdx.x;
+        for (ty = 0;; ++ty) {
+            const int first = ((a.tile_offset + ty * a.tile_stride) * QNW) / a.JC;
+            const int cntc = nJ - first;
+            if (rem < cntc) {
+                cx = first + rem;
+                break;
+            }
+            rem -= cntc;
+        }
+    }
+    const int i0 = (a.tile_offset + ty * a.tile_stride) * QNW;
+    const int i = i0 + wave;
+    const int j0 = cx * a.JC, j1 = min(a.B, j0 + a.JC);
+    const bool row_ok = i < a.A;
+    const double inv_h = a.inv_h;
+    const double nscale = -inv_h * 1.4426950408889634074;
+    const float m2h = (float)(-2.0 * inv_h);
+    float *hK = hK_all + wave * HN, *hU = hU_all + wave * HN, *hdummy = hdummy_all + wave * 64;
+    double *g64 = g64_all + wave * 128, *rdh = rdh_all + wave * 128;
+    float *srow63 = srow_all + (GRAD ? wave * 256 : 0), *srow64 = srow63 + (GRAD ? 128 : 0);
+    float *x64 = x64_all + (GRAD ? wave * (DPAD + 2) : 0);
+    for (int e = tid; e < HN; e += NT) ones[e] = 1.f;
+    for (int e = lane; e < HN; e += 64) hK[e] = 1.f, hU[e] = 1.f; // (entries the sweeps do not write stay at the boundary value)
+
+#ifdef SIGSVGD_PHASE_STAMPS
+    unsigned long long ph_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast_ = __builtin_amdgcn_s_memtime();
+#endif
+    float gacc[2][DPAD]; // row-side gradient of (band, channel), summed over the column chunk in fp32
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int c = 0; c < DPAD; ++c) gacc[b][c] = 0.f;
+
+    for (int j = j0; j < j1; ++j) {
+        // ---- stage y_j (centred on its first point): fp64 rows + scaled norms, fp32 copy, both twice ----------
+        __syncthreads();
+        for (int e = tid; e < 128 * DPAD; e += NT) {
+            const int t = e / DPAD, c = e % DPAD;
+            const bool ok = t < T && c < d;
+            const double r0 = ok ? q_ldany(a.Y, (size_t)j * T * d + c, io64) : 0.0;
+            const double v = ok ? q_ldany(a.Y, ((size_t)j * T + t) * d + c, io64) - r0 : 0.0;
+            const int r = 128 * (t >> 6) + (t & 63);
+            yd[r * YDS + c] = v;
+            yd[(r + 64) * YDS + c] = v;
+            if (GRAD) {
+                yf[r * YFS + c] = (float)v;
+                yf[(r + 64) * YFS + c] = (float)v;
+            }
+            if (t == 0) yref[c] = r0;
+            double s = v * v * nscale;
+#pragma unroll
+            for (int off = 1; off < DPAD; off <<= 1) s += __shfl_xor(s, off, 64);
+            if (c == 0) {
+                yd[r * YDS + DPAD] = s;
+                yd[(r + 64) * YDS + DPAD] = s;
+            }
+        }
+        if (GRAD && SYM)
+            for (int e = tid; e < 128 * CS; e += NT) colacc[e] = 0.f;
+        __syncthreads();
+
+        if (row_ok && (!SYM || j >= i)) {
+            float w_ij = 1.f, w_ji = 1.f; // row-side / column-side weights
+            if (GRAD) {
+                if (a.go) {
+                    w_ij = (float)q_ldany(a.go, (size_t)i * a.B + j, io64);
+                    if (SYM || a.symw) w_ji = (float)q_ldany(a.go, (size_t)j * a.B + i, io64);
+                    if (a.symw) { w_ij += w_ji; w_ji = w_ij; }
+                } else if (a.symw) {
+                    w_ij = 2.f; w_ji = 2.f;
+                }
+                if (SYM && j == i) w_ji = 0.f; // diagonal pair: first-slot derivative only
+            }
+
+            // ---- G row 64 (the row beyond band 0): differences along the row for lane 63 of band 0 ------------
+            {
+                double xs2[DPAD], xn2 = 0.0;
+#pragma unroll
+                for (int c = 0; c < DPAD; ++c) {
+                    const double xc = (c < d) ? q_ldany(a.X, ((size_t)i * T + 64) * d + c, io64) - yref[c] : 0.0;
+                    xn2 = __builtin_fma(xc, xc, xn2);
+                    xs2[c] = xc * (-2.0 * nscale);
+                    if (GRAD && lane == 0) x64[c] = (float)xc;
+                }
+                xn2 = __builtin_fma(xn2, nscale, -1.79248125036057809); // G / sqrt(12), as in the quadrant passes
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const double *yr = yd + (128 * hh + lane) * YDS;
+                    double e2 = xn2 + yr[DPAD];
+#pragma unroll
+                    for (int c = 0; c < DPAD; ++c) e2 = __builtin_fma(xs2[c], yr[c], e2);
+                    g64[lane + 64 * hh] = exp2_p7(e2);
+                }
+                if (GRAD) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) srow63[lane + 64 * u] = 0.f; // (both seam rows: 256 floats)
+                }
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): the row is in LDS before it is read back
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int n = lane + 64 * hh;
+                    rdh[n] = g64[n] - g64[(n - 1) & 127];
+                }
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+            }
+
+            float Dsl[64]; // increments / sqrt(12) of the quadrant in work
+            float Ssl[64]; // K_fwd, then S = K_fwd * U, of the quadrant in work
+            float fc = 1.f, fuA = 1.f, fuB = 1.f, fV = 0.f; // forward chain of the band in work (K, neighbours, V)
+            float rc = 1.f, rdA = 1.f, rdB = 1.f, rV = 0.f; // reverse chain (U)
+            float cap0h0 = 0.f, cap63h0 = 0.f, cap0h1 = 0.f; // S[l][0], S[l][63] of half 0, S[l][64] (first of half 1)
+            float xf[DPAD];
+            int rev_band = -1;
+            bool kdone = false;
+
+            // visit list, 4 bits per visit: band | half << 1 | reverse << 2 | leave K[64][.] << 3
+            unsigned long long vis = 0;
+            int nv = 0;
+            auto add = [&](int b, int h, int r, int hk) {
+                if ((b ? nrows1 : 64) > 0 && (h ? nrows1 : 64) > 0) {
+                    vis |= (unsigned long long)(b | (h << 1) | (r << 2) | (hk << 3)) << (4 * nv);
+                    ++nv;
+                }
+            };
+            if (GRAD) {
+                if (nrows1 > 0) { add(0, 0, 0, 1); add(0, 1, 0, 1); add(1, 0, 0, 0); add(1, 1, 1, 0); add(1, 0, 1, 0); }
+                add(0, 0, 0, 0); add(0, 1, 1, 0); add(0, 0, 1, 0);
+            } else {
+                add(0, 0, 0, 1); add(0, 1, 0, 1); add(1, 0, 0, 0); add(1, 1, 0, 0);
+            }
+            const int b_last = nrows1 > 0 ? 1 : 0, h_last = nrows1 > 0 ? 1 : 0;
+
+#pragma unroll 1
+            for (int v = 0; v < nv; ++v) {
+                const int code = (int)((vis >> (4 * v)) & 15);
+                const int b = code & 1, h = (code >> 1) & 1;
+                const bool rev = (code & 4) != 0, leave_k = (code & 8) != 0;
+                const int nrows = b ? nrows1 : 64, ncols = h ? nrows1 : 64;
+                const int m = 64 * b + lane; // point row of this lane
+                const unsigned long long rows = nrows >= 64 ? ~0ull : ((1ull << nrows) - 1ull);
+                const unsigned long long *mk = QUAD_MASK.m[ncols];
+
+                // ---- x_m, centred and pre-scaled (fp64 for the static kernel, fp32 for the gradient pass); re-read on
+                // every visit (L2 hits) so that the fp64 copy is not live across the gradient pass
+                double xs[DPAD], xn = 0.0;
+#pragma unroll
+                for (int c = 0; c < DPAD; ++c) {
+                    const double xc = (m <= P && c < d) ? q_ldany(a.X, ((size_t)i * T + m) * d + c, io64) - yref[c] : 0.0;
+                    xn = __builtin_fma(xc, xc, xn);
+                    xs[c] = xc * (-2.0 * nscale);
+                    xf[c] = (float)xc;
+                }
+                xn = __builtin_fma(xn, nscale, -1.79248125036057809); // - log2(sqrt(12)): D slots hold D / sqrt(12)
+
+                SIG_QSTAMP(0)
+                // ---- phase 1: G row (skewed: local column (t - lane) & 63 on iteration t) -> D slots --------------
+                {
+                    const double *ybase = yd + (128 * h + 64 - lane) * YDS; // local column (t - lane) & 63 == ybase + t * YDS
+                    // the point column that closes the last cell column of half 0 (column 64) is outside the ring
+                    double g64v = 0.0;
+                    if (h == 0) {
+                        const double *yr = yd + 128 * YDS;
+                        double e2 = xn + yr[DPAD];
+#pragma unroll
+                        for (int c = 0; c < DPAD; ++c) e2 = __builtin_fma(xs[c], yr[c], e2);
+                        g64v = exp2_p7(e2);
+                    }
+                    const double *rdhh = rdh + 64 * h;
+                    double g0 = 0.0, g1 = 0.0, gprev = 0.0, rdprev = 0.0;
+                    // the y~ row of column t+1 is fetched into the SAME registers right after the dot product of column t:
+                    // the exponential that follows covers the LDS latency, and there is no second row buffer to keep
+                    double yrow[DPAD + 1];
+#pragma unroll
+                    for (int c = 0; c <= DPAD; ++c) yrow[c] = ybase[c];
+#pragma unroll
+                    for (int t = 0; t < 66; ++t) {
+                        double g;
+                        if (t < 64) {
+                            double e2 = xn + yrow[DPAD];
+#pragma unroll
+                            for (int c = 0; c < DPAD; ++c) e2 = __builtin_fma(xs[c], yrow[c], e2);
+                            asm volatile("" : "+v"(e2));
+                            if (t < 63) {
+                                const double *yr = ybase + (t + 1) * YDS;
+#pragma unroll
+                                for (int c = 0; c <= DPAD; ++c) yrow[c] = yr[c];
+                            }
+                            g = exp2_p7(e2);
+                            if (t == 0) g0 = g;
+                            if (t == 1) g1 = g;
+                        } else {
+                            g = (t == 64) ? g0 : g1;
+                        }
+                        // a lane at local column 0 closes the previous row segment: G[m][64 h + 64] - G[m][64 h + 63]
+                        const double gsel = (lane == (t & 63)) ? g64v : g;
+                        const double rd = gsel - gprev; // G[m, c] - G[m, c-1]
+                        gprev = g;
+                        if (t >= 2) {
+                            // lane l+1 holds the same column difference one iteration later; lane 63 of band 0 takes the
+                            // row beyond the band (G row 64) from LDS: a virtual lane 64 is at local column t & 63
+                            const int cc = (t & 63) ? (t & 63) : 64;
+                            const double beyond = (64 * h + cc < 128) ? rdhh[cc] : 0.0;
+                            const double nb = q_shl_keep(rd, beyond);
+                            Dsl[(t - 2) & 63] = (float)(nb - rdprev);
+                            asm volatile("" : "+v"(Dsl[(t - 2) & 63])); // formed here (hipcc otherwise sinks it to the sweep)
+                        }
+                        rdprev = rd;
+                        __builtin_amdgcn_sched_barrier(0); // one column per scheduling region: bounds live ranges
+                    }
+                }
+
+                SIG_QSTAMP(1)
+                // ---- phase 2: forward sweep of the quadrant -----------------------------------------------------
+                {
+                    const float *topb = (b ? hK : ones) + 64 * h; // K[64 b][64 h + q + 1] for lane 0 on step sigma = q
+                    if (h == 0) { // a new band: left boundary column of ones
+                        fc = 1.f;
+                        fV = 0.f;
+                        fuA = (lane == 0) ? topb[1] : 1.f;
+                        fuB = (lane == 0) ? topb[0] : 1.f;
+                    }
+                    // lane 63 leaves K[64 b + 64][64 h + q + 1] after step sigma = 63 + q
+                    const unsigned ho = (unsigned)(size_t)(leave_k ? hK + 64 * h + 1 : hdummy + 63);
+                    int haddr = (int)((lane == 63) ? ho : (unsigned)(size_t)(hdummy + lane));
+                    const int hinc = (lane == 63 && leave_k) ? 4 : 0;
+                    float r3 = 1.7320508075688772f;
+                    asm volatile("" : "+s"(r3));
+#pragma unroll
+                    for (int k = 0; k < 64; ++k) Ssl[k] = 0.f; // slots without a grid cell must read as S = 0
+#pragma unroll
+                    for (int s0 = 0; s0 < 128; s0 += 4) {
+                        float bn[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) bn[u] = topb[(s0 + u + 2 < 66) ? s0 + u + 2 : 66];
+                        quad_fwd4(fc, fuA, fuB, fV, &Dsl[s0 & 63], &Ssl[s0 & 63], mk + s0, rows, bn, haddr, hinc, r3);
+                    }
+                }
+                SIG_QSTAMP(2)
+                if (!kdone && b == b_last && h == h_last) { // K[P][P]: last value of the last row with cells
+                    kdone = true;
+                    if (lane == nrows - 1) {
+                        q_stany(a.K, (size_t)i * a.B + j, (double)fc, io64);
+                        if (SYM && j != i) q_stany(a.K, (size_t)j * a.B + i, (double)fc, io64);
+                    }
+                }
+                if (!GRAD || !rev) continue;
+
+                // ---- phase 3: reverse sweep (S = K_fwd * U replaces K_fwd slot by slot) -------------------------
+                {
+                    const bool below = (b == 0) && nrows1 > 0;    // band 1 lies below: U[64][.] is in hU
+                    const float *botb = (below ? hU : ones) + 64 * h; // U[64 b + 64][64 h + q] for lane 63 on step sigma = q + 63
+                    if (rev_band != b) { // first reverse quadrant of the band: right boundary column of ones
+                        rev_band = b;
+                        rc = 1.f;
+                        rV = 0.f;
+                        // lane 63 starts on step 62 + ncols with the lower neighbour U[64 b + 64][64 h + ncols - 1] and the
+                        // corner U[.][64 h + ncols]; odd steps shift into dnA, even steps into dnB
+                        const float c1 = botb[ncols], c0 = botb[ncols - 1];
+                        const bool odd = ((62 + ncols) & 1) != 0;
+                        rdA = (lane == 63) ? (odd ? c0 : c1) : 1.f;
+                        rdB = (lane == 63) ? (odd ? c1 : c0) : 1.f;
+                    }
+                    // lane 0 of band 1 leaves U[64][64 h + q] after step sigma = q
+                    const bool leave_u = (b == 1);
+                    const unsigned ho = (unsigned)(size_t)(leave_u ? hU + 64 * h + ncols - 1 : hdummy);
+                    int haddr = (int)((lane == 0) ? ho : (unsigned)(size_t)(hdummy + lane));
+                    const int hinc = (lane == 0 && leave_u) ? -4 : 0;
+                    float r3 = 1.7320508075688772f;
+                    asm volatile("" : "+s"(r3));
+#pragma unroll
+                    for (int s0 = 124; s0 >= 0; s0 -= 4) {
+                        // after step sigma the boundary value of step sigma - 1: U[.][64 h + sigma - 1 - 63]
+                        float bn[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int sg = s0 + 3 - u; // the step executed
+                            // (step 63 of a right quadrant hands lane 63 the first value of the left one: index -1)
+                            bn[u] = botb[(sg >= 64) ? sg - 64 : ((sg == 63) ? -h : 0)];
+                        }
+                        quad_rev4(rc, rdA, rdB, rV, &Dsl[s0 & 63], &Ssl[s0 & 63], mk + s0, rows, bn, haddr, hinc, r3);
+                    }
+                }
+                SIG_QSTAMP(3)
+                // ---- seam rows for the hand-over pass: S[63][.] (band 0, lane 63), S[64][.] (band 1, lane 0) ------
+                if (lane == (b ? 0 : 63)) {
+                    float *dst = (b ? srow64 : srow63) + 64 * h;
+#pragma unroll
+                    for (int k = 0; k < 64; ++k) dst[(k - lane) & 63] = Ssl[k];
+                }
+
+                // ---- phase 4: 4-corner scatter R, static kernel in fp32, both contractions -----------------------
+                // iteration it: lane l is at local column n = (it - l) & 63; own row S[l][n] is slot it, the upper row
+                // arrives through a wave shift one column ahead (lane l-1's slot it holds S[l-1][n+1]), hence the
+                // two-deep history of the shifted values.  Local point column 0 needs the cell column left of the
+                // quadrant: it is masked here and done per band from the values captured at the wrap.
+                const float rowmask = (b == 1 && lane == 0) ? 0.f : 1.f; // point row 64 is contracted in the seam pass
+                const float ns32 = (float)nscale;
+                float s0 = 0.f;
+                qf32x2 acc[DPAD / 2];
+#pragma unroll
+                for (int c = 0; c < DPAD / 2; ++c) acc[c] = qf32x2{0.f, 0.f};
+                {
+                    float t0 = 0.f, tacc[DPAD]; // column-side travelling sums (SYM)
+#pragma unroll
+                    for (int c = 0; c < DPAD; ++c) tacc[c] = 0.f;
+                    float capA = 0.f, capB = 0.f;
+                    float Nc = q_shr_zero(Ssl[62]); // S[l-1][n-1]
+                    float Nb = q_shr_zero(Ssl[63]); // S[l-1][n]
+                    float Sprev = Ssl[63];          // S[l][n-1]
+                    const float *yfb = yf + (128 * h + 64 - lane) * YFS;
+                    qf32x2 ynx[DPAD / 2]; // the y~ row of the next iteration (fetched one iteration ahead)
+#pragma unroll
+                    for (int c = 0; c < DPAD / 2; ++c) ynx[c] = reinterpret_cast<const qf32x2 *>(yfb)[c];
+#pragma unroll
+                    for (int it = 0; it < 64; ++it) {
+                        qf32x2 yr2[DPAD / 2];
+#pragma unroll
+                        for (int c = 0; c < DPAD / 2; ++c) yr2[c] = ynx[c];
+                        if (it < 63) {
+                            const qf32x2 *yn = reinterpret_cast<const qf32x2 *>(yfb + (it + 1) * YFS);
+#pragma unroll
+                            for (int c = 0; c < DPAD / 2; ++c) ynx[c] = yn[c];
+                        }
+                        const float Scur = Ssl[it];
+                        const float Na = q_shr_zero(Scur); // S[l-1][n+1]
+                        const bool wrap = lane == it;      // local column 0
+                        float R = ((Nc - Nb) + (Scur - Sprev)) * rowmask;
+                        capA = wrap ? Scur : capA;
+                        capB = wrap ? Sprev : capB;
+                        R = wrap ? 0.f : R;
+                        Nc = Nb;
+                        Nb = Na;
+                        Sprev = Scur;
+                        // G[m][n] = 2^(-log2(e)/h * |x~_m - y~_n|^2) in fp32, from the DIFFERENCES (the expanded form loses
+                        // 6e-8 of its largest term, 1e-5 of G for rough paths)
+                        qf32x2 e2 = qf32x2{0.f, 0.f};
+#pragma unroll
+                        for (int c = 0; c < DPAD / 2; ++c) {
+                            const qf32x2 df = qf32x2{xf[2 * c], xf[2 * c + 1]} - yr2[c];
+                            e2 = __builtin_elementwise_fma(df, df, e2);
+                        }
+                        const float gv = __builtin_amdgcn_exp2f((e2[0] + e2[1]) * ns32);
+                        const float rg = R * gv;
+                        const qf32x2 rg2 = {rg, rg};
+                        s0 += rg;
+#pragma unroll
+                        for (int c = 0; c < DPAD / 2; ++c) acc[c] = __builtin_elementwise_fma(rg2, yr2[c], acc[c]);
+                        if (SYM) {
+                            const float rgw = rg * w_ji;
+                            t0 = q_add_ror1(t0, rgw);
+#pragma unroll
+                            for (int c = 0; c < DPAD; ++c) tacc[c] = q_add_ror1(tacc[c], rgw * xf[c]);
+#pragma unroll
+                            for (int c = 0; c < DPAD; ++c) asm volatile("" : "+v"(tacc[c]));
+                            asm volatile("" : "+v"(t0));
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (h == 0) {
+                        cap0h0 = capA;
+                        cap63h0 = capB;
+                    } else {
+                        cap0h1 = capA;
+                    }
+                    if (SYM) { // the finished sums of local column (63 - lane) & 63 join the tile's image
+                        float *dst = colacc + (64 * h + ((63 - lane) & 63)) * CS;
+#pragma unroll
+                        for (int c = 0; c < DPAD; ++c) atomicAdd(dst + c, tacc[c]);
+                        atomicAdd(dst + DPAD, t0);
+                    }
+                }
+
+                SIG_QSTAMP(4)
+                // ---- the band's seam columns (after its left quadrant): point columns 0 and 64 ---------------------
+                if (h == 0) {
+#pragma unroll
+                    for (int sc = 0; sc < 2; ++sc) {
+                        // E_l = S[l][n-1] - S[l][n];  R[m][n] = E_{l-1} - E_l
+                        const float E = sc ? (cap63h0 - cap0h1) : -cap0h0;
+                        const float R = (q_shr_zero(E) - E) * rowmask;
+                        const float *yr = yf + (128 * sc) * YFS;
+                        float e2 = 0.f;
+#pragma unroll
+                        for (int c = 0; c < DPAD; ++c) e2 = __builtin_fmaf(xf[c] - yr[c], xf[c] - yr[c], e2);
+                        const float rg = R * __builtin_amdgcn_exp2f(e2 * ns32);
+                        s0 += rg;
+#pragma unroll
+                        for (int c = 0; c < DPAD / 2; ++c) {
+                            acc[c][0] = __builtin_fmaf(rg, yr[2 * c], acc[c][0]);
+                            acc[c][1] = __builtin_fmaf(rg, yr[2 * c + 1], acc[c][1]);
+                        }
+                        if (SYM) { // one column, 64 rows: wave sums, lane c adds channel c (all lanes on one address would
+                                   // serialise 64-fold in LDS)
+                            const float rgw = rg * w_ji;
+                            float mine = 0.f;
+#pragma unroll
+                            for (int c = 0; c <= DPAD; ++c) {
+                                float vsum = (c < DPAD) ? rgw * xf[c] : rgw;
+#pragma unroll
+                                for (int off = 32; off >= 1; off >>= 1) vsum += __shfl_xor(vsum, off, 64);
+                                mine = (lane == c) ? vsum : mine;
+                            }
+                            if (lane <= DPAD) atomicAdd(colacc + (64 * sc) * CS + lane, mine);
+                        }
+                    }
+                    cap0h0 = cap63h0 = cap0h1 = 0.f;
+                }
+#pragma unroll
+                for (int c = 0; c < DPAD; ++c) {
+                    const float gv = w_ij * m2h * (xf[c] * s0 - acc[c / 2][c % 2]);
+                    gacc[0][c] += b ? 0.f : gv; // (static indices: a runtime band index would put the array in scratch)
+                    gacc[1][c] += b ? gv : 0.f;
+                }
+                SIG_QSTAMP(5)
+            } // quadrant visits
+
+            if (GRAD) {
+                // ---- seam: point row 64.  R[64][n] = (S[63][n-1] - S[63][n]) - (S[64][n-1] - S[64][n]), formed from both
+                // bands' rows before the contraction; lanes take columns n = lane and lane + 64.
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                float ps0 = 0.f, part[DPAD], xm[DPAD];
+#pragma unroll
+                for (int c = 0; c < DPAD; ++c) {
+                    part[c] = 0.f;
+                    xm[c] = x64[c];
+                }
+                const float ns32 = (float)nscale;
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int n = lane + 64 * hh;
+                    const float Sa = n ? srow63[n - 1] : 0.f, Sz = srow63[n];
+                    const float Ta = n ? srow64[n - 1] : 0.f, Tz = srow64[n];
+                    const float *yr = yf + (128 * hh + lane) * YFS;
+                    float e2 = 0.f;
+#pragma unroll
+                    for (int c = 0; c < DPAD; ++c) e2 = __builtin_fmaf(xm[c] - yr[c], xm[c] - yr[c], e2);
+                    const float rgn = (n <= P) ? ((Sa - Sz) - (Ta - Tz)) * __builtin_amdgcn_exp2f(e2 * ns32) : 0.f;
+                    ps0 += rgn;
+#pragma unroll
+                    for (int c = 0; c < DPAD; ++c) part[c] = __builtin_fmaf(rgn, yr[c], part[c]);
+                    if (SYM) {
+                        float *dst = colacc + n * CS;
+#pragma unroll
+                        for (int c = 0; c < DPAD; ++c) atomicAdd(dst + c, rgn * w_ji * xm[c]);
+                        atomicAdd(dst + DPAD, rgn * w_ji);
+                    }
+                }
+                // row 64 belongs to band 1's lane 0 accumulators
+#pragma unroll
+                for (int c = 0; c < DPAD; ++c) {
+                    float v = w_ij * m2h * (xm[c] * ps0 - part[c]);
+#pragma unroll
+                    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+                    if (lane == 0) gacc[1][c] += v;
+                }
+            }
+        } // this wavefront's pair
+
+        if (GRAD && SYM) {
+            // close the column-side sums of y_j over the rows of the tile:
+            // d/dy_n = -(2/h) * (y~_n * sum_m w R G - sum_m w R G x~_m)
+            __syncthreads();
+            for (int e = tid; e < T * DPAD; e += NT) {
+                const int n = e / DPAD, c = e % DPAD;
+                const float sw = colacc[n * CS + DPAD], sx = colacc[n * CS + c];
+                const float v = m2h * (yf[(128 * (n >> 6) + (n & 63)) * YFS + c] * sw - sx);
+                if (c < d && v != 0.f) unsafeAtomicAdd(&a.gacc[((size_t)j * T + n) * d + c], (double)v);
+            }
+        }
+    }
+
+    SIG_QSTAMP(0)
+#ifdef SIGSVGD_PHASE_STAMPS
+    if (lane == 0 && a.stamps)
+        for (int k = 0; k < 8; ++k) atomicAdd(&a.stamps[k], ph_[k]);
+#endif
+    if (GRAD && row_ok) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const int p = kb * 64 + lane;
+            if (p < T)
+#pragma unroll
+                for (int c = 0; c < DPAD; ++c)
+                    if (c < d) unsafeAtomicAdd(&a.gacc[((size_t)i * T + p) * d + c], (double)gacc[kb][c]);
+        }
+    }
+}
+
+template <typename IO>
+__global__ void quad_finalize_kernel(const double *gacc, IO *gradX, size_t n)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < n) gradX[idx] = (IO)gacc[idx];
+}
+
+bool quad_supported(int A, int B, int T, int d, int n, int kind, unsigned flags)
+{
+    (void)A; (void)B;
+    if (n != 0 || T < 65 || T > 128 || d > 16) return false;
+    if (kind != SIGSVGD_STATIC_RBF) return false;
+    if (flags & SIGSVGD_FLAG_NAIVE_SOLVER) return false;
+    return true;
+}
+
+int quad_workspace_bytes(int A, int T, int d, int want_grad, size_t *bytes)
+{
+    *bytes = want_grad ? (size_t)A * T * d * sizeof(double) + 256 : 0;
+    return SIGSVGD_OK;
+}
+
+namespace {
+template <int DPAD>
+int quad_launch_variant(const GramProblem &p, QuadArgs &a, bool grad, bool sym)
+{
+    const int ntile = (p.A + QNW - 1) / QNW;
+    const int owned = (ntile - a.tile_offset + a.tile_stride - 1) / a.tile_stride;
+    if (owned <= 0) return SIGSVGD_OK;
+    int JC = 8;
+    while (JC > 1 && (long long)owned * ((p.B + JC - 1) / JC) < (sym ? 2048 : 1024)) JC >>= 1;
+    a.JC = JC;
+    dim3 grid((p.B + JC - 1) / JC, owned), block(QNW * 64);
+    if (sym) { // count the chunks on or right of the diagonal of every owned tile
+        const int nJ = (p.B + JC - 1) / JC;
+        long long total = 0;
+        for (int k = 0; k < owned; ++k) {
+            const int first = ((a.tile_offset + k * a.tile_stride) * QNW) / JC;
+            if (first < nJ) total += nJ - first;
+        }
+        if (total <= 0) return SIGSVGD_OK;
+        grid = dim3((unsigned)total, 1);
+    }
+#ifdef SIGSVGD_PHASE_STAMPS
+    {
+        static unsigned long long *dbg = nullptr;
+        if (!dbg) (void)hipMalloc(&dbg, 8 * sizeof(unsigned long long));
+        (void)hipMemsetAsync(dbg, 0, 8 * sizeof(unsigned long long), p.stream);
+        a.stamps = dbg;
+    }
+#endif
+    if (grad && sym)
+        hipLaunchKernelGGL((gram_quad_kernel<DPAD, true, true>), grid, block, 0, p.stream, a);
+    else if (grad)
+        hipLaunchKernelGGL((gram_quad_kernel<DPAD, true, false>), grid, block, 0, p.stream, a);
+    else if (sym)
+        hipLaunchKernelGGL((gram_quad_kernel<DPAD, false, true>), grid, block, 0, p.stream, a);
+    else
+        hipLaunchKernelGGL((gram_quad_kernel<DPAD, false, false>), grid, block, 0, p.stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "launch gram_quad_kernel");
+#ifdef SIGSVGD_PHASE_STAMPS
+    {
+        unsigned long long hst[8];
+        (void)hipStreamSynchronize(p.stream);
+        (void)hipMemcpy(hst, a.stamps, sizeof(hst), hipMemcpyDeviceToHost);
+        double tot = 0;
+        for (int k = 0; k < 8; ++k) tot += (double)hst[k];
+        static const char *nm[8] = {"staging/other", "phase 1 static kernel", "forward sweep", "reverse sweep",
+                                    "gradient pass", "seams + row sums", "-", "-"};
+        fprintf(stderr, "[phase stamps quad] A=%d T=%d d=%d grad=%d sym=%d: ", p.A, p.T, p.d, (int)grad, (int)sym);
+        for (int k = 0; k < 6; ++k) fprintf(stderr, "%s %.1f%% | ", nm[k], 100.0 * (double)hst[k] / tot);
+        fprintf(stderr, "total %.3e wave-cycles\n", tot);
+    }
+#endif
+    return SIGSVGD_OK;
+}
+
+int quad_dispatch(const GramProblem &p, QuadArgs &a, bool grad, bool sym)
+{
+    if (p.d <= 8) return quad_launch_variant<8>(p, a, grad, sym);
+    return quad_launch_variant<16>(p, a, grad, sym);
+}
+
+void quad_fill_args(const GramProblem &p, QuadArgs &a)
+{
+    a.X = p.X; a.Y = p.Y; a.go = p.grad_out; a.K = p.K_out; a.gacc = nullptr;
+    a.io64 = p.dtype == SIGSVGD_F64; a.A = p.A; a.B = p.B; a.T = p.T; a.d = p.d; a.JC = 1;
+    a.symw = (p.flags & SIGSVGD_FLAG_SYM) ? 1 : 0; a.inv_h = p.inv_h;
+    a.tile_offset = 0; a.tile_stride = 1;
+}
+} // namespace
+
+int quad_launch(const GramProblem &p)
+{
+    const bool grad = p.gradX_out != nullptr;
+    const bool sym = (p.flags & SIGSVGD_FLAG_Y_IS_X) && p.A == p.B; // Y is X: each unordered pair once
+    QuadArgs a;
+    quad_fill_args(p, a);
+    if (a.symw && p.A != p.B) {
+        set_error("sym backward needs A == B");
+        return SIGSVGD_E_BADARG;
+    }
+    const size_t nacc = (size_t)p.A * p.T * p.d;
+    if (grad) {
+        const size_t need = nacc * sizeof(double) + 256;
+        if (!p.ws || p.ws_bytes < need) {
+            set_error("quad: workspace %zu B < required %zu B", p.ws_bytes, need);
+            return SIGSVGD_E_WORKSPACE;
+        }
+        a.gacc = reinterpret_cast<double *>((reinterpret_cast<uintptr_t>(p.ws) + 255) & ~(uintptr_t)255);
+        hipError_t e = hipMemsetAsync(a.gacc, 0, nacc * sizeof(double), p.stream);
+        if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(gacc)");
+    }
+    int rc = quad_dispatch(p, a, grad, sym);
+    if (rc) return rc;
+    if (grad) {
+        const int bs = 256;
+        const unsigned gs = (unsigned)((nacc + bs - 1) / bs);
+        if (p.dtype == SIGSVGD_F64)
+            hipLaunchKernelGGL(quad_finalize_kernel<double>, dim3(gs), dim3(bs), 0, p.stream, a.gacc,
+                               static_cast<double *>(p.gradX_out), nacc);
+        else
+            hipLaunchKernelGGL(quad_finalize_kernel<float>, dim3(gs), dim3(bs), 0, p.stream, a.gacc,
+                               static_cast<float *>(p.gradX_out), nacc);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return hip_fail(e, "launch quad_finalize_kernel");
+    }
+    return SIGSVGD_OK;
+}
+
+// Sharded partial solve (sigsvgd_gram_sym_partial) for the long-path shapes: row tiles of 8 rows,
+// tiles tile_offset + k * tile_stride, both orientations of K stored into the caller-zeroed K_partial,
+// gradient shares accumulated (fp64 atomics) straight into the caller-zeroed grad_partial.
+int quad_sym_partial(const GramProblem &p, int tile_offset, int tile_stride, double *grad_partial)
+{
+    if (tile_stride < 1 || tile_offset < 0 || tile_offset >= tile_stride) {
+        set_error("bad tile_offset/tile_stride %d/%d", tile_offset, tile_stride);
+        return SIGSVGD_E_BADARG;
+    }
+    QuadArgs a;
+    quad_fill_args(p, a);
+    a.gacc = grad_partial;
+    a.tile_offset = tile_offset;
+    a.tile_stride = tile_stride;
+    return quad_dispatch(p, a, true, true);
+}
+
+} // namespace sigsvgd
