@@ -8,7 +8,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-OUT = os.path.join(ROOT, "sigsvgd_amd", "libsigsvgd_stamps.so")
+OUT = os.environ.get("SIGSVGD_STAMPS_LIB") or os.path.join(ROOT, "sigsvgd_amd", "libsigsvgd_stamps.so")
 
 
 def build():

@@ -83,6 +83,24 @@ __device__ __forceinline__ double q_ldany(const void *b, size_t i, int io64)
 {
     return io64 ? static_cast<const double *>(b)[i] : (double)static_cast<const float *>(b)[i];
 }
+// n consecutive elements (stride 1) as doubles, ONE uniform branch on the I/O type and independent loads (a branch
+// per element serialises the loads behind one s_waitcnt each)
+template <int N>
+__device__ __forceinline__ void q_ldrow(const void *b, size_t i0, int nvalid, int io64, double (&out)[N])
+{
+    if (io64) {
+        const double *p = static_cast<const double *>(b) + i0;
+#pragma unroll
+        for (int c = 0; c < N; ++c) out[c] = (c < nvalid) ? p[c] : 0.0;
+    } else {
+        const float *p = static_cast<const float *>(b) + i0;
+        float tmp[N];
+#pragma unroll
+        for (int c = 0; c < N; ++c) tmp[c] = (c < nvalid) ? p[c] : 0.f;
+#pragma unroll
+        for (int c = 0; c < N; ++c) out[c] = (double)tmp[c];
+    }
+}
 __device__ __forceinline__ void q_stany(void *b, size_t i, double v, int io64)
 {
     if (io64)
@@ -107,6 +125,34 @@ __device__ __forceinline__ float q_add_ror1(float acc, float v)
     float out;
     asm("v_add_f32_dpp %0, %1, %2 wave_ror:1 row_mask:0xf bank_mask:0xf" : "=v"(out) : "v"(acc), "v"(v));
     return out;
+}
+
+// 2^t as in sig_common.h (exp2_p7), with the coefficients in scalar registers: under this kernel's register pressure
+// hipcc otherwise materialises them as VGPR pairs and spills those (16 scratch round trips per use site)
+struct QExp7 {
+    double c7, c6, c5, c4, c3, c2, c1, c0;
+};
+__device__ __forceinline__ QExp7 qexp7_coef()
+{
+    return QExp7{1.5303701161442145e-05, 1.5469729221575116e-04, 1.3333478471058548e-03, 9.618025613268967e-03,
+                 5.5504109063307244e-02, 2.4022651213498578e-01, 6.931471805568296e-01,  0.9999999999595621};
+}
+__device__ __forceinline__ void qexp7_pin(QExp7 &k)
+{
+    asm volatile("" : "+s"(k.c7), "+s"(k.c6), "+s"(k.c5), "+s"(k.c4), "+s"(k.c3), "+s"(k.c2), "+s"(k.c1), "+s"(k.c0));
+}
+__device__ __forceinline__ double qexp2_p7(double t, const QExp7 &k)
+{
+    const double kf = __builtin_rint(t);
+    const double f = t - kf;
+    double p = __builtin_fma(k.c7, f, k.c6);
+    p = __builtin_fma(p, f, k.c5);
+    p = __builtin_fma(p, f, k.c4);
+    p = __builtin_fma(p, f, k.c3);
+    p = __builtin_fma(p, f, k.c2);
+    p = __builtin_fma(p, f, k.c1);
+    p = __builtin_fma(p, f, k.c0);
+    return ldexp(p, (int)kf);
 }
 
 // ---- four steps of a sweep (cf. gram_fast.hip for the scheduling rules).  Per step: DPP shift under full EXEC, the
@@ -194,10 +240,11 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
     __shared__ float colacc[(GRAD && SYM) ? 128 * CS : 4];
     constexpr int HN = 136; // hand-over rows: entries 0 .. 129 are read
     __shared__ float ones[HN];
-    __shared__ float hK_all[QNW * HN], hU_all[QNW * HN], hdummy_all[QNW * 64];
-    __shared__ double g64_all[QNW * 128], rdh_all[QNW * 128];
-    __shared__ float srow_all[GRAD ? QNW * 256 : 4];
-    __shared__ float x64_all[GRAD ? QNW * (DPAD + 2) : 4];
+    struct WaveLds { // everything a wavefront keeps for itself, behind ONE base address
+        double g64[128], rdh[128];
+        float hK[HN], hU[HN], hdummy[64], srow[256], x64[DPAD + 2];
+    };
+    __shared__ WaveLds wl_all[QNW];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int T = a.T, d = a.d, P = T - 1, io64 = a.io64;
@@ -225,30 +272,54 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
     const double inv_h = a.inv_h;
     const double nscale = -inv_h * 1.4426950408889634074;
     const float m2h = (float)(-2.0 * inv_h);
-    float *hK = hK_all + wave * HN, *hU = hU_all + wave * HN, *hdummy = hdummy_all + wave * 64;
-    double *g64 = g64_all + wave * 128, *rdh = rdh_all + wave * 128;
-    float *srow63 = srow_all + (GRAD ? wave * 256 : 0), *srow64 = srow63 + (GRAD ? 128 : 0);
-    float *x64 = x64_all + (GRAD ? wave * (DPAD + 2) : 0);
+    WaveLds &wl = wl_all[wave];
+    float *hK = wl.hK, *hU = wl.hU, *hdummy = wl.hdummy;
+    double *g64 = wl.g64, *rdh = wl.rdh;
+    float *srow63 = wl.srow, *srow64 = wl.srow + 128;
+    float *x64 = wl.x64;
     for (int e = tid; e < HN; e += NT) ones[e] = 1.f;
     for (int e = lane; e < HN; e += 64) hK[e] = 1.f, hU[e] = 1.f; // (entries the sweeps do not write stay at the boundary value)
 
 #ifdef SIGSVGD_PHASE_STAMPS
     unsigned long long ph_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast_ = __builtin_amdgcn_s_memtime();
 #endif
-    float gacc[2][DPAD]; // row-side gradient of (band, channel), summed over the column chunk in fp32
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int c = 0; c < DPAD; ++c) gacc[b][c] = 0.f;
 
     for (int j = j0; j < j1; ++j) {
+        // per-pair copies of the thread indices that the optimiser cannot see through: every index / address vector
+        // built from them is recomputed inside the pair instead of becoming a loop invariant of the column loop that
+        // is spilled and reloaded (one exposed scratch round trip each: measured 40 % of the kernel)
+        int tidp = tid, lanep = lane;
+        asm volatile("" : "+v"(tidp), "+v"(lanep));
         // ---- stage y_j (centred on its first point): fp64 rows + scaled norms, fp32 copy, both twice ----------
         __syncthreads();
-        for (int e = tid; e < 128 * DPAD; e += NT) {
+        constexpr int EPT = (128 * DPAD) / NT; // elements per thread: all loads of a thread are issued together
+        double sv[EPT], sr[EPT];
+        if (io64) {
+#pragma unroll
+            for (int k = 0; k < EPT; ++k) {
+                const int e = tidp + k * NT, t = e / DPAD, c = e % DPAD;
+                const bool ok = t < T && c < d;
+                sv[k] = ok ? static_cast<const double *>(a.Y)[((size_t)j * T + t) * d + c] : 0.0;
+                sr[k] = ok ? static_cast<const double *>(a.Y)[(size_t)j * T * d + c] : 0.0;
+            }
+        } else {
+            float fv[EPT], fr[EPT];
+#pragma unroll
+            for (int k = 0; k < EPT; ++k) {
+                const int e = tidp + k * NT, t = e / DPAD, c = e % DPAD;
+                const bool ok = t < T && c < d;
+                fv[k] = ok ? static_cast<const float *>(a.Y)[((size_t)j * T + t) * d + c] : 0.f;
+                fr[k] = ok ? static_cast<const float *>(a.Y)[(size_t)j * T * d + c] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < EPT; ++k) sv[k] = (double)fv[k], sr[k] = (double)fr[k];
+        }
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            const int e = tidp + k * NT;
             const int t = e / DPAD, c = e % DPAD;
-            const bool ok = t < T && c < d;
-            const double r0 = ok ? q_ldany(a.Y, (size_t)j * T * d + c, io64) : 0.0;
-            const double v = ok ? q_ldany(a.Y, ((size_t)j * T + t) * d + c, io64) - r0 : 0.0;
+            const double r0 = sr[k];
+            const double v = sv[k] - sr[k];
             const int r = 128 * (t >> 6) + (t & 63);
             yd[r * YDS + c] = v;
             yd[(r + 64) * YDS + c] = v;
@@ -266,9 +337,10 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
             }
         }
         if (GRAD && SYM)
-            for (int e = tid; e < 128 * CS; e += NT) colacc[e] = 0.f;
+            for (int e = tidp; e < 128 * CS; e += NT) colacc[e] = 0.f;
         __syncthreads();
 
+        SIG_QSTAMP(7)
         if (row_ok && (!SYM || j >= i)) {
             float w_ij = 1.f, w_ji = 1.f; // row-side / column-side weights
             if (GRAD) {
@@ -282,34 +354,36 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                 if (SYM && j == i) w_ji = 0.f; // diagonal pair: first-slot derivative only
             }
 
-            // ---- G row 64 (the row beyond band 0): differences along the row for lane 63 of band 0 ------------
+            // ---- G row 64 (the row beyond band 0): differences along the row for lanep 63 of band 0 ------------
             {
-                double xs2[DPAD], xn2 = 0.0;
+                QExp7 ek = qexp7_coef();
+                double xs2[DPAD], xn2 = 0.0, xr2[DPAD];
+                q_ldrow<DPAD>(a.X, ((size_t)i * T + 64) * d, d, io64, xr2);
 #pragma unroll
                 for (int c = 0; c < DPAD; ++c) {
-                    const double xc = (c < d) ? q_ldany(a.X, ((size_t)i * T + 64) * d + c, io64) - yref[c] : 0.0;
+                    const double xc = (c < d) ? xr2[c] - yref[c] : 0.0;
                     xn2 = __builtin_fma(xc, xc, xn2);
                     xs2[c] = xc * (-2.0 * nscale);
-                    if (GRAD && lane == 0) x64[c] = (float)xc;
+                    if (GRAD && lanep == 0) x64[c] = (float)xc;
                 }
                 xn2 = __builtin_fma(xn2, nscale, -1.79248125036057809); // G / sqrt(12), as in the quadrant passes
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh) {
-                    const double *yr = yd + (128 * hh + lane) * YDS;
+                    const double *yr = yd + (128 * hh + lanep) * YDS;
                     double e2 = xn2 + yr[DPAD];
 #pragma unroll
                     for (int c = 0; c < DPAD; ++c) e2 = __builtin_fma(xs2[c], yr[c], e2);
-                    g64[lane + 64 * hh] = exp2_p7(e2);
+                    g64[lanep + 64 * hh] = qexp2_p7(e2, ek);
                 }
                 if (GRAD) {
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) srow63[lane + 64 * u] = 0.f; // (both seam rows: 256 floats)
+                    for (int u = 0; u < 4; ++u) srow63[lanep + 64 * u] = 0.f; // (both seam rows: 256 floats)
                 }
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): the row is in LDS before it is read back
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh) {
-                    const int n = lane + 64 * hh;
+                    const int n = lanep + 64 * hh;
                     rdh[n] = g64[n] - g64[(n - 1) & 127];
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -322,6 +396,11 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
             float rc = 1.f, rdA = 1.f, rdB = 1.f, rV = 0.f; // reverse chain (U)
             float cap0h0 = 0.f, cap63h0 = 0.f, cap0h1 = 0.f; // S[l][0], S[l][63] of half 0, S[l][64] (first of half 1)
             float xf[DPAD];
+            // row-side contraction sums of the band in work: carried over its two reverse visits, sent when the band is done
+            float s0 = 0.f;
+            qf32x2 acc[DPAD / 2];
+#pragma unroll
+            for (int c = 0; c < DPAD / 2; ++c) acc[c] = qf32x2{0.f, 0.f};
             int rev_band = -1;
             bool kdone = false;
 
@@ -348,16 +427,20 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                 const int b = code & 1, h = (code >> 1) & 1;
                 const bool rev = (code & 4) != 0, leave_k = (code & 8) != 0;
                 const int nrows = b ? nrows1 : 64, ncols = h ? nrows1 : 64;
-                const int m = 64 * b + lane; // point row of this lane
+                QExp7 ek = qexp7_coef();
+                int lv = lanep; // per-visit copy the optimiser cannot see through: address vectors built from it stay inside
+                asm volatile("" : "+v"(lv)); // the visit instead of becoming spilled loop invariants
+                const int m = 64 * b + lv; // point row of this lanep
                 const unsigned long long rows = nrows >= 64 ? ~0ull : ((1ull << nrows) - 1ull);
                 const unsigned long long *mk = QUAD_MASK.m[ncols];
 
                 // ---- x_m, centred and pre-scaled (fp64 for the static kernel, fp32 for the gradient pass); re-read on
                 // every visit (L2 hits) so that the fp64 copy is not live across the gradient pass
                 double xs[DPAD], xn = 0.0;
+                q_ldrow<DPAD>(a.X, ((size_t)i * T + min(m, P)) * d, d, io64, xs);
 #pragma unroll
                 for (int c = 0; c < DPAD; ++c) {
-                    const double xc = (m <= P && c < d) ? q_ldany(a.X, ((size_t)i * T + m) * d + c, io64) - yref[c] : 0.0;
+                    const double xc = (m <= P && c < d) ? xs[c] - yref[c] : 0.0;
                     xn = __builtin_fma(xc, xc, xn);
                     xs[c] = xc * (-2.0 * nscale);
                     xf[c] = (float)xc;
@@ -365,9 +448,9 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                 xn = __builtin_fma(xn, nscale, -1.79248125036057809); // - log2(sqrt(12)): D slots hold D / sqrt(12)
 
                 SIG_QSTAMP(0)
-                // ---- phase 1: G row (skewed: local column (t - lane) & 63 on iteration t) -> D slots --------------
+                // ---- phase 1: G row (skewed: local column (t - lanep) & 63 on iteration t) -> D slots --------------
                 {
-                    const double *ybase = yd + (128 * h + 64 - lane) * YDS; // local column (t - lane) & 63 == ybase + t * YDS
+                    const double *ybase = yd + (128 * h + 64 - lv) * YDS; // local column (t - lanep) & 63 == ybase + t * YDS
                     // the point column that closes the last cell column of half 0 (column 64) is outside the ring
                     double g64v = 0.0;
                     if (h == 0) {
@@ -375,7 +458,7 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                         double e2 = xn + yr[DPAD];
 #pragma unroll
                         for (int c = 0; c < DPAD; ++c) e2 = __builtin_fma(xs[c], yr[c], e2);
-                        g64v = exp2_p7(e2);
+                        g64v = qexp2_p7(e2, ek);
                     }
                     const double *rdhh = rdh + 64 * h;
                     double g0 = 0.0, g1 = 0.0, gprev = 0.0, rdprev = 0.0;
@@ -384,8 +467,13 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                     double yrow[DPAD + 1];
 #pragma unroll
                     for (int c = 0; c <= DPAD; ++c) yrow[c] = ybase[c];
+#ifdef QEXP_NOP1
+#define QP1_N 4
+#else
+#define QP1_N 66
+#endif
 #pragma unroll
-                    for (int t = 0; t < 66; ++t) {
+                    for (int t = 0; t < QP1_N; ++t) {
                         double g;
                         if (t < 64) {
                             double e2 = xn + yrow[DPAD];
@@ -397,19 +485,20 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
                                 for (int c = 0; c <= DPAD; ++c) yrow[c] = yr[c];
                             }
-                            g = exp2_p7(e2);
+                            qexp7_pin(ek);
+                            g = qexp2_p7(e2, ek);
                             if (t == 0) g0 = g;
                             if (t == 1) g1 = g;
                         } else {
                             g = (t == 64) ? g0 : g1;
                         }
-                        // a lane at local column 0 closes the previous row segment: G[m][64 h + 64] - G[m][64 h + 63]
-                        const double gsel = (lane == (t & 63)) ? g64v : g;
+                        // a lanep at local column 0 closes the previous row segment: G[m][64 h + 64] - G[m][64 h + 63]
+                        const double gsel = (lv == (t & 63)) ? g64v : g;
                         const double rd = gsel - gprev; // G[m, c] - G[m, c-1]
                         gprev = g;
                         if (t >= 2) {
-                            // lane l+1 holds the same column difference one iteration later; lane 63 of band 0 takes the
-                            // row beyond the band (G row 64) from LDS: a virtual lane 64 is at local column t & 63
+                            // lanep l+1 holds the same column difference one iteration later; lanep 63 of band 0 takes the
+                            // row beyond the band (G row 64) from LDS: a virtual lanep 64 is at local column t & 63
                             const int cc = (t & 63) ? (t & 63) : 64;
                             const double beyond = (64 * h + cc < 128) ? rdhh[cc] : 0.0;
                             const double nb = q_shl_keep(rd, beyond);
@@ -424,23 +513,28 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                 SIG_QSTAMP(1)
                 // ---- phase 2: forward sweep of the quadrant -----------------------------------------------------
                 {
-                    const float *topb = (b ? hK : ones) + 64 * h; // K[64 b][64 h + q + 1] for lane 0 on step sigma = q
+                    const float *topb = (b ? hK : ones) + 64 * h; // K[64 b][64 h + q + 1] for lanep 0 on step sigma = q
                     if (h == 0) { // a new band: left boundary column of ones
                         fc = 1.f;
                         fV = 0.f;
-                        fuA = (lane == 0) ? topb[1] : 1.f;
-                        fuB = (lane == 0) ? topb[0] : 1.f;
+                        fuA = (lanep == 0) ? topb[1] : 1.f;
+                        fuB = (lanep == 0) ? topb[0] : 1.f;
                     }
-                    // lane 63 leaves K[64 b + 64][64 h + q + 1] after step sigma = 63 + q
+                    // lanep 63 leaves K[64 b + 64][64 h + q + 1] after step sigma = 63 + q
                     const unsigned ho = (unsigned)(size_t)(leave_k ? hK + 64 * h + 1 : hdummy + 63);
-                    int haddr = (int)((lane == 63) ? ho : (unsigned)(size_t)(hdummy + lane));
-                    const int hinc = (lane == 63 && leave_k) ? 4 : 0;
+                    int haddr = (int)((lv == 63) ? ho : (unsigned)(size_t)(hdummy + lv));
+                    const int hinc = (lanep == 63 && leave_k) ? 4 : 0;
                     float r3 = 1.7320508075688772f;
                     asm volatile("" : "+s"(r3));
 #pragma unroll
                     for (int k = 0; k < 64; ++k) Ssl[k] = 0.f; // slots without a grid cell must read as S = 0
+#ifdef QEXP_NOSWEEP
+#define QSW_N 8
+#else
+#define QSW_N 128
+#endif
 #pragma unroll
-                    for (int s0 = 0; s0 < 128; s0 += 4) {
+                    for (int s0 = 0; s0 < QSW_N; s0 += 4) {
                         float bn[4];
 #pragma unroll
                         for (int u = 0; u < 4; ++u) bn[u] = topb[(s0 + u + 2 < 66) ? s0 + u + 2 : 66];
@@ -450,7 +544,7 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                 SIG_QSTAMP(2)
                 if (!kdone && b == b_last && h == h_last) { // K[P][P]: last value of the last row with cells
                     kdone = true;
-                    if (lane == nrows - 1) {
+                    if (lanep == nrows - 1) {
                         q_stany(a.K, (size_t)i * a.B + j, (double)fc, io64);
                         if (SYM && j != i) q_stany(a.K, (size_t)j * a.B + i, (double)fc, io64);
                     }
@@ -460,57 +554,59 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                 // ---- phase 3: reverse sweep (S = K_fwd * U replaces K_fwd slot by slot) -------------------------
                 {
                     const bool below = (b == 0) && nrows1 > 0;    // band 1 lies below: U[64][.] is in hU
-                    const float *botb = (below ? hU : ones) + 64 * h; // U[64 b + 64][64 h + q] for lane 63 on step sigma = q + 63
+                    const float *botb = (below ? hU : ones) + 64 * h; // U[64 b + 64][64 h + q] for lanep 63 on step sigma = q + 63
                     if (rev_band != b) { // first reverse quadrant of the band: right boundary column of ones
                         rev_band = b;
+                        s0 = 0.f;
+#pragma unroll
+                        for (int c = 0; c < DPAD / 2; ++c) acc[c] = qf32x2{0.f, 0.f};
                         rc = 1.f;
                         rV = 0.f;
-                        // lane 63 starts on step 62 + ncols with the lower neighbour U[64 b + 64][64 h + ncols - 1] and the
+                        // lanep 63 starts on step 62 + ncols with the lower neighbour U[64 b + 64][64 h + ncols - 1] and the
                         // corner U[.][64 h + ncols]; odd steps shift into dnA, even steps into dnB
                         const float c1 = botb[ncols], c0 = botb[ncols - 1];
                         const bool odd = ((62 + ncols) & 1) != 0;
-                        rdA = (lane == 63) ? (odd ? c0 : c1) : 1.f;
-                        rdB = (lane == 63) ? (odd ? c1 : c0) : 1.f;
+                        rdA = (lanep == 63) ? (odd ? c0 : c1) : 1.f;
+                        rdB = (lanep == 63) ? (odd ? c1 : c0) : 1.f;
                     }
-                    // lane 0 of band 1 leaves U[64][64 h + q] after step sigma = q
+                    // lanep 0 of band 1 leaves U[64][64 h + q] after step sigma = q
                     const bool leave_u = (b == 1);
                     const unsigned ho = (unsigned)(size_t)(leave_u ? hU + 64 * h + ncols - 1 : hdummy);
-                    int haddr = (int)((lane == 0) ? ho : (unsigned)(size_t)(hdummy + lane));
-                    const int hinc = (lane == 0 && leave_u) ? -4 : 0;
+                    int haddr = (int)((lv == 0) ? ho : (unsigned)(size_t)(hdummy + lv));
+                    const int hinc = (lanep == 0 && leave_u) ? -4 : 0;
                     float r3 = 1.7320508075688772f;
                     asm volatile("" : "+s"(r3));
 #pragma unroll
-                    for (int s0 = 124; s0 >= 0; s0 -= 4) {
+                    for (int s0 = QSW_N - 4; s0 >= 0; s0 -= 4) {
                         // after step sigma the boundary value of step sigma - 1: U[.][64 h + sigma - 1 - 63]
                         float bn[4];
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
                             const int sg = s0 + 3 - u; // the step executed
-                            // (step 63 of a right quadrant hands lane 63 the first value of the left one: index -1)
+                            // (step 63 of a right quadrant hands lanep 63 the first value of the left one: index -1)
                             bn[u] = botb[(sg >= 64) ? sg - 64 : ((sg == 63) ? -h : 0)];
                         }
                         quad_rev4(rc, rdA, rdB, rV, &Dsl[s0 & 63], &Ssl[s0 & 63], mk + s0, rows, bn, haddr, hinc, r3);
                     }
                 }
                 SIG_QSTAMP(3)
-                // ---- seam rows for the hand-over pass: S[63][.] (band 0, lane 63), S[64][.] (band 1, lane 0) ------
-                if (lane == (b ? 0 : 63)) {
+                // ---- seam rows for the hand-over pass: S[63][.] (band 0, lanep 63), S[64][.] (band 1, lanep 0) ------
+                // (slot k of lanep l is local column (k - l) & 63; the index is formed from scalars: per-lanep index vectors
+                //  are loop invariants that hipcc hoists out of the pair loop and spills -- 64 serialised scratch loads)
+                if (lanep == (b ? 0 : 63)) {
                     float *dst = (b ? srow64 : srow63) + 64 * h;
+                    const int off = b ? 0 : 1;
 #pragma unroll
-                    for (int k = 0; k < 64; ++k) dst[(k - lane) & 63] = Ssl[k];
+                    for (int k = 0; k < 64; ++k) dst[(k + off) & 63] = Ssl[k];
                 }
 
                 // ---- phase 4: 4-corner scatter R, static kernel in fp32, both contractions -----------------------
-                // iteration it: lane l is at local column n = (it - l) & 63; own row S[l][n] is slot it, the upper row
-                // arrives through a wave shift one column ahead (lane l-1's slot it holds S[l-1][n+1]), hence the
+                // iteration it: lanep l is at local column n = (it - l) & 63; own row S[l][n] is slot it, the upper row
+                // arrives through a wave shift one column ahead (lanep l-1's slot it holds S[l-1][n+1]), hence the
                 // two-deep history of the shifted values.  Local point column 0 needs the cell column left of the
                 // quadrant: it is masked here and done per band from the values captured at the wrap.
-                const float rowmask = (b == 1 && lane == 0) ? 0.f : 1.f; // point row 64 is contracted in the seam pass
+                const float rowmask = (b == 1 && lanep == 0) ? 0.f : 1.f; // point row 64 is contracted in the seam pass
                 const float ns32 = (float)nscale;
-                float s0 = 0.f;
-                qf32x2 acc[DPAD / 2];
-#pragma unroll
-                for (int c = 0; c < DPAD / 2; ++c) acc[c] = qf32x2{0.f, 0.f};
                 {
                     float t0 = 0.f, tacc[DPAD]; // column-side travelling sums (SYM)
 #pragma unroll
@@ -519,12 +615,18 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                     float Nc = q_shr_zero(Ssl[62]); // S[l-1][n-1]
                     float Nb = q_shr_zero(Ssl[63]); // S[l-1][n]
                     float Sprev = Ssl[63];          // S[l][n-1]
-                    const float *yfb = yf + (128 * h + 64 - lane) * YFS;
+                    const float *yfb = yf + (128 * h + 64 - lv) * YFS;
                     qf32x2 ynx[DPAD / 2]; // the y~ row of the next iteration (fetched one iteration ahead)
 #pragma unroll
                     for (int c = 0; c < DPAD / 2; ++c) ynx[c] = reinterpret_cast<const qf32x2 *>(yfb)[c];
+                    SIG_QSTAMP(6)
+#ifdef QEXP_NOPH4
+#define QPH4_N 2
+#else
+#define QPH4_N 64
+#endif
 #pragma unroll
-                    for (int it = 0; it < 64; ++it) {
+                    for (int it = 0; it < QPH4_N; ++it) {
                         qf32x2 yr2[DPAD / 2];
 #pragma unroll
                         for (int c = 0; c < DPAD / 2; ++c) yr2[c] = ynx[c];
@@ -535,7 +637,11 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                         }
                         const float Scur = Ssl[it];
                         const float Na = q_shr_zero(Scur); // S[l-1][n+1]
-                        const bool wrap = lane == it;      // local column 0
+#ifdef QEXP_NOWRAP
+                        const bool wrap = false;
+#else
+                        const bool wrap = lv == it;        // local column 0
+#endif
                         float R = ((Nc - Nb) + (Scur - Sprev)) * rowmask;
                         capA = wrap ? Scur : capA;
                         capB = wrap ? Sprev : capB;
@@ -551,13 +657,21 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                             const qf32x2 df = qf32x2{xf[2 * c], xf[2 * c + 1]} - yr2[c];
                             e2 = __builtin_elementwise_fma(df, df, e2);
                         }
+#ifdef QEXP_NOG
+                        const float gv = e2[0];
+#else
                         const float gv = __builtin_amdgcn_exp2f((e2[0] + e2[1]) * ns32);
+#endif
                         const float rg = R * gv;
                         const qf32x2 rg2 = {rg, rg};
                         s0 += rg;
 #pragma unroll
                         for (int c = 0; c < DPAD / 2; ++c) acc[c] = __builtin_elementwise_fma(rg2, yr2[c], acc[c]);
+#ifdef QEXP_NOSYM
+                        if (false) {
+#else
                         if (SYM) {
+#endif
                             const float rgw = rg * w_ji;
                             t0 = q_add_ror1(t0, rgw);
 #pragma unroll
@@ -568,21 +682,22 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
+                    SIG_QSTAMP(4)
                     if (h == 0) {
                         cap0h0 = capA;
                         cap63h0 = capB;
                     } else {
                         cap0h1 = capA;
                     }
-                    if (SYM) { // the finished sums of local column (63 - lane) & 63 join the tile's image
-                        float *dst = colacc + (64 * h + ((63 - lane) & 63)) * CS;
+                    if (SYM) { // the finished sums of local column (63 - lanep) & 63 join the tile's image
+                        float *dst = colacc + (64 * h + ((63 - lv) & 63)) * CS;
 #pragma unroll
                         for (int c = 0; c < DPAD; ++c) atomicAdd(dst + c, tacc[c]);
                         atomicAdd(dst + DPAD, t0);
                     }
                 }
 
-                SIG_QSTAMP(4)
+                SIG_QSTAMP(7)
                 // ---- the band's seam columns (after its left quadrant): point columns 0 and 64 ---------------------
                 if (h == 0) {
 #pragma unroll
@@ -601,7 +716,7 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                             acc[c][0] = __builtin_fmaf(rg, yr[2 * c], acc[c][0]);
                             acc[c][1] = __builtin_fmaf(rg, yr[2 * c + 1], acc[c][1]);
                         }
-                        if (SYM) { // one column, 64 rows: wave sums, lane c adds channel c (all lanes on one address would
+                        if (SYM) { // one column, 64 rows: wave sums, lanep c adds channel c (all lanes on one address would
                                    // serialise 64-fold in LDS)
                             const float rgw = rg * w_ji;
                             float mine = 0.f;
@@ -610,25 +725,29 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                                 float vsum = (c < DPAD) ? rgw * xf[c] : rgw;
 #pragma unroll
                                 for (int off = 32; off >= 1; off >>= 1) vsum += __shfl_xor(vsum, off, 64);
-                                mine = (lane == c) ? vsum : mine;
+                                mine = (lv == c) ? vsum : mine;
                             }
-                            if (lane <= DPAD) atomicAdd(colacc + (64 * sc) * CS + lane, mine);
+                            if (lanep <= DPAD) atomicAdd(colacc + (64 * sc) * CS + lanep, mine);
                         }
                     }
                     cap0h0 = cap63h0 = cap0h1 = 0.f;
-                }
+                    // the band is done: its row-side gradient d k(x_i, y_j) / d x_i[m] goes to the fp64 accumulation buffer
+                    // (point row 64 comes from the seam pass below)
+                    if (m <= P && !(b == 1 && lv == 0)) {
 #pragma unroll
-                for (int c = 0; c < DPAD; ++c) {
-                    const float gv = w_ij * m2h * (xf[c] * s0 - acc[c / 2][c % 2]);
-                    gacc[0][c] += b ? 0.f : gv; // (static indices: a runtime band index would put the array in scratch)
-                    gacc[1][c] += b ? gv : 0.f;
+                        for (int c = 0; c < DPAD; ++c)
+                            if (c < d)
+                                unsafeAtomicAdd(&a.gacc[((size_t)i * T + m) * d + c],
+                                                (double)(w_ij * m2h * (xf[c] * s0 - acc[c / 2][c % 2])));
+                    }
                 }
                 SIG_QSTAMP(5)
             } // quadrant visits
 
+            SIG_QSTAMP(0)
             if (GRAD) {
                 // ---- seam: point row 64.  R[64][n] = (S[63][n-1] - S[63][n]) - (S[64][n-1] - S[64][n]), formed from both
-                // bands' rows before the contraction; lanes take columns n = lane and lane + 64.
+                // bands' rows before the contraction; lanes take columns n = lanep and lanep + 64.
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_s_waitcnt(0xc07f);
                 float ps0 = 0.f, part[DPAD], xm[DPAD];
@@ -640,10 +759,10 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                 const float ns32 = (float)nscale;
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh) {
-                    const int n = lane + 64 * hh;
+                    const int n = lanep + 64 * hh;
                     const float Sa = n ? srow63[n - 1] : 0.f, Sz = srow63[n];
                     const float Ta = n ? srow64[n - 1] : 0.f, Tz = srow64[n];
-                    const float *yr = yf + (128 * hh + lane) * YFS;
+                    const float *yr = yf + (128 * hh + lanep) * YFS;
                     float e2 = 0.f;
 #pragma unroll
                     for (int c = 0; c < DPAD; ++c) e2 = __builtin_fmaf(xm[c] - yr[c], xm[c] - yr[c], e2);
@@ -658,22 +777,23 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                         atomicAdd(dst + DPAD, rgn * w_ji);
                     }
                 }
-                // row 64 belongs to band 1's lane 0 accumulators
+                // row 64 belongs to band 1's lanep 0 accumulators
 #pragma unroll
                 for (int c = 0; c < DPAD; ++c) {
                     float v = w_ij * m2h * (xm[c] * ps0 - part[c]);
 #pragma unroll
                     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-                    if (lane == 0) gacc[1][c] += v;
+                    if (lanep == 0 && c < d) unsafeAtomicAdd(&a.gacc[((size_t)i * T + 64) * d + c], (double)v);
                 }
             }
+            SIG_QSTAMP(6)
         } // this wavefront's pair
 
         if (GRAD && SYM) {
             // close the column-side sums of y_j over the rows of the tile:
             // d/dy_n = -(2/h) * (y~_n * sum_m w R G - sum_m w R G x~_m)
             __syncthreads();
-            for (int e = tid; e < T * DPAD; e += NT) {
+            for (int e = tidp; e < T * DPAD; e += NT) {
                 const int n = e / DPAD, c = e % DPAD;
                 const float sw = colacc[n * CS + DPAD], sx = colacc[n * CS + c];
                 const float v = m2h * (yf[(128 * (n >> 6) + (n & 63)) * YFS + c] * sw - sx);
@@ -687,16 +807,6 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
     if (lane == 0 && a.stamps)
         for (int k = 0; k < 8; ++k) atomicAdd(&a.stamps[k], ph_[k]);
 #endif
-    if (GRAD && row_ok) {
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            const int p = kb * 64 + lane;
-            if (p < T)
-#pragma unroll
-                for (int c = 0; c < DPAD; ++c)
-                    if (c < d) unsafeAtomicAdd(&a.gacc[((size_t)i * T + p) * d + c], (double)gacc[kb][c]);
-        }
-    }
 }
 
 template <typename IO>
@@ -768,9 +878,9 @@ int quad_launch_variant(const GramProblem &p, QuadArgs &a, bool grad, bool sym)
         double tot = 0;
         for (int k = 0; k < 8; ++k) tot += (double)hst[k];
         static const char *nm[8] = {"staging/other", "phase 1 static kernel", "forward sweep", "reverse sweep",
-                                    "gradient pass", "seams + row sums", "-", "-"};
+                                    "gradient pass", "seams + row sums", "row seam (+ gradient-pass prologue)", "Y staging + barriers (+ column-sum flush)"};
         fprintf(stderr, "[phase stamps quad] A=%d T=%d d=%d grad=%d sym=%d: ", p.A, p.T, p.d, (int)grad, (int)sym);
-        for (int k = 0; k < 6; ++k) fprintf(stderr, "%s %.1f%% | ", nm[k], 100.0 * (double)hst[k] / tot);
+        for (int k = 0; k < 8; ++k) fprintf(stderr, "%s %.1f%% | ", nm[k], 100.0 * (double)hst[k] / tot);
         fprintf(stderr, "total %.3e wave-cycles\n", tot);
     }
 #endif
