@@ -67,10 +67,11 @@ extern "C" {
 #define SIGSVGD_FLAG_SYM 2u          /* sigkernel sym=True backward weighting: go + go^T (A==B) */
 #define SIGSVGD_FLAG_Y_IS_X 4u       /* caller guarantees Y aliases X (same values): lets the   */
                                      /* library solve each unordered pair once                  */
-#define SIGSVGD_FLAG_STORED_FORWARD 32u /* long paths (65 <= T <= 128): use the banded kernel, which keeps the forward     */
-                                       /* solution (gram_band.hip) instead of regenerating it: no limit on the roughness  */
-                                       /* of the paths, at 2-3x the time of the streaming kernel on smooth ones.  This is  */
-                                       /* where callers send the launches the streaming kernel declined (NaN gradients).   */
+#define SIGSVGD_FLAG_STORED_FORWARD 32u /* long paths (65 <= T <= 128): use the quadrant kernel (gram_quad.hip), which keeps  */
+                                       /* the forward solution instead of regenerating it: no limit on the roughness of    */
+                                       /* the paths.  It is the default for d > 8; with d <= 8 the streaming kernel is     */
+                                       /* faster on smooth paths and this flag is where callers send the launches it       */
+                                       /* declined (NaN gradients), at 1.1-1.3x its time.                                  */
 #define SIGSVGD_FLAG_WS_CLEAN 16u     /* the caller guarantees that the workspace is ZERO on entry (fresh, or left  */
                                       /* by an earlier call with this flag); honoured by the register-resident       */
                                       /* gradient launches (dyadic order 0, T <= 64), which then issue no memset and */

@@ -14,4 +14,4 @@ sf = arg.endswith('q')
 shapes = {'c5q':[(256,128,14)],'streamq':[(256,128,14),(256,100,7),(256,96,3)],'c5bigq':[(1024,128,14)]}.get(arg, shapes)
 for (N,T,d) in shapes:
     X,s=synthetic_inputs(N,T,d); X=X.to(dev)
-    print(f'N={N} T={T} d={d}: sym %.3f ms | ordered %.3f ms | fwd %.3f ms'%(t(lambda: ops.gram_fwd_bwd(X,X,1.0,y_is_x=True,stored_forward=sf)), t(lambda: ops.gram_fwd_bwd(X,X,1.0,stored_forward=sf)), t(lambda: ops.gram_fwd(X,X,1.0))), flush=True)
+    print(f'N={N} T={T} d={d}: sym %.3f ms | ordered %.3f ms | fwd %.3f ms | fwd sym %.3f ms'%(t(lambda: ops.gram_fwd_bwd(X,X,1.0,y_is_x=True,stored_forward=sf)), t(lambda: ops.gram_fwd_bwd(X,X,1.0,stored_forward=sf)), t(lambda: ops.gram_fwd(X,X,1.0,stored_forward=sf)), t(lambda: ops.gram_fwd(X,X,1.0,y_is_x=True,stored_forward=sf))), flush=True)

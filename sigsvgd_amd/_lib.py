@@ -14,7 +14,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_PKG, "csrc")
 # SIGSVGD_LIB_PATH: A/B benchmarking of two builds on the same GPU box (scripts/ab.py); never set in tests
 LIB_PATH = os.environ.get("SIGSVGD_LIB_PATH") or os.path.join(_PKG, "libsigsvgd_hip.so")
-SOURCES = ["capi.hip", "gram_generic.hip", "gram_fast.hip", "gram_stream.hip", "gram_band.hip", "gram_quad.hip", "svgd_phi.hip",
+SOURCES = ["capi.hip", "gram_generic.hip", "gram_fast.hip", "gram_stream.hip", "gram_quad.hip", "svgd_phi.hip",
            "vec_kernels.hip", "cost_kernels.hip"]
 HEADERS = [os.path.join(_CSRC, "sig_common.h"), os.path.join(_PKG, "..", "include", "sigsvgd_hip.h")]
 

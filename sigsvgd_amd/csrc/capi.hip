@@ -114,11 +114,13 @@ static int dispatch(const GramProblem &p)
     (void)want_grad;
     if (!(p.flags & SIGSVGD_FLAG_FORCE_GENERIC) && fast_supported(p.A, p.B, p.T, p.d, p.n, p.kind, p.flags))
         return fast_launch(p);
-    // long paths: the streaming kernel by default (fastest on smooth paths, refuses rough pairs with NaN gradients);
-    // SIGSVGD_FLAG_STORED_FORWARD selects the banded kernel, which keeps the forward solution (any roughness)
-    if (!(p.flags & SIGSVGD_FLAG_FORCE_GENERIC) && (p.flags & SIGSVGD_FLAG_STORED_FORWARD) &&
+    // long paths (65 <= T <= 128): the quadrant kernel keeps the forward solution (no limit on roughness); it is the
+    // default for more than 8 channels (C5: d = 14), where it is also the faster one, and on request
+    // (SIGSVGD_FLAG_STORED_FORWARD).  With <= 8 channels the streaming kernel is faster on smooth paths; it refuses
+    // rough pairs with NaN gradients and the host repeats such launches with the flag.
+    if (!(p.flags & SIGSVGD_FLAG_FORCE_GENERIC) && ((p.flags & SIGSVGD_FLAG_STORED_FORWARD) || p.d > 8) &&
         quad_supported(p.A, p.B, p.T, p.d, p.n, p.kind, p.flags))
-        return getenv("SIGSVGD_BAND") ? band_launch(p) : quad_launch(p);
+        return quad_launch(p);
     if (!(p.flags & SIGSVGD_FLAG_FORCE_GENERIC) && stream_supported(p.A, p.B, p.T, p.d, p.n, p.kind, p.flags))
         return stream_launch(p);
     return generic_launch(p);
@@ -145,7 +147,7 @@ int sigsvgd_gram_workspace_bytes(int A, int B, int T, int d, int dyadic_order, i
     if (!(flags & SIGSVGD_FLAG_FORCE_GENERIC) && fast_supported(A, B, T, d, dyadic_order, SIGSVGD_STATIC_RBF, flags))
         return fast_workspace_bytes(A, B, T, d, want_grad, flags, bytes);
     if (!(flags & SIGSVGD_FLAG_FORCE_GENERIC) && stream_supported(A, B, T, d, dyadic_order, SIGSVGD_STATIC_RBF, flags))
-        return stream_workspace_bytes(A, T, d, want_grad, bytes); // (the banded kernel needs the same)
+        return stream_workspace_bytes(A, T, d, want_grad, bytes); // (the quadrant kernel needs the same)
     return generic_workspace_bytes(A, B, T, d, dyadic_order, want_grad, bytes);
 }
 
@@ -195,7 +197,7 @@ int sigsvgd_gram_sym_partial(const void *X, int N, int T, int d, int dtype, doub
     GramProblem p{X, X, N, N, T, d, dtype, inv_h, 0, static_kind, flags | SIGSVGD_FLAG_Y_IS_X, grad_out,
                   K_partial, grad_partial, workspace, workspace_bytes, static_cast<hipStream_t>(stream)};
     Range range("sigsvgd_gram_sym_partial");
-    if (!fast_supported(N, N, T, d, 0, static_kind, flags) && (flags & SIGSVGD_FLAG_STORED_FORWARD) &&
+    if (!fast_supported(N, N, T, d, 0, static_kind, flags) && ((flags & SIGSVGD_FLAG_STORED_FORWARD) || d > 8) &&
         quad_supported(N, N, T, d, 0, static_kind, flags))
         return quad_sym_partial(p, tile_offset, tile_stride, grad_partial);
     if (!fast_supported(N, N, T, d, 0, static_kind, flags) && stream_supported(N, N, T, d, 0, static_kind, flags))

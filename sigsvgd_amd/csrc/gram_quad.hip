@@ -119,6 +119,31 @@ __device__ __forceinline__ float q_shr_zero(float v) // lane l <- lane l-1, lane
 {
     return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x138, 0xF, 0xF, true));
 }
+// sum over the 64 lanes in six DPP adds (no LDS round trips); the total ends up in lane 63
+__device__ __forceinline__ float q_wave_sum63(float v)
+{
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xF, 0xF, true)); // row_shr:1
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112, 0xF, 0xF, true)); // row_shr:2
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xF, 0xF, true)); // row_shr:4
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x118, 0xF, 0xF, true)); // row_shr:8 (inclusive scan of each row of 16)
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, true)); // row_bcast:15 into rows 1, 3
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xC, 0xF, true)); // row_bcast:31 into rows 2, 3
+    return v;
+}
+// G[m][n] = 2^(-log2(e)/h * |x~_m - y~_n|^2) in fp32, from the DIFFERENCES (the expanded form loses 6e-8 of its largest
+// term, 1e-5 of G for rough paths).  ONE expression for the gradient pass and both seam passes: the row-side sums
+// telescope exactly (constant column paths give an exactly zero gradient) only if every point sees the same bits.
+template <int DPAD>
+__device__ __forceinline__ float q_gval(const float (&xf)[DPAD], const qf32x2 (&y2)[DPAD / 2], float ns32)
+{
+    qf32x2 e2 = qf32x2{0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < DPAD / 2; ++c) {
+        const qf32x2 df = qf32x2{xf[2 * c], xf[2 * c + 1]} - y2[c];
+        e2 = __builtin_elementwise_fma(df, df, e2);
+    }
+    return __builtin_amdgcn_exp2f((e2[0] + e2[1]) * ns32);
+}
 // rotate-and-add in one VALU instruction: returns acc[lane-1] + v (lane 0 reads lane 63)
 __device__ __forceinline__ float q_add_ror1(float acc, float v)
 {
@@ -467,13 +492,8 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                     double yrow[DPAD + 1];
 #pragma unroll
                     for (int c = 0; c <= DPAD; ++c) yrow[c] = ybase[c];
-#ifdef QEXP_NOP1
-#define QP1_N 4
-#else
-#define QP1_N 66
-#endif
 #pragma unroll
-                    for (int t = 0; t < QP1_N; ++t) {
+                    for (int t = 0; t < 66; ++t) {
                         double g;
                         if (t < 64) {
                             double e2 = xn + yrow[DPAD];
@@ -528,13 +548,8 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                     asm volatile("" : "+s"(r3));
 #pragma unroll
                     for (int k = 0; k < 64; ++k) Ssl[k] = 0.f; // slots without a grid cell must read as S = 0
-#ifdef QEXP_NOSWEEP
-#define QSW_N 8
-#else
-#define QSW_N 128
-#endif
 #pragma unroll
-                    for (int s0 = 0; s0 < QSW_N; s0 += 4) {
+                    for (int s0 = 0; s0 < 128; s0 += 4) {
                         float bn[4];
 #pragma unroll
                         for (int u = 0; u < 4; ++u) bn[u] = topb[(s0 + u + 2 < 66) ? s0 + u + 2 : 66];
@@ -577,7 +592,7 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                     float r3 = 1.7320508075688772f;
                     asm volatile("" : "+s"(r3));
 #pragma unroll
-                    for (int s0 = QSW_N - 4; s0 >= 0; s0 -= 4) {
+                    for (int s0 = 124; s0 >= 0; s0 -= 4) {
                         // after step sigma the boundary value of step sigma - 1: U[.][64 h + sigma - 1 - 63]
                         float bn[4];
 #pragma unroll
@@ -620,13 +635,8 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
                     for (int c = 0; c < DPAD / 2; ++c) ynx[c] = reinterpret_cast<const qf32x2 *>(yfb)[c];
                     SIG_QSTAMP(6)
-#ifdef QEXP_NOPH4
-#define QPH4_N 2
-#else
-#define QPH4_N 64
-#endif
 #pragma unroll
-                    for (int it = 0; it < QPH4_N; ++it) {
+                    for (int it = 0; it < 64; ++it) {
                         qf32x2 yr2[DPAD / 2];
 #pragma unroll
                         for (int c = 0; c < DPAD / 2; ++c) yr2[c] = ynx[c];
@@ -637,11 +647,7 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                         }
                         const float Scur = Ssl[it];
                         const float Na = q_shr_zero(Scur); // S[l-1][n+1]
-#ifdef QEXP_NOWRAP
-                        const bool wrap = false;
-#else
                         const bool wrap = lv == it;        // local column 0
-#endif
                         float R = ((Nc - Nb) + (Scur - Sprev)) * rowmask;
                         capA = wrap ? Scur : capA;
                         capB = wrap ? Sprev : capB;
@@ -649,29 +655,13 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                         Nc = Nb;
                         Nb = Na;
                         Sprev = Scur;
-                        // G[m][n] = 2^(-log2(e)/h * |x~_m - y~_n|^2) in fp32, from the DIFFERENCES (the expanded form loses
-                        // 6e-8 of its largest term, 1e-5 of G for rough paths)
-                        qf32x2 e2 = qf32x2{0.f, 0.f};
-#pragma unroll
-                        for (int c = 0; c < DPAD / 2; ++c) {
-                            const qf32x2 df = qf32x2{xf[2 * c], xf[2 * c + 1]} - yr2[c];
-                            e2 = __builtin_elementwise_fma(df, df, e2);
-                        }
-#ifdef QEXP_NOG
-                        const float gv = e2[0];
-#else
-                        const float gv = __builtin_amdgcn_exp2f((e2[0] + e2[1]) * ns32);
-#endif
+                        const float gv = q_gval<DPAD>(xf, yr2, ns32);
                         const float rg = R * gv;
                         const qf32x2 rg2 = {rg, rg};
                         s0 += rg;
 #pragma unroll
                         for (int c = 0; c < DPAD / 2; ++c) acc[c] = __builtin_elementwise_fma(rg2, yr2[c], acc[c]);
-#ifdef QEXP_NOSYM
-                        if (false) {
-#else
                         if (SYM) {
-#endif
                             const float rgw = rg * w_ji;
                             t0 = q_add_ror1(t0, rgw);
 #pragma unroll
@@ -705,29 +695,22 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                         // E_l = S[l][n-1] - S[l][n];  R[m][n] = E_{l-1} - E_l
                         const float E = sc ? (cap63h0 - cap0h1) : -cap0h0;
                         const float R = (q_shr_zero(E) - E) * rowmask;
-                        const float *yr = yf + (128 * sc) * YFS;
-                        float e2 = 0.f;
+                        qf32x2 ys2[DPAD / 2];
 #pragma unroll
-                        for (int c = 0; c < DPAD; ++c) e2 = __builtin_fmaf(xf[c] - yr[c], xf[c] - yr[c], e2);
-                        const float rg = R * __builtin_amdgcn_exp2f(e2 * ns32);
+                        for (int c = 0; c < DPAD / 2; ++c) ys2[c] = reinterpret_cast<const qf32x2 *>(yf + (128 * sc) * YFS)[c];
+                        const float rg = R * q_gval<DPAD>(xf, ys2, ns32);
+                        const qf32x2 rg2 = {rg, rg};
                         s0 += rg;
 #pragma unroll
-                        for (int c = 0; c < DPAD / 2; ++c) {
-                            acc[c][0] = __builtin_fmaf(rg, yr[2 * c], acc[c][0]);
-                            acc[c][1] = __builtin_fmaf(rg, yr[2 * c + 1], acc[c][1]);
-                        }
+                        for (int c = 0; c < DPAD / 2; ++c) acc[c] = __builtin_elementwise_fma(rg2, ys2[c], acc[c]);
                         if (SYM) { // one column, 64 rows: wave sums, lanep c adds channel c (all lanes on one address would
                                    // serialise 64-fold in LDS)
                             const float rgw = rg * w_ji;
-                            float mine = 0.f;
 #pragma unroll
                             for (int c = 0; c <= DPAD; ++c) {
-                                float vsum = (c < DPAD) ? rgw * xf[c] : rgw;
-#pragma unroll
-                                for (int off = 32; off >= 1; off >>= 1) vsum += __shfl_xor(vsum, off, 64);
-                                mine = (lv == c) ? vsum : mine;
+                                const float vsum = q_wave_sum63((c < DPAD) ? rgw * xf[c] : rgw);
+                                if (lv == 63) atomicAdd(colacc + (64 * sc) * CS + c, vsum);
                             }
-                            if (lanep <= DPAD) atomicAdd(colacc + (64 * sc) * CS + lanep, mine);
                         }
                     }
                     cap0h0 = cap63h0 = cap0h1 = 0.f;

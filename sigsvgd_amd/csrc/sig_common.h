@@ -178,12 +178,6 @@ int stream_launch(const GramProblem &p);
 int stream_sym_partial(const GramProblem &p, int tile_offset, int tile_stride, double *grad_partial);
 
 
-// long paths, stored forward solution (n == 0, 65 <= T <= 128, RBF): two 64-row bands on a 128-slot ring -- gram_band.hip
-bool band_supported(int A, int B, int T, int d, int n, int kind, unsigned flags);
-int band_workspace_bytes(int A, int T, int d, int want_grad, size_t *bytes);
-int band_launch(const GramProblem &p);
-int band_sym_partial(const GramProblem &p, int tile_offset, int tile_stride, double *grad_partial);
-
 // long paths, stored forward solution, 2 x 2 quadrants of 64 x 64 cells at two waves per SIMD -- gram_quad.hip
 bool quad_supported(int A, int B, int T, int d, int n, int kind, unsigned flags);
 int quad_workspace_bytes(int A, int T, int d, int want_grad, size_t *bytes);

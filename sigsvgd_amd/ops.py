@@ -106,7 +106,8 @@ def _flags(naive: bool, sym: bool, y_is_x: bool, force_generic: bool, stored_for
 
 
 def gram_fwd(X, Y, inv_h: float, dyadic_order: int = 0, static_kind: int = _lib.STATIC_RBF,
-             naive: bool = False, force_generic: bool = False, y_is_x: bool = False) -> torch.Tensor:
+             naive: bool = False, force_generic: bool = False, y_is_x: bool = False,
+             stored_forward: bool = False) -> torch.Tensor:
     """K[A,B] = signature-kernel Gram matrix (forward only).  y_is_x: the caller states that Y holds the
     same values as X, so each unordered pair is solved once and K is mirrored."""
     L = _lib.load()
@@ -114,7 +115,7 @@ def gram_fwd(X, Y, inv_h: float, dyadic_order: int = 0, static_kind: int = _lib.
     Xc, Yc = _prep_paths(X, Y)
     A, T, d = Xc.shape
     B = Yc.shape[0]
-    flags = _flags(naive, False, bool(y_is_x) and A == B, force_generic)
+    flags = _flags(naive, False, bool(y_is_x) and A == B, force_generic, stored_forward)
     nbytes = ctypes.c_size_t(0)
     _lib.check(L.sigsvgd_gram_workspace_bytes(A, B, T, d, dyadic_order, 0, flags, ctypes.byref(nbytes)),
                "gram_workspace_bytes")
@@ -129,12 +130,13 @@ def gram_fwd(X, Y, inv_h: float, dyadic_order: int = 0, static_kind: int = _lib.
 
 
 STREAM_GMAX = 0.4  # include/sigsvgd_hip.h SIGSVGD_STREAM_GMAX
-STREAM_GUARDED = True  # the 65 <= T <= 128 kernel may return NaN gradients for pairs beyond STREAM_GMAX
+STREAM_GUARDED = True  # the long-path kernel for <= 8 channels may return NaN gradients for pairs beyond STREAM_GMAX
 
 
 def _is_streaming_shape(T: int, d: int, dyadic_order: int, static_kind: int, naive: bool) -> bool:
-    """Launches the streaming kernel serves (include/sigsvgd_hip.h): long paths, dyadic order 0, RBF."""
-    return dyadic_order == 0 and static_kind == _lib.STATIC_RBF and 65 <= T <= 128 and d <= 16 and not naive
+    """Launches the streaming kernel serves by default (csrc/capi.hip dispatch): long paths of up to 8 channels,
+    dyadic order 0, RBF.  (More channels, or stored_forward=True, go to the quadrant kernel, which has no guard.)"""
+    return dyadic_order == 0 and static_kind == _lib.STATIC_RBF and 65 <= T <= 128 and d <= 8 and not naive
 
 
 def gram_fwd_bwd(X, Y, inv_h: float, dyadic_order: int = 0, static_kind: int = _lib.STATIC_RBF,
@@ -143,12 +145,12 @@ def gram_fwd_bwd(X, Y, inv_h: float, dyadic_order: int = 0, static_kind: int = _
                  check_regime: bool = True, stored_forward: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
     """(K[A,B], gradX[A,T,d]) with gradX = d sum(grad_out*K)/dX (first slot); grad_out None = ones.
 
-    check_regime: long paths (65 <= T <= 128) run on the streaming kernel, which regenerates the forward
-    solution backwards and returns NaN gradients for the pairs whose increments exceed STREAM_GMAX (very
-    rough paths, typically a path against itself).  With check_regime the result is inspected (one scalar
-    read-back) and, if the guard fired on finite inputs, the launch is repeated on the banded kernel
-    (`stored_forward=True`, csrc/gram_band.hip), which keeps the forward solution and has no such limit --
-    2-3x the streaming kernel's time, not the 30x of the coverage kernel.  Skipped for T <= 64."""
+    Long paths (65 <= T <= 128): more than 8 channels, or stored_forward=True, run on the quadrant kernel
+    (csrc/gram_quad.hip), which keeps the forward solution and has no limit on roughness.  Up to 8 channels run on
+    the streaming kernel (faster there on smooth paths), which regenerates the forward solution backwards and
+    returns NaN gradients for the pairs whose increments exceed STREAM_GMAX (very rough paths, typically a path
+    against itself).  With check_regime such a result is detected (one scalar read-back) and, if the guard fired
+    on finite inputs, the launch is repeated with stored_forward=True (1.1-1.3x the time).  Skipped for T <= 64."""
     L = _lib.load()
     dev = _require_gpu(X, Y, grad_out)
     Xc, Yc = _prep_paths(X, Y)
@@ -183,8 +185,7 @@ def gram_fwd_bwd(X, Y, inv_h: float, dyadic_order: int = 0, static_kind: int = _
     _lib.check(rc, "gram_fwd_bwd")
     if guarded and bool(torch.isnan(gX).any()) and bool(torch.isfinite(Xc).all()) and bool(torch.isfinite(Yc).all()):
         _warn_rough_once()
-        # ordered pairs on the banded kernel (its symmetric variant is the slower one at present)
-        return gram_fwd_bwd(X, Y, inv_h, dyadic_order, static_kind, grad_out, naive, sym, False, False, False, True)
+        return gram_fwd_bwd(X, Y, inv_h, dyadic_order, static_kind, grad_out, naive, sym, y_is_x, False, False, True)
     return K, gX
 
 
@@ -197,7 +198,7 @@ def _warn_rough_once():
         import warnings
 
         warnings.warn("sigsvgd_amd: the long-path streaming kernel declined pairs with very rough increments; such "
-                      "launches are repeated on the stored-forward kernel (2-3x slower)", RuntimeWarning)
+                      "launches are repeated on the stored-forward kernel (1.1-1.3x slower)", RuntimeWarning)
 
 
 def svgd_phi(K, score, grad_k, mask=None, X=None, lr: Optional[float] = None, adagrad_state=None,

@@ -2,6 +2,7 @@
 solvers (register-resident T <= 64, streaming T <= 128, coverage).  Tolerance 1e-5 relative to max-abs
 (BASELINE.json north_star), fp32 I/O against the fp64 C oracle."""
 import numpy as np
+from contextlib import nullcontext as _nullcontext
 import pytest
 import torch
 
@@ -67,7 +68,8 @@ def test_degenerate_paths(gpu, T, d):
     same = np.repeat(mov[:1], 5, axis=0)
     K3, g3 = ops.gram_fwd_bwd(torch.as_tensor(same, device=gpu), torch.as_tensor(same, device=gpu), 1.0, y_is_x=True)
     assert float((K3 - K3[0, 0]).abs().max()) <= 1e-6 * float(K3[0, 0])
-    assert _rel(g3[1:].cpu().numpy(), g3[:1].double().cpu().numpy().repeat(4, 0)) < 1e-6
+    # (identical rows up to the order of the fp32 column-side sums)
+    assert _rel(g3[1:].cpu().numpy(), g3[:1].double().cpu().numpy().repeat(4, 0)) < 3e-6
     # a repeated point: path of length T with x[t] == x[t+1] at one place vs the oracle
     rep = mov.copy()
     rep[:, T // 2] = rep[:, T // 2 - 1]
@@ -92,20 +94,29 @@ def test_non_finite_inputs_propagate_without_hanging(gpu):
 
 
 def test_streaming_kernel_guard_is_loud(gpu):
-    """Rough long paths: with the regime check off, the streaming kernel must flag the pairs whose forward
-    solution it cannot regenerate (NaN gradient rows) rather than return numbers that look plausible;
-    K itself (forward sweep only) stays exact.  With the check on, the coverage kernel takes over."""
+    """Rough long paths of <= 8 channels: with the regime check off, the streaming kernel must flag the pairs whose
+    forward solution it cannot regenerate (NaN gradient rows) rather than return numbers that look plausible; K itself
+    (forward sweep only) stays exact.  With the check on, the stored-forward kernel takes over.  More than 8 channels
+    run on the stored-forward kernel in the first place: nothing to guard."""
     from sigsvgd_amd import ops
 
-    X = _paths(6, 128, 14, 21, 0.15)
+    X = _paths(6, 128, 7, 21, 0.22)
     Kref, gref = C.gram_fwd_bwd(X, X, 1.0, 0)
     Xg = torch.as_tensor(X, device=gpu)
     K, g = ops.gram_fwd_bwd(Xg, Xg, 1.0, y_is_x=True, check_regime=False)
     assert _rel(K.cpu().numpy(), Kref) < TOL
     assert torch.isnan(g).flatten(1).all(1).all()  # every particle's own pair is beyond the guard
-    K2, g2 = ops.gram_fwd_bwd(Xg, Xg, 1.0, y_is_x=True)
+    with pytest.warns(RuntimeWarning) if not ops._ROUGH_WARNED[0] else _nullcontext():
+        K2, g2 = ops.gram_fwd_bwd(Xg, Xg, 1.0, y_is_x=True)
     assert _rel(K2.cpu().numpy(), Kref) < TOL and _rel(g2.cpu().numpy(), gref) < TOL
     # smooth paths are untouched by the guard
-    Xs = torch.as_tensor(_paths(6, 128, 14, 22, 0.05), device=gpu)
+    Xs = torch.as_tensor(_paths(6, 128, 7, 22, 0.05), device=gpu)
     _, gs = ops.gram_fwd_bwd(Xs, Xs, 1.0, y_is_x=True, check_regime=False)
     assert torch.isfinite(gs).all()
+    # d = 14: stored forward by default, finite and right without any check
+    X14 = _paths(6, 128, 14, 21, 0.15)
+    K14ref, g14ref = C.gram_fwd_bwd(X14, X14, 1.0, 0)
+    X14g = torch.as_tensor(X14, device=gpu)
+    K14, g14 = ops.gram_fwd_bwd(X14g, X14g, 1.0, y_is_x=True, check_regime=False)
+    assert torch.isfinite(g14).all()
+    assert _rel(K14.cpu().numpy(), K14ref) < TOL and _rel(g14.cpu().numpy(), g14ref) < TOL

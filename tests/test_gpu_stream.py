@@ -124,9 +124,10 @@ def test_stream_symmetric_large_property(gpu):
 
 @pytest.mark.parametrize("A,B,T,d,sym,scale", [(2, 3, 128, 14, False, 0.05), (5, 5, 128, 14, True, 0.05), (3, 2, 65, 3, False, 0.05),
                                                (4, 4, 100, 7, True, 0.05), (6, 6, 66, 2, True, 0.05), (4, 4, 128, 14, True, 0.15),
-                                               (3, 5, 97, 5, False, 0.3)])
-def test_banded_stored_forward_kernel(gpu, A, B, T, d, sym, scale):
-    """gram_band.hip (SIGSVGD_FLAG_STORED_FORWARD): the long-path kernel that keeps the forward solution, on smooth AND
+                                               (3, 5, 97, 5, False, 0.3), (9, 9, 127, 8, True, 0.05), (3, 3, 65, 16, True, 0.05),
+                                               (10, 10, 129 - 1, 9, True, 0.1)])
+def test_stored_forward_quadrant_kernel(gpu, A, B, T, d, sym, scale):
+    """gram_quad.hip (SIGSVGD_FLAG_STORED_FORWARD; default for d > 8): the long-path kernel that keeps the forward solution, on smooth AND
     rough paths (scale 0.15 / 0.3: increments far beyond what the streaming kernel accepts), ordered and symmetric,
     against the C oracle; K also from the forward-only launch of the default kernel."""
     from sigsvgd_amd import ops
@@ -140,5 +141,23 @@ def test_banded_stored_forward_kernel(gpu, A, B, T, d, sym, scale):
     torch.cuda.synchronize()
     assert bool(torch.isfinite(g).all())
     assert _rel(K.cpu().numpy(), Kref) < TOL and _rel(g.cpu().numpy(), gref) < TOL
+    # forward-only launch of the same kernel, and fp64 I/O
+    Kf = ops.gram_fwd(Xg, Xg if sym else Yg, 1.0, y_is_x=sym, stored_forward=True)
+    assert _rel(Kf.cpu().numpy(), Kref) < TOL
+    K64, g64 = ops.gram_fwd_bwd(Xg.double(), (Xg if sym else Yg).double(), 1.0, y_is_x=sym, stored_forward=True)
+    assert K64.dtype == torch.float64 and _rel(K64.cpu().numpy(), Kref) < TOL and _rel(g64.cpu().numpy(), gref) < TOL
     if sym:
         assert np.array_equal(K.cpu().numpy(), K.cpu().numpy().T)
+        # weighted backward (grad_out) and the sharded partial solve: two shares sum to the full result
+        go = torch.as_tensor(rng.standard_normal((A, A)).astype(np.float32), device=gpu)
+        Kw, gw = ops.gram_fwd_bwd(Xg, Xg, 1.0, grad_out=go, y_is_x=True, stored_forward=True)
+        _, gwref = C.gram_fwd_bwd(X, X, 1.0, 0, grad_out=go.double().cpu().numpy())
+        assert _rel(gw.cpu().numpy(), gwref) < TOL
+        if d > 8:  # (the partial solve of <= 8 channels runs on the streaming kernel)
+            Ks = torch.zeros_like(K)
+            gs = torch.zeros((A, T, d), dtype=torch.float64, device=gpu)
+            for off in range(2):
+                Kp, gp = ops.gram_sym_partial(Xg, 1.0, off, 2)
+                Ks += Kp
+                gs += gp
+            assert torch.equal(Ks, K) and _rel(gs.cpu().numpy(), gref) < TOL
