@@ -309,8 +309,8 @@ def main(argv=None) -> int:
             "algorithmic_bytes_per_launch": by,
             "avg_launch_ms": k_ms,
             "median_launch_ms": ms[len(ms) // 2],
-            "note": "fused pair solves are fp64-VALU/latency bound, not HBM bound (SURVEY.md §8d); "
-                    "secondary figure below",
+            "note": "fused pair solves are bound by vector-instruction issue (fp64 static kernel, fp32 sweeps and "
+                    "contraction), not by HBM (SURVEY.md §8d); secondary figures below",
             "valu_issue": pmc["valu_issue"],
             "valu_fp64": {
                 "achieved_tflops": fl / (k_ms * 1e-3) / 1e12,
@@ -385,7 +385,7 @@ def main(argv=None) -> int:
             "vs_baseline": None,
             # arithmetic types on the path: static kernel, increments and both PDE sweeps fp64; stored D / K_fwd / G,
             # the gradient contraction and the velocity GEMM fp32; reduction over partners fp64; fp32 I/O
-            "dtype": "f64 sweeps + f32 contraction (mixed), f32 I/O",
+            "dtype": "f64 static kernel + f32 sweeps and contraction (mixed), f32 I/O",
             "data": "synthetic",
             "config": {
                 "workload": "C4: 7-DoF Panda-shaped particles, N=1024 trajectories x T=64 points x d=7, "

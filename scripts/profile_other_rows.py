@@ -1,6 +1,6 @@
-"""Workload for rocprofv3 --kernel-trace --stats of the kernels bench.py does not touch: the streaming
-kernel at the C5 path shape (N=256 of 4096, T=128, d=14, symmetric), the coverage kernel at C1, the vector
-kernels and the truncated signature.  usage: rocprofv3 --kernel-trace --stats ... -- python3 scripts/profile_other_rows.py"""
+"""Workload for rocprofv3 --kernel-trace --stats of the kernels bench.py does not touch: the long-path kernels (quadrant
+kernel at the C5 path shape N=256 of 4096, T=128, d=14, symmetric; streaming kernel at N=256, T=100, d=7), the coverage
+kernel at C1, the vector kernels, the truncated signature, the planning cost and the fused Adam update.  usage: rocprofv3 --kernel-trace --stats ... -- python3 scripts/profile_other_rows.py"""
 import os
 import sys
 
@@ -18,9 +18,19 @@ X1, s1 = X1.to(dev), s1.to(dev)
 g = torch.Generator().manual_seed(0)
 V = torch.randn(1024, 448, generator=g).to(dev)
 P = torch.cumsum(0.3 * torch.randn(1024, 64, 2, generator=g), 1).to(dev)
+X7, s7 = synthetic_inputs(256, 100, 7)
+X7, s7 = X7.to(dev), s7.to(dev)
+from sigsvgd_amd.costs import ObstacleFieldCost
+cost_fn = ObstacleFieldCost(torch.ones(10, device=dev), 0.5 + 4 * torch.rand(10, 2, generator=g).to(dev),
+                            0.05 * torch.ones(10, 2, device=dev), torch.tensor([0.25, 0.75]), torch.tensor([4.75, 4.5]))
+knots = (2.5 + torch.randn(1024, 3, 2, generator=g)).to(dev)
+adam = ops.AdamState(X5)
 for _ in range(10):
     K, gk = ops.gram_fwd_bwd(X5, X5, 1.0, 0, y_is_x=True, check_regime=False)
     ops.svgd_phi(K, s5, gk, X=X5, lr=1e-3)
+    ops.svgd_adam(K, s5, gk, X5.clone(), 0.05, adam)
+    K7, gk7 = ops.gram_fwd_bwd(X7, X7, 1.0, 0, y_is_x=True, check_regime=False)
+    cost_fn.cost_and_score(knots)
     K, gk = ops.gram_fwd_bwd(X1, X1, 1.0, 2, y_is_x=True)
     ops.svgd_phi(K, s1, gk, X=X1, lr=1e-3)
     sq = ops.vec_sqdist(V, V)
