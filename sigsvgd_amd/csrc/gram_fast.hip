@@ -9,17 +9,19 @@
 //     the slot index is a compile-time constant of the (fully unrolled) step, the same for all
 //     lanes, so D and K_fwd live in 2 x 64 VGPRs and G in a [slot][lane] LDS image;
 //   * neighbour rows are reached with wave-wide DPP shifts (no LDS round trip in the recurrence);
-//   * the static kernel, the 4-corner increments and both PDE sweeps run in fp64 (the increments
-//     cancel ~1e-2 of G; the sweep accumulates ~4e3 cells), everything that is only stored or
-//     contracted (D, K_fwd, G, S = K_fwd*U, R, gradient sums per pair) is fp32, the reduction over
-//     pairs is fp64 -- measured to keep K within 3e-8 and grad within 1e-6 of the fp64 oracle.
+//   * the static kernel and the 4-corner increments run in fp64 (the increments cancel ~1e-2 of G); the two PDE
+//     sweeps run in fp32 in DIFFERENCE FORM (a lane carries V = K[l+1][q] - K[l][q] along its row, see phase 2:
+//     1.5e-7 on K, 1.9e-7 on the gradient against the fp64 oracle, where the plain fp32 stencil loses 1e-5);
+//     everything that is only stored or contracted (D, K_fwd, G, S = K_fwd*U, R, gradient sums per pair) is fp32,
+//     the reduction over pairs is fp64 (row side) / fp32 atomics into a separate buffer (column side).
 //
 // Per pair: phase 1 static kernel + increments (wrap-around skew, all lanes busy, 66 iterations);
 // phase 2 forward sweep (K_fwd into the slots); phase 3 reverse sweep (U recurrence only, S = K_fwd*U
 // overwrites K_fwd in its slot); phase 4 scatter R, R*G and both contractions in a second wrap-around
 // pass (66 iterations, all lanes busy).  The two sweeps have on average half of their lanes outside the
-// grid, so they contain nothing but the recurrence.  The kernel is bound by vector-instruction issue
-// (84 % pipe occupancy at two waves per SIMD), i.e. by its instruction count: see DESIGN.md 5.1.
+// grid: their steps are hand-written (8 VALU + 2 SALU) and the idle lanes are switched off through EXEC windows
+// read from a constant table.  The kernel is bound by vector-instruction issue at two waves per SIMD, i.e. by
+// its instruction count (5,430 per pair at C4): see DESIGN.md 5.1 / 5.1.1.
 //
 // A workgroup is NW wavefronts = NW consecutive rows i of X against a chunk of columns j; the
 // column trajectory (centred on its first point, fp64 + fp32 copies) is staged once per j in LDS
@@ -27,7 +29,7 @@
 // contraction gives d k(x_i,x_j)/d x_i, the column-side sums (travelling accumulators, one wave
 // rotation per sum and iteration) give d k(x_j,x_i)/d x_j.  Row-side gradients stay in per-lane fp64
 // registers while a workgroup works on its row tile (work queue); column-side results of the NW waves
-// are summed in fixed order through LDS and added with one fp64 atomic per element and column.
+// are summed in fixed order through LDS and added with one fp32 atomic per element and column.
 //
 // Reference semantics: sigkernel _SigKernelGram.forward/backward [RECALLED, SURVEY.md App. A];
 // static kernel src/kernels/_traj_kernels.py:176-195; callers src/inference/score.py:68-69.
@@ -759,6 +761,21 @@ int fast_workspace_bytes(int A, int B, int T, int d, int want_grad, unsigned fla
 }
 
 namespace {
+// compute units of the current device (256 on MI355X); the persistent grid is sized from it
+int cu_count()
+{
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+            n = v;
+        else
+            n = 256;
+    }
+    return n;
+}
+
 template <int DPAD, int NW>
 int launch_variant(const GramProblem &p, FastArgs &a, bool grad, bool sym)
 {
@@ -776,8 +793,9 @@ int launch_variant(const GramProblem &p, FastArgs &a, bool grad, bool sym)
     };
     // Column chunk: chunks are pulled from a queue, so short ones cost only their staging prologue
     // (~1 % at 4 columns) and buy fine-grained balance; tiny problems go down to single columns.
+    const int ncu = cu_count();
     int JC = 4;
-    while (JC > 1 && nblocks(JC) < 256 * 16) JC >>= 1;
+    while (JC > 1 && nblocks(JC) < ncu * 16) JC >>= 1;
     a.JC = JC;
     a.owned = owned;
     // the queue lives behind the fp64 accumulation buffer in the caller's workspace
@@ -794,7 +812,7 @@ int launch_variant(const GramProblem &p, FastArgs &a, bool grad, bool sym)
     }
 #endif
     const long long total = nblocks(JC);
-    const long long resident = 256LL * (grad ? 1 : (NW == 4 ? (DPAD == 4 ? 3 : 2) : 1)); // workgroups the chip holds at once (LDS / VGPR bound)
+    const long long resident = (long long)ncu * (grad ? 1 : (NW == 4 ? (DPAD == 4 ? 3 : 2) : 1)); // workgroups the chip holds at once (LDS / VGPR bound)
     dim3 grid((unsigned)(total < resident ? total : resident), 1);
     dim3 block(NW * 64);
     constexpr bool HAS_LP = DPAD <= 8; // the d == DPAD - 1 instantiations exist for the 4- and 8-channel layouts

@@ -88,17 +88,22 @@ __device__ __forceinline__ double q_ldany(const void *b, size_t i, int io64)
 template <int N>
 __device__ __forceinline__ void q_ldrow(const void *b, size_t i0, int nvalid, int io64, double (&out)[N])
 {
+    // (clamped index + select instead of a guarded load: a guard is a branch per element, and hipcc reloads the
+    //  spilled row pointer before each of them)
     if (io64) {
         const double *p = static_cast<const double *>(b) + i0;
+        double tmp[N];
 #pragma unroll
-        for (int c = 0; c < N; ++c) out[c] = (c < nvalid) ? p[c] : 0.0;
+        for (int c = 0; c < N; ++c) tmp[c] = p[min(c, nvalid - 1)];
+#pragma unroll
+        for (int c = 0; c < N; ++c) out[c] = (c < nvalid) ? tmp[c] : 0.0;
     } else {
         const float *p = static_cast<const float *>(b) + i0;
         float tmp[N];
 #pragma unroll
-        for (int c = 0; c < N; ++c) tmp[c] = (c < nvalid) ? p[c] : 0.f;
+        for (int c = 0; c < N; ++c) tmp[c] = p[min(c, nvalid - 1)];
 #pragma unroll
-        for (int c = 0; c < N; ++c) out[c] = (double)tmp[c];
+        for (int c = 0; c < N; ++c) out[c] = (c < nvalid) ? (double)tmp[c] : 0.0;
     }
 }
 __device__ __forceinline__ void q_stany(void *b, size_t i, double v, int io64)
@@ -321,23 +326,28 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
         double sv[EPT], sr[EPT];
         if (io64) {
 #pragma unroll
-            for (int k = 0; k < EPT; ++k) {
-                const int e = tidp + k * NT, t = e / DPAD, c = e % DPAD;
-                const bool ok = t < T && c < d;
-                sv[k] = ok ? static_cast<const double *>(a.Y)[((size_t)j * T + t) * d + c] : 0.0;
-                sr[k] = ok ? static_cast<const double *>(a.Y)[(size_t)j * T * d + c] : 0.0;
+            for (int k = 0; k < EPT; ++k) { // clamped indices + select below: no branch per element
+                const int e = tidp + k * NT, t = min(e / DPAD, T - 1), c = min(e % DPAD, d - 1);
+                sv[k] = static_cast<const double *>(a.Y)[((size_t)j * T + t) * d + c];
+                sr[k] = static_cast<const double *>(a.Y)[(size_t)j * T * d + c];
             }
         } else {
             float fv[EPT], fr[EPT];
 #pragma unroll
             for (int k = 0; k < EPT; ++k) {
-                const int e = tidp + k * NT, t = e / DPAD, c = e % DPAD;
-                const bool ok = t < T && c < d;
-                fv[k] = ok ? static_cast<const float *>(a.Y)[((size_t)j * T + t) * d + c] : 0.f;
-                fr[k] = ok ? static_cast<const float *>(a.Y)[(size_t)j * T * d + c] : 0.f;
+                const int e = tidp + k * NT, t = min(e / DPAD, T - 1), c = min(e % DPAD, d - 1);
+                fv[k] = static_cast<const float *>(a.Y)[((size_t)j * T + t) * d + c];
+                fr[k] = static_cast<const float *>(a.Y)[(size_t)j * T * d + c];
             }
 #pragma unroll
             for (int k = 0; k < EPT; ++k) sv[k] = (double)fv[k], sr[k] = (double)fr[k];
+        }
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            const int e = tidp + k * NT;
+            const bool ok = e / DPAD < T && e % DPAD < d;
+            sv[k] = ok ? sv[k] : 0.0;
+            sr[k] = ok ? sr[k] : 0.0;
         }
 #pragma unroll
         for (int k = 0; k < EPT; ++k) {
