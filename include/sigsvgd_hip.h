@@ -22,6 +22,7 @@
  *                          IMQKernel / ScaledIMQKernel: K and d_K.sum(1) without the [A,B,D] tensor
  *   sigsvgd_obstacle_cost  batch_cost_fn of examples/script_planning_obstacle_field.py:113-126 (spline samples,
  *                          obstacle field, path length) and its gradient w.r.t. the knots (torch autograd there)
+ *   sigsvgd_vec_kernel_fused  the same classes with a fixed bandwidth: distance, kernel and summed gradient in one launch
  *   sigsvgd_signature      signatory.signature(path, depth, basepoint) [third-party, absent] as
  *                          called by PathSigKernel, src/kernels/_traj_kernels.py:124-125
  *
@@ -46,7 +47,7 @@
 extern "C" {
 #endif
 
-#define SIGSVGD_ABI_VERSION 5
+#define SIGSVGD_ABI_VERSION 6
 
 /* dtype */
 #define SIGSVGD_F32 0
@@ -176,6 +177,14 @@ int sigsvgd_vec_sqdist(const void *X, const void *Y, const void *XM, const void 
 int sigsvgd_vec_kernel(const void *sq, const void *XM, const void *YM, const void *grad_out, int A, int B,
                        int D, int dtype, int kind, double inv_h2, double grad_scale, void *K_out,
                        void *dK_out, void *stream);
+
+/* The same in ONE launch when the bandwidth is known in advance (no sq[A,B] round trip through HBM; both
+ * GEMM-shaped sums on the fp32 matrix cores).  X, Y [.,D]; XM, YM = X M, Y M or both NULL (M = I); K_out / dK_out
+ * nullable (not both).  fp32 and D <= 512 only (else SIGSVGD_E_UNSUPPORTED: use the two calls above).  Operands
+ * are centred on the first row of Y (differences are unchanged); dK_out is zeroed by the call. */
+int sigsvgd_vec_kernel_fused(const void *X, const void *Y, const void *XM, const void *YM, const void *grad_out, int A,
+                             int B, int D, int dtype, int kind, double inv_h2, double grad_scale, void *K_out,
+                             void *dK_out, void *stream);
 
 /* ---- trajectory cost in front of the path -----------------------------------------------
  * The reference's planning cost, examples/script_planning_obstacle_field.py:113-126, with its analytic gradient:

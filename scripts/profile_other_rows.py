@@ -35,6 +35,7 @@ for _ in range(10):
     ops.svgd_phi(K, s1, gk, X=X1, lr=1e-3)
     sq = ops.vec_sqdist(V, V)
     ops.vec_kernel(sq, V, V, _lib.VEC_GAUSSIAN, 1 / 448.0, -1 / 448.0)
+    ops.vec_kernel_fused(V, V, _lib.VEC_GAUSSIAN, 1 / 448.0, -1 / 448.0)
     S = ops.signature(P, 3, basepoint=True)
 torch.cuda.synchronize()
 print("ok", float(K.sum()), tuple(S.shape))

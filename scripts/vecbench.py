@@ -53,6 +53,14 @@ for N, D in [(1024, 448), (4096, 64), (4096, 448), (512, 14)]:
     K, dK = ours()
     Kr, dKr = ref_gaussian(X.double(), X.double(), h) if N * N * D * 8 < 40e9 else (None, None)
     err = float((dK.double() - dKr).abs().max() / dKr.abs().max()) if dKr is not None else float("nan")
+    t_fused = timeit(lambda: ops.vec_kernel_fused(X, X, _lib.VEC_GAUSSIAN, 1 / h**2, -1 / h**2))
+    Kf, dKf = ops.vec_kernel_fused(X, X, _lib.VEC_GAUSSIAN, 1 / h**2, -1 / h**2)
+    errf = float((dKf.double() - dKr).abs().max() / dKr.abs().max()) if dKr is not None else float((dKf - dK).abs().max() / dK.abs().max())
+    byf = 4 * (2 * N * D + N * N + N * D)      # fused: read X twice, write K, write dK
+    fl = 2.0 * 2 * N * N * D                   # two N x N x D products
+    print(f"N={N} D={D}: FUSED (one launch, fp32 MFMA) {t_fused*1e3:.1f} us = {byf/t_fused/1e6:.0f} GB/s algorithmic "
+          f"({byf/t_fused/1e6/8000*100:.1f} % of 8 TB/s), {fl/t_fused/1e9:.1f} TFLOP/s ({fl/t_fused/1e9/157.3*100:.1f} % of the "
+          f"157.3 TFLOP/s fp32 matrix peak), dK rel err {errf:.1e}")
     by = 4 * (2 * N * D + 3 * N * N + N * D)  # read X twice, write+read sq, write K, write dK
     print(f"N={N} D={D}: sqdist {t_sq*1e3:.1f} us, sqdist+kernel {t_all*1e3:.1f} us "
           f"({by/t_all/1e6:.1f} GB/s algorithmic), torch reference formulation {t_ref*1e3:.1f} us, dK rel err {err:.1e}")

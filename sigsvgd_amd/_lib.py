@@ -15,7 +15,7 @@ _CSRC = os.path.join(_PKG, "csrc")
 # SIGSVGD_LIB_PATH: A/B benchmarking of two builds on the same GPU box (scripts/ab.py); never set in tests
 LIB_PATH = os.environ.get("SIGSVGD_LIB_PATH") or os.path.join(_PKG, "libsigsvgd_hip.so")
 SOURCES = ["capi.hip", "gram_generic.hip", "gram_fast.hip", "gram_stream.hip", "gram_quad.hip", "svgd_phi.hip",
-           "vec_kernels.hip", "cost_kernels.hip"]
+           "vec_kernels.hip", "vec_fused.hip", "cost_kernels.hip"]
 HEADERS = [os.path.join(_CSRC, "sig_common.h"), os.path.join(_PKG, "..", "include", "sigsvgd_hip.h")]
 
 # mirror of include/sigsvgd_hip.h
@@ -23,7 +23,7 @@ F32, F64 = 0, 1
 STATIC_RBF, STATIC_LINEAR = 0, 1
 FLAG_NAIVE_SOLVER, FLAG_SYM, FLAG_Y_IS_X, FLAG_FORCE_GENERIC, FLAG_WS_CLEAN, FLAG_STORED_FORWARD = 1, 2, 4, 8, 16, 32
 VEC_GAUSSIAN, VEC_IMQ, VEC_UNIT = 0, 1, 2
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 EXPORTS = [
     "sigsvgd_abi_version",
@@ -37,6 +37,7 @@ EXPORTS = [
     "sigsvgd_svgd_adam_step",
     "sigsvgd_vec_sqdist",
     "sigsvgd_vec_kernel",
+    "sigsvgd_vec_kernel_fused",
     "sigsvgd_signature",
     "sigsvgd_obstacle_cost",
 ]
@@ -134,6 +135,8 @@ def load():
     L.sigsvgd_vec_sqdist.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp, vp]
     L.sigsvgd_vec_kernel.restype = ci
     L.sigsvgd_vec_kernel.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, cd, cd, vp, vp, vp]
+    L.sigsvgd_vec_kernel_fused.restype = ci
+    L.sigsvgd_vec_kernel_fused.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, cd, cd, vp, vp, vp]
     L.sigsvgd_obstacle_cost.restype = ci
     L.sigsvgd_obstacle_cost.argtypes = [vp, ci, ci, ci, vp, vp, vp, ci, vp, vp, vp, ci, cf, cf, vp, vp, vp, vp]
     L.sigsvgd_signature.restype = ci

@@ -33,6 +33,9 @@ int vec_sqdist_launch(const void *X, const void *Y, const void *XM, const void *
                       void *sq, hipStream_t stream);
 int vec_kgrad_launch(const void *sq, const void *XM, const void *YM, const void *go, int A, int B, int D, int dtype,
                      int kind, double inv_h2, double grad_scale, void *K, void *dK, hipStream_t stream);
+bool vec_fused_supported(int D, int dtype);
+int vec_fused_launch(const void *X, const void *Y, const void *XM, const void *YM, const void *go, int A, int B, int D,
+                     int kind, double inv_h2, double grad_scale, void *K, void *dK, hipStream_t stream);
 long long signature_channels(int C, int depth);
 int obstacle_cost_launch(const float *x, int N, int Kx, int d, const float *start, const float *target, const float *basis,
                          int Tt, const float *logw, const float *mean, const float *stdv, int M, float w_obst, float w_len,
@@ -249,6 +252,32 @@ int sigsvgd_vec_sqdist(const void *X, const void *Y, const void *XM, const void 
         return SIGSVGD_E_BADARG;
     }
     return vec_sqdist_launch(X, Y, XM, YM, A, B, D, dtype, sq_out, static_cast<hipStream_t>(stream));
+}
+
+int sigsvgd_vec_kernel_fused(const void *X, const void *Y, const void *XM, const void *YM, const void *grad_out, int A,
+                             int B, int D, int dtype, int kind, double inv_h2, double grad_scale, void *K_out,
+                             void *dK_out, void *stream)
+{
+    if (!X || !Y || (!K_out && !dK_out) || (XM == nullptr) != (YM == nullptr)) {
+        set_error("vec_kernel_fused: null pointer argument (XM and YM must both be given or both be NULL)");
+        return SIGSVGD_E_BADARG;
+    }
+    if (A < 1 || B < 1 || D < 1 || (dtype != SIGSVGD_F32 && dtype != SIGSVGD_F64)) {
+        set_error("vec_kernel_fused: bad arguments A=%d B=%d D=%d dtype=%d", A, B, D, dtype);
+        return SIGSVGD_E_BADARG;
+    }
+    if (kind != SIGSVGD_VEC_GAUSSIAN && kind != SIGSVGD_VEC_IMQ && kind != SIGSVGD_VEC_UNIT) {
+        set_error("vec_kernel_fused: bad kind %d", kind);
+        return SIGSVGD_E_BADARG;
+    }
+    if (!vec_fused_supported(D, dtype)) {
+        set_error("vec_kernel_fused: fp32 with D <= 512 only (got dtype=%d D=%d); use sigsvgd_vec_sqdist + sigsvgd_vec_kernel",
+                  dtype, D);
+        return SIGSVGD_E_UNSUPPORTED;
+    }
+    Range range("sigsvgd_vec_kernel_fused");
+    return vec_fused_launch(X, Y, XM, YM, grad_out, A, B, D, kind, inv_h2, grad_scale, K_out, dK_out,
+                            static_cast<hipStream_t>(stream));
 }
 
 int sigsvgd_vec_kernel(const void *sq, const void *XM, const void *YM, const void *grad_out, int A, int B, int D,

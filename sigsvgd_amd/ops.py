@@ -402,6 +402,44 @@ def vec_kernel(sq, XM, YM, kind: int, inv_h2: float, grad_scale: float, grad_out
     return K, dK
 
 
+def vec_fused_supported(X: torch.Tensor) -> bool:
+    """Shapes / dtypes `vec_kernel_fused` takes (include/sigsvgd_hip.h): fp32, up to 512 channels."""
+    return X.dtype == torch.float32 and 1 <= X.reshape(X.shape[0], -1).shape[1] <= 512
+
+
+def vec_kernel_fused(X, Y, kind: int, inv_h2: float, grad_scale: float, XM=None, YM=None, grad_out=None,
+                     want_K: bool = True, want_grad: bool = True):
+    """(K[A,B] or None, dK[A,D] or None) for a GIVEN bandwidth in one launch (`sigsvgd_vec_kernel_fused`): the
+    distance never goes to HBM and both GEMM-shaped sums run on the fp32 matrix cores.  XM / YM = X M / Y M for the
+    scaled kernels (both or neither)."""
+    L = _lib.load()
+    dev = _require_gpu(X, Y, XM, YM, grad_out)
+    Xc, Yc = _prep_vec(X, torch.float32), _prep_vec(Y, torch.float32)
+    A, D = Xc.shape
+    B = Yc.shape[0]
+    if Yc.shape[1] != D:
+        raise ValueError(f"X {tuple(Xc.shape)} / Y {tuple(Yc.shape)} channel mismatch")
+    if (XM is None) != (YM is None):
+        raise ValueError("XM and YM must both be given or both be None")
+    XMc = YMc = go = None
+    if XM is not None:
+        XMc, YMc = _prep_vec(XM, torch.float32), _prep_vec(YM, torch.float32)
+        if XMc.shape != Xc.shape or YMc.shape != Yc.shape:
+            raise ValueError(f"XM {tuple(XMc.shape)} / YM {tuple(YMc.shape)} do not match X / Y")
+    if grad_out is not None:
+        if tuple(grad_out.shape) != (A, B):
+            raise ValueError(f"grad_out must be [{A},{B}], got {tuple(grad_out.shape)}")
+        go = grad_out.detach().to(torch.float32).contiguous()
+    K = torch.empty((A, B), dtype=torch.float32, device=dev) if want_K else None
+    dK = torch.empty((A, D), dtype=torch.float32, device=dev) if want_grad else None
+    p = lambda t: t.data_ptr() if t is not None else None
+    with torch.cuda.device(dev):
+        rc = L.sigsvgd_vec_kernel_fused(Xc.data_ptr(), Yc.data_ptr(), p(XMc), p(YMc), p(go), A, B, D, _lib.F32, int(kind),
+                                        float(inv_h2), float(grad_scale), p(K), p(dK), _stream_ptr(dev))
+    _lib.check(rc, "vec_kernel_fused")
+    return K, dK
+
+
 def signature_channels(channels: int, depth: int) -> int:
     L = _lib.load()
     n = ctypes.c_longlong(0)

@@ -249,3 +249,59 @@ def test_vector_kernel_argument_errors(gpu):
         GaussianKernel()(x, torch.zeros(5, 3, device=gpu))
     with pytest.raises(ValueError):
         GaussianKernel(bandwidth_fn=3.0)
+
+
+# ---- fused fixed-bandwidth kernel (fp32 MFMA) ----------------------------------------------------------------
+@pytest.mark.parametrize("A,B,D", [(1, 1, 1), (3, 70, 5), (65, 17, 67), (130, 130, 129), (257, 300, 448), (700, 513, 64)])
+@pytest.mark.parametrize("kind", ["gaussian", "imq"])
+@pytest.mark.parametrize("offset", [0.0, 100.0])
+def test_vec_kernel_fused_fp32_vs_oracle(gpu, A, B, D, kind, offset):
+    """One launch for a given bandwidth (distance on the matrix cores, operands centred on Y[0]) against the fp64
+    oracle; `offset` moves the whole cloud away from the origin, where an uncentred |x|^2 + |y|^2 - 2 x.y loses bits."""
+    from sigsvgd_amd import _lib, ops
+
+    rng = np.random.default_rng(A * 1000 + B + D)
+    X = (rng.normal(size=(A, D)) + offset).astype(np.float32)
+    Y = (rng.normal(size=(B, D)) * 0.9 + 0.1 + offset).astype(np.float32)
+    go = rng.uniform(0.5, 1.5, size=(A, B)).astype(np.float32)
+    h = float(np.sqrt(D))
+    Xg, Yg, gog = (torch.as_tensor(a, device=gpu) for a in (X, Y, go))
+    k = _lib.VEC_GAUSSIAN if kind == "gaussian" else _lib.VEC_IMQ
+    K, dK = ops.vec_kernel_fused(Xg, Yg, k, 1 / h**2, -1 / h**2, grad_out=gog)
+    want_sq = VO.pw_dist_sq(X.astype(np.float64), Y.astype(np.float64))
+    wantK = np.exp(-0.5 / h**2 * want_sq) if kind == "gaussian" else (1 + 0.5 * want_sq / h**2) ** -0.5
+    assert rel(K, wantK) < 1e-5
+    want = VO.vec_kernel_weighted_grad(want_sq, X.astype(np.float64), Y.astype(np.float64), go, kind, h, -1 / h**2)
+    assert rel(dK, want) < 2e-5
+    K2, none = ops.vec_kernel_fused(Xg, Yg, k, 1 / h**2, -1 / h**2, want_grad=False)
+    assert none is None and torch.equal(K2, K)
+    none, dK2 = ops.vec_kernel_fused(Xg, Yg, k, 1 / h**2, -1 / h**2, grad_out=gog, want_K=False)
+    assert none is None and rel(dK2, want) < 2e-5
+
+
+def test_vec_kernel_fused_metric_and_classes(gpu):
+    """Scaled kernels (a non-symmetric metric included) through the fused launch, and the drop-in classes route a
+    fixed bandwidth (argument or constant bandwidth_fn) to it with the same results as the two-launch path."""
+    from sigsvgd_amd import _lib, ops
+    from sigsvgd_amd.kernels import GaussianKernel, ScaledIMQKernel
+
+    rng = np.random.default_rng(11)
+    X, Y = rng.normal(size=(90, 33)).astype(np.float32), rng.normal(size=(75, 33)).astype(np.float32)
+    R = rng.normal(size=(33, 33))
+    for M in ((R @ R.T / 33 + np.eye(33)).astype(np.float32), (R / 6 + np.eye(33)).astype(np.float32)):
+        Xg, Yg, Mg = (torch.as_tensor(a, device=gpu) for a in (X, Y, M))
+        XM, YM = Xg @ Mg, Yg @ Mg
+        K, dK = ops.vec_kernel_fused(Xg, Yg, _lib.VEC_GAUSSIAN, 1 / 3.0**2, -1 / 3.0**2, XM=XM, YM=YM)
+        sq = ops.vec_sqdist(Xg, Yg, XM, YM)
+        K0, dK0 = ops.vec_kernel(sq, XM, YM, _lib.VEC_GAUSSIAN, 1 / 3.0**2, -1 / 3.0**2)
+        assert rel(K, K0.double().cpu().numpy()) < 1e-5 and rel(dK, dK0.double().cpu().numpy()) < 2e-5
+    Xs = torch.as_tensor(rng.normal(size=(40, 96)).astype(np.float32), device=gpu)
+    two_launch = GaussianKernel()  # median heuristic: distance matrix needed
+    K1, d1 = two_launch(Xs, Xs)
+    hmed = float(two_launch.get_bandwidth(ops.vec_sqdist(Xs, Xs)))
+    K2, d2 = GaussianKernel()(Xs, Xs, h=hmed)                       # fused: h given
+    K3, d3 = GaussianKernel(bandwidth_fn=lambda _: hmed)(Xs, Xs)    # fused: constant bandwidth function
+    for Kx, dx in ((K2, d2), (K3, d3)):
+        assert rel(Kx, K1.double().cpu().numpy()) < 1e-5 and rel(dx, d1.double().cpu().numpy()) < 2e-5
+    Ki, di = ScaledIMQKernel()(Xs, Xs, M=torch.eye(96, device=gpu), h=2.0)
+    assert Ki.shape == (40, 40) and di.shape == (40, 96) and bool(torch.isfinite(di).all())
