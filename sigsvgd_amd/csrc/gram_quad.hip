@@ -19,8 +19,9 @@
 // reverse sweep runs: the schedule recomputes (static kernel + forward sweep) instead of storing
 //     band 0:  (0,0) (0,1)                                  forward only: leaves K[64][.]
 //     band 1:  (1,0) (1,1)* (1,0)*                          * = reverse sweep + gradient pass follow the forward sweep
-//     band 0:  (0,0) (0,1)* (0,0)*
-// i.e. 8 static-kernel + forward-sweep quadrant passes, 4 reverse sweeps, 4 gradient passes per pair (the minimum is
+//     band 0:        (0,1)* (0,0)*                          (0,1) restarts from the lanes' state at the end of the first
+//                                                           (0,0) pass: four registers per lane, kept across band 1
+// i.e. 7 static-kernel + forward-sweep quadrant passes, 4 reverse sweeps, 4 gradient passes per pair (the minimum is
 // 4 / 4 / 4; holding everything would take 4 x 128 slot registers or 100 KB of LDS per pair).
 // The gradient pass is the 4-corner scatter of gram_fast.hip, with the static kernel re-evaluated in fp32 from the
 // centred coordinates (no G image: LDS stays small enough for 8 wavefronts).  Points on the seams between
@@ -428,6 +429,8 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
             float Dsl[64]; // increments / sqrt(12) of the quadrant in work
             float Ssl[64]; // K_fwd, then S = K_fwd * U, of the quadrant in work
             float fc = 1.f, fuA = 1.f, fuB = 1.f, fV = 0.f; // forward chain of the band in work (K, neighbours, V)
+            float svc = 1.f, svA = 1.f, svB = 1.f, svV = 0.f; // the same at the end of quadrant (0,0)
+            int fwd_prev = -1;                               // quadrant (b + 2 h) of the previous forward sweep
             float rc = 1.f, rdA = 1.f, rdB = 1.f, rV = 0.f; // reverse chain (U)
             float cap0h0 = 0.f, cap63h0 = 0.f, cap0h1 = 0.f; // S[l][0], S[l][63] of half 0, S[l][64] (first of half 1)
             float xf[DPAD];
@@ -449,8 +452,14 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                 }
             };
             if (GRAD) {
-                if (nrows1 > 0) { add(0, 0, 0, 1); add(0, 1, 0, 1); add(1, 0, 0, 0); add(1, 1, 1, 0); add(1, 0, 1, 0); }
-                add(0, 0, 0, 0); add(0, 1, 1, 0); add(0, 0, 1, 0);
+                if (nrows1 > 0) {
+                    // band 0 forward (leaves K[64][.]; the lanes' state at the end of (0,0) is kept: sv*), band 1, then band 0
+                    // again, where (0,1) restarts from the kept state instead of a third pass over (0,0)
+                    add(0, 0, 0, 1); add(0, 1, 0, 1); add(1, 0, 0, 0); add(1, 1, 1, 0); add(1, 0, 1, 0);
+                    add(0, 1, 1, 0); add(0, 0, 1, 0);
+                } else {
+                    add(0, 0, 0, 0); add(0, 1, 1, 0); add(0, 0, 1, 0);
+                }
             } else {
                 add(0, 0, 0, 1); add(0, 1, 0, 1); add(1, 0, 0, 0); add(1, 1, 0, 0);
             }
@@ -549,7 +558,13 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                         fV = 0.f;
                         fuA = (lanep == 0) ? topb[1] : 1.f;
                         fuB = (lanep == 0) ? topb[0] : 1.f;
+                    } else if (fwd_prev != b) { // right quadrant without its left one swept just before: kept state
+                        fc = svc;
+                        fV = svV;
+                        fuA = svA;
+                        fuB = svB;
                     }
+                    fwd_prev = b + 2 * h;
                     // lanep 63 leaves K[64 b + 64][64 h + q + 1] after step sigma = 63 + q
                     const unsigned ho = (unsigned)(size_t)(leave_k ? hK + 64 * h + 1 : hdummy + 63);
                     int haddr = (int)((lv == 63) ? ho : (unsigned)(size_t)(hdummy + lv));
@@ -565,6 +580,12 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                         for (int u = 0; u < 4; ++u) bn[u] = topb[(s0 + u + 2 < 66) ? s0 + u + 2 : 66];
                         quad_fwd4(fc, fuA, fuB, fV, &Dsl[s0 & 63], &Ssl[s0 & 63], mk + s0, rows, bn, haddr, hinc, r3);
                     }
+                }
+                if (b == 0 && h == 0) {
+                    svc = fc;
+                    svV = fV;
+                    svA = fuA;
+                    svB = fuB;
                 }
                 SIG_QSTAMP(2)
                 if (!kdone && b == b_last && h == h_last) { // K[P][P]: last value of the last row with cells
