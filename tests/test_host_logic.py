@@ -289,3 +289,23 @@ def test_package_synthetic_inputs_match_the_oracle_generator():
         Xa, sa = synthetic_inputs(*shape)
         Xb, sb = O.synthetic_inputs(*shape)
         assert torch.equal(Xa, Xb) and torch.equal(sa, sb)
+
+
+def test_constant_bandwidth_detection():
+    """`_VectorKernel._constant_bandwidth`: a bandwidth function that ignores the distances is recognised once per
+    kernel object (the fused one-launch path then applies); the median heuristic and data-dependent functions are not."""
+    from sigsvgd_amd.kernels import GaussianKernel, IMQKernel
+
+    assert GaussianKernel()._constant_bandwidth() is None                      # bw_median: data-dependent
+    assert GaussianKernel(bandwidth_fn=lambda _: 0.2)._constant_bandwidth() == 0.2
+    assert IMQKernel(bandwidth_fn=lambda sq: sq.mean())._constant_bandwidth() is None
+    calls = []
+
+    def needs_matrix(sq):  # a function that only works on a real [N, N] matrix
+        calls.append(1)
+        return sq[0, 1]
+
+    k = GaussianKernel(bandwidth_fn=needs_matrix)
+    assert k._constant_bandwidth() is None and k._constant_bandwidth() is None
+    assert len(calls) == 1  # probed once (the first probe raised), then cached
+    assert GaussianKernel(bandwidth_fn=lambda _: -1.0)._constant_bandwidth() is None  # not a usable bandwidth
