@@ -390,7 +390,7 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                 if (SYM && j == i) w_ji = 0.f; // diagonal pair: first-slot derivative only
             }
 
-            // ---- G row 64 (the row beyond band 0): differences along the row for lanep 63 of band 0 ------------
+            // ---- G row 64 (the row beyond band 0): differences along the row for lane 63 of band 0 ------------
             {
                 QExp7 ek = qexp7_coef();
                 double xs2[DPAD], xn2 = 0.0, xr2[DPAD];
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                 QExp7 ek = qexp7_coef();
                 int lv = lanep; // per-visit copy the optimiser cannot see through: address vectors built from it stay inside
                 asm volatile("" : "+v"(lv)); // the visit instead of becoming spilled loop invariants
-                const int m = 64 * b + lv; // point row of this lanep
+                const int m = 64 * b + lv; // point row of this lane
                 const unsigned long long rows = nrows >= 64 ? ~0ull : ((1ull << nrows) - 1ull);
                 const unsigned long long *mk = QUAD_MASK.m[ncols];
 
@@ -492,9 +492,9 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                 xn = __builtin_fma(xn, nscale, -1.79248125036057809); // - log2(sqrt(12)): D slots hold D / sqrt(12)
 
                 SIG_QSTAMP(0)
-                // ---- phase 1: G row (skewed: local column (t - lanep) & 63 on iteration t) -> D slots --------------
+                // ---- phase 1: G row (skewed: local column (t - lane) & 63 on iteration t) -> D slots --------------
                 {
-                    const double *ybase = yd + (128 * h + 64 - lv) * YDS; // local column (t - lanep) & 63 == ybase + t * YDS
+                    const double *ybase = yd + (128 * h + 64 - lv) * YDS; // local column (t - lane) & 63 == ybase + t * YDS
                     // the point column that closes the last cell column of half 0 (column 64) is outside the ring
                     double g64v = 0.0;
                     if (h == 0) {
@@ -531,13 +531,13 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                         } else {
                             g = (t == 64) ? g0 : g1;
                         }
-                        // a lanep at local column 0 closes the previous row segment: G[m][64 h + 64] - G[m][64 h + 63]
+                        // a lane at local column 0 closes the previous row segment: G[m][64 h + 64] - G[m][64 h + 63]
                         const double gsel = (lv == (t & 63)) ? g64v : g;
                         const double rd = gsel - gprev; // G[m, c] - G[m, c-1]
                         gprev = g;
                         if (t >= 2) {
-                            // lanep l+1 holds the same column difference one iteration later; lanep 63 of band 0 takes the
-                            // row beyond the band (G row 64) from LDS: a virtual lanep 64 is at local column t & 63
+                            // lane l+1 holds the same column difference one iteration later; lane 63 of band 0 takes the
+                            // row beyond the band (G row 64) from LDS: a virtual lane 64 is at local column t & 63
                             const int cc = (t & 63) ? (t & 63) : 64;
                             const double beyond = (64 * h + cc < 128) ? rdhh[cc] : 0.0;
                             const double nb = q_shl_keep(rd, beyond);
@@ -552,7 +552,7 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                 SIG_QSTAMP(1)
                 // ---- phase 2: forward sweep of the quadrant -----------------------------------------------------
                 {
-                    const float *topb = (b ? hK : ones) + 64 * h; // K[64 b][64 h + q + 1] for lanep 0 on step sigma = q
+                    const float *topb = (b ? hK : ones) + 64 * h; // K[64 b][64 h + q + 1] for lane 0 on step sigma = q
                     if (h == 0) { // a new band: left boundary column of ones
                         fc = 1.f;
                         fV = 0.f;
@@ -565,7 +565,7 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                         fuB = svB;
                     }
                     fwd_prev = b + 2 * h;
-                    // lanep 63 leaves K[64 b + 64][64 h + q + 1] after step sigma = 63 + q
+                    // lane 63 leaves K[64 b + 64][64 h + q + 1] after step sigma = 63 + q
                     const unsigned ho = (unsigned)(size_t)(leave_k ? hK + 64 * h + 1 : hdummy + 63);
                     int haddr = (int)((lv == 63) ? ho : (unsigned)(size_t)(hdummy + lv));
                     const int hinc = (lanep == 63 && leave_k) ? 4 : 0;
@@ -600,7 +600,7 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                 // ---- phase 3: reverse sweep (S = K_fwd * U replaces K_fwd slot by slot) -------------------------
                 {
                     const bool below = (b == 0) && nrows1 > 0;    // band 1 lies below: U[64][.] is in hU
-                    const float *botb = (below ? hU : ones) + 64 * h; // U[64 b + 64][64 h + q] for lanep 63 on step sigma = q + 63
+                    const float *botb = (below ? hU : ones) + 64 * h; // U[64 b + 64][64 h + q] for lane 63 on step sigma = q + 63
                     if (rev_band != b) { // first reverse quadrant of the band: right boundary column of ones
                         rev_band = b;
                         s0 = 0.f;
@@ -608,14 +608,14 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                         for (int c = 0; c < DPAD / 2; ++c) acc[c] = qf32x2{0.f, 0.f};
                         rc = 1.f;
                         rV = 0.f;
-                        // lanep 63 starts on step 62 + ncols with the lower neighbour U[64 b + 64][64 h + ncols - 1] and the
+                        // lane 63 starts on step 62 + ncols with the lower neighbour U[64 b + 64][64 h + ncols - 1] and the
                         // corner U[.][64 h + ncols]; odd steps shift into dnA, even steps into dnB
                         const float c1 = botb[ncols], c0 = botb[ncols - 1];
                         const bool odd = ((62 + ncols) & 1) != 0;
                         rdA = (lanep == 63) ? (odd ? c0 : c1) : 1.f;
                         rdB = (lanep == 63) ? (odd ? c1 : c0) : 1.f;
                     }
-                    // lanep 0 of band 1 leaves U[64][64 h + q] after step sigma = q
+                    // lane 0 of band 1 leaves U[64][64 h + q] after step sigma = q
                     const bool leave_u = (b == 1);
                     const unsigned ho = (unsigned)(size_t)(leave_u ? hU + 64 * h + ncols - 1 : hdummy);
                     int haddr = (int)((lv == 0) ? ho : (unsigned)(size_t)(hdummy + lv));
@@ -629,15 +629,15 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
                             const int sg = s0 + 3 - u; // the step executed
-                            // (step 63 of a right quadrant hands lanep 63 the first value of the left one: index -1)
+                            // (step 63 of a right quadrant hands lane 63 the first value of the left one: index -1)
                             bn[u] = botb[(sg >= 64) ? sg - 64 : ((sg == 63) ? -h : 0)];
                         }
                         quad_rev4(rc, rdA, rdB, rV, &Dsl[s0 & 63], &Ssl[s0 & 63], mk + s0, rows, bn, haddr, hinc, r3);
                     }
                 }
                 SIG_QSTAMP(3)
-                // ---- seam rows for the hand-over pass: S[63][.] (band 0, lanep 63), S[64][.] (band 1, lanep 0) ------
-                // (slot k of lanep l is local column (k - l) & 63; the index is formed from scalars: per-lanep index vectors
+                // ---- seam rows for the hand-over pass: S[63][.] (band 0, lane 63), S[64][.] (band 1, lane 0) ------
+                // (slot k of lane l is local column (k - l) & 63; the index is formed from scalars: per-lane index vectors
                 //  are loop invariants that hipcc hoists out of the pair loop and spills -- 64 serialised scratch loads)
                 if (lanep == (b ? 0 : 63)) {
                     float *dst = (b ? srow64 : srow63) + 64 * h;
@@ -647,8 +647,8 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                 }
 
                 // ---- phase 4: 4-corner scatter R, static kernel in fp32, both contractions -----------------------
-                // iteration it: lanep l is at local column n = (it - l) & 63; own row S[l][n] is slot it, the upper row
-                // arrives through a wave shift one column ahead (lanep l-1's slot it holds S[l-1][n+1]), hence the
+                // iteration it: lane l is at local column n = (it - l) & 63; own row S[l][n] is slot it, the upper row
+                // arrives through a wave shift one column ahead (lane l-1's slot it holds S[l-1][n+1]), hence the
                 // two-deep history of the shifted values.  Local point column 0 needs the cell column left of the
                 // quadrant: it is masked here and done per band from the values captured at the wrap.
                 const float rowmask = (b == 1 && lanep == 0) ? 0.f : 1.f; // point row 64 is contracted in the seam pass
@@ -710,7 +710,7 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                     } else {
                         cap0h1 = capA;
                     }
-                    if (SYM) { // the finished sums of local column (63 - lanep) & 63 join the tile's image
+                    if (SYM) { // the finished sums of local column (63 - lane) & 63 join the tile's image
                         float *dst = colacc + (64 * h + ((63 - lv) & 63)) * CS;
 #pragma unroll
                         for (int c = 0; c < DPAD; ++c) atomicAdd(dst + c, tacc[c]);
@@ -734,7 +734,7 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                         s0 += rg;
 #pragma unroll
                         for (int c = 0; c < DPAD / 2; ++c) acc[c] = __builtin_elementwise_fma(rg2, ys2[c], acc[c]);
-                        if (SYM) { // one column, 64 rows: wave sums, lanep c adds channel c (all lanes on one address would
+                        if (SYM) { // one column, 64 rows: wave sums, lane c adds channel c (all lanes on one address would
                                    // serialise 64-fold in LDS)
                             const float rgw = rg * w_ji;
 #pragma unroll
@@ -761,7 +761,7 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
             SIG_QSTAMP(0)
             if (GRAD) {
                 // ---- seam: point row 64.  R[64][n] = (S[63][n-1] - S[63][n]) - (S[64][n-1] - S[64][n]), formed from both
-                // bands' rows before the contraction; lanes take columns n = lanep and lanep + 64.
+                // bands' rows before the contraction; lanes take columns n = lane and lane + 64.
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_s_waitcnt(0xc07f);
                 float ps0 = 0.f, part[DPAD], xm[DPAD];
@@ -791,7 +791,7 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                         atomicAdd(dst + DPAD, rgn * w_ji);
                     }
                 }
-                // row 64 belongs to band 1's lanep 0 accumulators
+                // row 64 belongs to band 1's lane 0 accumulators
 #pragma unroll
                 for (int c = 0; c < DPAD; ++c) {
                     float v = w_ij * m2h * (xm[c] * ps0 - part[c]);
