@@ -740,7 +740,9 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
                             for (int c = 0; c <= DPAD; ++c) {
                                 const float vsum = q_wave_sum63((c < DPAD) ? rgw * xf[c] : rgw);
-                                if (lv == 63) atomicAdd(colacc + (64 * sc) * CS + c, vsum);
+                                // (address formed from the lane index: with a uniform address hipcc wraps the atomic in a
+                                //  scan-over-active-lanes loop, ~30 instructions per add)
+                                if (lv == 63) atomicAdd(colacc + (64 * sc) * CS + c + (lv - 63), vsum);
                             }
                         }
                     }
@@ -794,10 +796,8 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                 // row 64 belongs to band 1's lane 0 accumulators
 #pragma unroll
                 for (int c = 0; c < DPAD; ++c) {
-                    float v = w_ij * m2h * (xm[c] * ps0 - part[c]);
-#pragma unroll
-                    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-                    if (lanep == 0 && c < d) unsafeAtomicAdd(&a.gacc[((size_t)i * T + 64) * d + c], (double)v);
+                    const float v = q_wave_sum63(w_ij * m2h * (xm[c] * ps0 - part[c])); // total in lane 63
+                    if (lanep == 63 && c < d) unsafeAtomicAdd(&a.gacc[((size_t)i * T + 64) * d + c], (double)v);
                 }
             }
             SIG_QSTAMP(6)
