@@ -70,9 +70,11 @@ extern "C" {
                                      /* library solve each unordered pair once                  */
 #define SIGSVGD_FLAG_STORED_FORWARD 32u /* long paths (65 <= T <= 128): use the quadrant kernel (gram_quad.hip), which keeps  */
                                        /* the forward solution instead of regenerating it: no limit on the roughness of    */
-                                       /* the paths.  It is the default for d > 8; with d <= 8 the streaming kernel is     */
-                                       /* faster on smooth paths and this flag is where callers send the launches it       */
-                                       /* declined (NaN gradients), at 1.1-1.3x its time.                                  */
+                                       /* the paths.  It is the default for T >= SIGSVGD_QUAD_MIN_T; shorter long paths    */
+                                       /* run on the streaming kernel (its cost shrinks with T^2, the quadrant kernel's    */
+                                       /* does not) and this flag is where callers send the launches it declined (NaN      */
+                                       /* gradients).                                                                      */
+#define SIGSVGD_QUAD_MIN_T 112
 #define SIGSVGD_FLAG_WS_CLEAN 16u     /* the caller guarantees that the workspace is ZERO on entry (fresh, or left  */
                                       /* by an earlier call with this flag); honoured by the register-resident       */
                                       /* gradient launches (dyadic order 0, T <= 64), which then issue no memset and */
@@ -120,7 +122,7 @@ int sigsvgd_gram_fwd_bwd(const void *X, const void *Y, int A, int B, int T, int 
 
 /* Multi-GPU building block (particles sharded over ranks; new design, the reference has no
  * distributed code -- SURVEY.md §8e).  Solves the unordered pairs {i <= j} whose row tile
- * (8 consecutive rows i for T <= 64 and d <= 8, otherwise 4) has index tile_offset + k*tile_stride, on the
+ * (8 consecutive rows i for T <= 64 with d <= 8 and for T >= SIGSVGD_QUAD_MIN_T, otherwise 4) has index tile_offset + k*tile_stride, on the
  * full gathered particle tensor X[N,T,d], and ACCUMULATES into caller-zeroed buffers:
  *   K_partial[N,N]      (dtype)  both orientations K[i,j], K[j,i] of every owned pair, 0 elsewhere
  *   grad_partial[N,T,d] (fp64)   this rank's share of d sum(grad_out*K)/dX (row- and column-side)

@@ -117,11 +117,12 @@ static int dispatch(const GramProblem &p)
     (void)want_grad;
     if (!(p.flags & SIGSVGD_FLAG_FORCE_GENERIC) && fast_supported(p.A, p.B, p.T, p.d, p.n, p.kind, p.flags))
         return fast_launch(p);
-    // long paths (65 <= T <= 128): the quadrant kernel keeps the forward solution (no limit on roughness); it is the
-    // default for more than 8 channels (C5: d = 14), where it is also the faster one, and on request
-    // (SIGSVGD_FLAG_STORED_FORWARD).  With <= 8 channels the streaming kernel is faster on smooth paths; it refuses
-    // rough pairs with NaN gradients and the host repeats such launches with the flag.
-    if (!(p.flags & SIGSVGD_FLAG_FORCE_GENERIC) && ((p.flags & SIGSVGD_FLAG_STORED_FORWARD) || p.d > 8) &&
+    // long paths (65 <= T <= 128): the quadrant kernel keeps the forward solution (no limit on roughness) and costs
+    // the same whatever T; it is the default from SIGSVGD_QUAD_MIN_T points on (C5: T = 128), where it is also the
+    // faster one, and on request (SIGSVGD_FLAG_STORED_FORWARD).  Shorter long paths run on the streaming kernel,
+    // whose cost shrinks with T^2; it refuses rough pairs with NaN gradients and the host repeats such launches
+    // with the flag.
+    if (!(p.flags & SIGSVGD_FLAG_FORCE_GENERIC) && ((p.flags & SIGSVGD_FLAG_STORED_FORWARD) || p.T >= SIGSVGD_QUAD_MIN_T) &&
         quad_supported(p.A, p.B, p.T, p.d, p.n, p.kind, p.flags))
         return quad_launch(p);
     if (!(p.flags & SIGSVGD_FLAG_FORCE_GENERIC) && stream_supported(p.A, p.B, p.T, p.d, p.n, p.kind, p.flags))
@@ -200,7 +201,7 @@ int sigsvgd_gram_sym_partial(const void *X, int N, int T, int d, int dtype, doub
     GramProblem p{X, X, N, N, T, d, dtype, inv_h, 0, static_kind, flags | SIGSVGD_FLAG_Y_IS_X, grad_out,
                   K_partial, grad_partial, workspace, workspace_bytes, static_cast<hipStream_t>(stream)};
     Range range("sigsvgd_gram_sym_partial");
-    if (!fast_supported(N, N, T, d, 0, static_kind, flags) && ((flags & SIGSVGD_FLAG_STORED_FORWARD) || d > 8) &&
+    if (!fast_supported(N, N, T, d, 0, static_kind, flags) && ((flags & SIGSVGD_FLAG_STORED_FORWARD) || T >= SIGSVGD_QUAD_MIN_T) &&
         quad_supported(N, N, T, d, 0, static_kind, flags))
         return quad_sym_partial(p, tile_offset, tile_stride, grad_partial);
     if (!fast_supported(N, N, T, d, 0, static_kind, flags) && stream_supported(N, N, T, d, 0, static_kind, flags))

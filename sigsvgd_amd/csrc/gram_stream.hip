@@ -1,6 +1,6 @@
 // Signature-kernel Gram forward/backward for LONG paths: dyadic order 0, 65 <= T <= 128, d <= 16, RBF,
-// second-order stencil.  Default for d <= 8 (faster there on smooth paths); d > 8 (BASELINE.json config C5: T = 128,
-// d = 14) and the launches this kernel declines run on gram_quad.hip, which keeps the forward solution.
+// second-order stencil.  Default for T < 112 (its cost shrinks with T^2); longer paths (BASELINE.json config C5:
+// T = 128, d = 14) and the launches this kernel declines run on gram_quad.hip, which keeps the forward solution.
 //
 // For these shapes the per-pair arrays the register-resident kernel keeps (increments D, forward
 // solution K_fwd, static kernel G: 3 x 64 KB at T = 128) no longer fit a CU more than twice, so this

@@ -153,8 +153,8 @@ class ShardedSigSVGD:
         """Paths longer than 64 points run on a kernel that may return NaN gradients for pairs it cannot solve
         to tolerance (`ops.STREAM_GUARDED`; very rough paths).  Ranks must agree on the route, so the flag is
         max-reduced (one 4-byte collective + one host read-back per step, long paths only)."""
-        if (not getattr(ops, "STREAM_GUARDED", False) or X_full.shape[1] <= 64 or X_full.shape[2] > 8
-                or not torch.is_tensor(grad_partial)):  # (more than 8 channels: the quadrant kernel, no guard)
+        if (not getattr(ops, "STREAM_GUARDED", False) or X_full.shape[1] <= 64 or X_full.shape[1] >= ops.QUAD_MIN_T
+                or not torch.is_tensor(grad_partial)):  # (QUAD_MIN_T points and more: the quadrant kernel, no guard)
             return False
         flag = torch.isnan(grad_partial).any().to(torch.int32).reshape(1)
         dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)

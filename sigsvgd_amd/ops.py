@@ -130,13 +130,16 @@ def gram_fwd(X, Y, inv_h: float, dyadic_order: int = 0, static_kind: int = _lib.
 
 
 STREAM_GMAX = 0.4  # include/sigsvgd_hip.h SIGSVGD_STREAM_GMAX
-STREAM_GUARDED = True  # the long-path kernel for <= 8 channels may return NaN gradients for pairs beyond STREAM_GMAX
+STREAM_GUARDED = True  # the long-path kernel for 65 <= T < QUAD_MIN_T may return NaN gradients for pairs beyond STREAM_GMAX
+
+
+QUAD_MIN_T = 112  # include/sigsvgd_hip.h SIGSVGD_QUAD_MIN_T
 
 
 def _is_streaming_shape(T: int, d: int, dyadic_order: int, static_kind: int, naive: bool) -> bool:
-    """Launches the streaming kernel serves by default (csrc/capi.hip dispatch): long paths of up to 8 channels,
-    dyadic order 0, RBF.  (More channels, or stored_forward=True, go to the quadrant kernel, which has no guard.)"""
-    return dyadic_order == 0 and static_kind == _lib.STATIC_RBF and 65 <= T <= 128 and d <= 8 and not naive
+    """Launches the streaming kernel serves by default (csrc/capi.hip dispatch): long paths of fewer than QUAD_MIN_T
+    points, dyadic order 0, RBF.  (Longer ones, or stored_forward=True, go to the quadrant kernel: no guard.)"""
+    return (dyadic_order == 0 and static_kind == _lib.STATIC_RBF and 65 <= T < QUAD_MIN_T and d <= 16 and not naive)
 
 
 def gram_fwd_bwd(X, Y, inv_h: float, dyadic_order: int = 0, static_kind: int = _lib.STATIC_RBF,
@@ -145,12 +148,12 @@ def gram_fwd_bwd(X, Y, inv_h: float, dyadic_order: int = 0, static_kind: int = _
                  check_regime: bool = True, stored_forward: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
     """(K[A,B], gradX[A,T,d]) with gradX = d sum(grad_out*K)/dX (first slot); grad_out None = ones.
 
-    Long paths (65 <= T <= 128): more than 8 channels, or stored_forward=True, run on the quadrant kernel
-    (csrc/gram_quad.hip), which keeps the forward solution and has no limit on roughness.  Up to 8 channels run on
-    the streaming kernel (faster there on smooth paths), which regenerates the forward solution backwards and
+    Long paths (65 <= T <= 128): from QUAD_MIN_T points on, or with stored_forward=True, they run on the quadrant
+    kernel (csrc/gram_quad.hip), which keeps the forward solution and has no limit on roughness.  Shorter ones run on
+    the streaming kernel (its cost shrinks with T^2), which regenerates the forward solution backwards and
     returns NaN gradients for the pairs whose increments exceed STREAM_GMAX (very rough paths, typically a path
     against itself).  With check_regime such a result is detected (one scalar read-back) and, if the guard fired
-    on finite inputs, the launch is repeated with stored_forward=True (1.1-1.3x the time).  Skipped for T <= 64."""
+    on finite inputs, the launch is repeated with stored_forward=True (1.0-1.5x the time, more for short paths).  Skipped for T <= 64."""
     L = _lib.load()
     dev = _require_gpu(X, Y, grad_out)
     Xc, Yc = _prep_paths(X, Y)
@@ -198,7 +201,7 @@ def _warn_rough_once():
         import warnings
 
         warnings.warn("sigsvgd_amd: the long-path streaming kernel declined pairs with very rough increments; such "
-                      "launches are repeated on the stored-forward kernel (1.1-1.3x slower)", RuntimeWarning)
+                      "launches are repeated on the stored-forward kernel (up to 1.5x slower)", RuntimeWarning)
 
 
 def svgd_phi(K, score, grad_k, mask=None, X=None, lr: Optional[float] = None, adagrad_state=None,

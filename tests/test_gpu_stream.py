@@ -127,7 +127,7 @@ def test_stream_symmetric_large_property(gpu):
                                                (3, 5, 97, 5, False, 0.3), (9, 9, 127, 8, True, 0.05), (3, 3, 65, 16, True, 0.05),
                                                (10, 10, 129 - 1, 9, True, 0.1)])
 def test_stored_forward_quadrant_kernel(gpu, A, B, T, d, sym, scale):
-    """gram_quad.hip (SIGSVGD_FLAG_STORED_FORWARD; default for d > 8): the long-path kernel that keeps the forward solution, on smooth AND
+    """gram_quad.hip (SIGSVGD_FLAG_STORED_FORWARD; default from 112 points on): the long-path kernel that keeps the forward solution, on smooth AND
     rough paths (scale 0.15 / 0.3: increments far beyond what the streaming kernel accepts), ordered and symmetric,
     against the C oracle; K also from the forward-only launch of the default kernel."""
     from sigsvgd_amd import ops
@@ -153,7 +153,7 @@ def test_stored_forward_quadrant_kernel(gpu, A, B, T, d, sym, scale):
         Kw, gw = ops.gram_fwd_bwd(Xg, Xg, 1.0, grad_out=go, y_is_x=True, stored_forward=True)
         _, gwref = C.gram_fwd_bwd(X, X, 1.0, 0, grad_out=go.double().cpu().numpy())
         assert _rel(gw.cpu().numpy(), gwref) < TOL
-        if d > 8:  # (the partial solve of <= 8 channels runs on the streaming kernel)
+        if T >= ops.QUAD_MIN_T:  # (the partial solve of shorter paths runs on the streaming kernel)
             Ks = torch.zeros_like(K)
             gs = torch.zeros((A, T, d), dtype=torch.float64, device=gpu)
             for off in range(2):
