@@ -235,7 +235,7 @@ __device__ __forceinline__ void quad_fwd4(float &cur, float &upA, float &upB, fl
                  : [g0] "v"(g[0]), [g1] "v"(g[1]), [g2] "v"(g[2]), [g3] "v"(g[3]), [b0] "v"(bn[0]), [b1] "v"(bn[1]),
                    [b2] "v"(bn[2]), [b3] "v"(bn[3]), [m0] "s"(m0), [m1] "s"(m1), [m2] "s"(m2), [m3] "s"(m3),
                    [rows] "s"(rows), [hinc] "v"(hinc), [r3] "s"(r3)
-                 : "memory", "scc");
+                 : "scc");
 }
 // steps sigma0+3 .. sigma0 (descending); bn[u]: boundary value of the step after the u-th one executed
 __device__ __forceinline__ void quad_rev4(float &cur, float &dnA, float &dnB, float &V, const float *g, float *ksl,
@@ -252,7 +252,7 @@ __device__ __forceinline__ void quad_rev4(float &cur, float &dnA, float &dnB, fl
                  : [g0] "v"(g[0]), [g1] "v"(g[1]), [g2] "v"(g[2]), [g3] "v"(g[3]), [b0] "v"(bn[0]), [b1] "v"(bn[1]),
                    [b2] "v"(bn[2]), [b3] "v"(bn[3]), [m0] "s"(m0), [m1] "s"(m1), [m2] "s"(m2), [m3] "s"(m3),
                    [rows] "s"(rows), [hinc] "v"(hinc), [r3] "s"(r3)
-                 : "memory", "scc");
+                 : "scc");
 }
 } // namespace
 
@@ -573,6 +573,11 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                     asm volatile("" : "+s"(r3));
 #pragma unroll
                     for (int k = 0; k < 64; ++k) Ssl[k] = 0.f; // slots without a grid cell must read as S = 0
+                    // The statements write the hand-over row in LDS but carry no "memory" clobber: with one, the boundary
+                    // values and EXEC windows of a statement could not be fetched before the previous statement has ended,
+                    // and every statement would start with an exposed LDS + scalar-load latency.  What they write is read
+                    // in LATER visits only, so one compiler barrier around the sweep is enough.
+                    asm volatile("" ::: "memory");
 #pragma unroll
                     for (int s0 = 0; s0 < 128; s0 += 4) {
                         float bn[4];
@@ -580,6 +585,7 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                         for (int u = 0; u < 4; ++u) bn[u] = topb[(s0 + u + 2 < 66) ? s0 + u + 2 : 66];
                         quad_fwd4(fc, fuA, fuB, fV, &Dsl[s0 & 63], &Ssl[s0 & 63], mk + s0, rows, bn, haddr, hinc, r3);
                     }
+                    asm volatile("" ::: "memory");
                 }
                 if (b == 0 && h == 0) {
                     svc = fc;
@@ -622,6 +628,7 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                     const int hinc = (lanep == 0 && leave_u) ? -4 : 0;
                     float r3 = 1.7320508075688772f;
                     asm volatile("" : "+s"(r3));
+                    asm volatile("" ::: "memory");
 #pragma unroll
                     for (int s0 = 124; s0 >= 0; s0 -= 4) {
                         // after step sigma the boundary value of step sigma - 1: U[.][64 h + sigma - 1 - 63]
@@ -634,6 +641,7 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                         }
                         quad_rev4(rc, rdA, rdB, rV, &Dsl[s0 & 63], &Ssl[s0 & 63], mk + s0, rows, bn, haddr, hinc, r3);
                     }
+                    asm volatile("" ::: "memory");
                 }
                 SIG_QSTAMP(3)
                 // ---- seam rows for the hand-over pass: S[63][.] (band 0, lane 63), S[64][.] (band 1, lane 0) ------
