@@ -150,8 +150,11 @@ int sigsvgd_gram_workspace_bytes(int A, int B, int T, int d, int dyadic_order, i
     // size for whichever kernel dispatch() would pick; the static kind does not change the size
     if (!(flags & SIGSVGD_FLAG_FORCE_GENERIC) && fast_supported(A, B, T, d, dyadic_order, SIGSVGD_STATIC_RBF, flags))
         return fast_workspace_bytes(A, B, T, d, want_grad, flags, bytes);
+    if (!(flags & SIGSVGD_FLAG_FORCE_GENERIC) && ((flags & SIGSVGD_FLAG_STORED_FORWARD) || T >= SIGSVGD_QUAD_MIN_T) &&
+        quad_supported(A, B, T, d, dyadic_order, SIGSVGD_STATIC_RBF, flags))
+        return quad_workspace_bytes(A, T, d, want_grad, bytes);
     if (!(flags & SIGSVGD_FLAG_FORCE_GENERIC) && stream_supported(A, B, T, d, dyadic_order, SIGSVGD_STATIC_RBF, flags))
-        return stream_workspace_bytes(A, T, d, want_grad, bytes); // (the quadrant kernel needs the same)
+        return stream_workspace_bytes(A, T, d, want_grad, bytes);
     return generic_workspace_bytes(A, B, T, d, dyadic_order, want_grad, bytes);
 }
 

@@ -42,6 +42,9 @@ struct QuadArgs {
     double *gacc; // [A][T][d] fp64, zeroed by the launcher (or the caller's accumulating buffer: partial solve)
     int io64, A, B, T, d, JC, symw;
     int tile_offset, tile_stride; // row tiles tile_offset + k * tile_stride are solved (sharded partial solve)
+    int nblocks;                  // work items (row tile x column chunk) of the launch; the grid strides over them
+    float *dcache;                // [gridDim.x][8 waves][3 quadrants][64 slots][64 lanes] fp32: increments kept between
+                                  // the forward-only and the full pass over a quadrant (gradient launches; may be NULL)
     double inv_h;
 #ifdef SIGSVGD_PHASE_STAMPS
     unsigned long long *stamps; // diagnostic build only (scripts/dev/phase_stamps.py): shader-clock totals per phase
@@ -280,26 +283,6 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int T = a.T, d = a.d, P = T - 1, io64 = a.io64;
     const int nrows1 = P - 64; // cell rows of band 1 = cell columns of half 1 (0 .. 63)
-    // grid decode: ordered launches 2-D (column chunk, owned row tile); symmetric launches 1-D over the chunks that
-    // reach the diagonal of their row tile
-    int ty = blockIdx.y, cx = blockIdx.x;
-    if (SYM) {
-        const int nJ = (a.B + a.JC - 1) / a.JC;
-        int rem = blockIdx.x;
-        for (ty = 0;; ++ty) {
-            const int first = ((a.tile_offset + ty * a.tile_stride) * QNW) / a.JC;
-            const int cntc = nJ - first;
-            if (rem < cntc) {
-                cx = first + rem;
-                break;
-            }
-            rem -= cntc;
-        }
-    }
-    const int i0 = (a.tile_offset + ty * a.tile_stride) * QNW;
-    const int i = i0 + wave;
-    const int j0 = cx * a.JC, j1 = min(a.B, j0 + a.JC);
-    const bool row_ok = i < a.A;
     const double inv_h = a.inv_h;
     const double nscale = -inv_h * 1.4426950408889634074;
     const float m2h = (float)(-2.0 * inv_h);
@@ -314,6 +297,30 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
 #ifdef SIGSVGD_PHASE_STAMPS
     unsigned long long ph_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast_ = __builtin_amdgcn_s_memtime();
 #endif
+    float *dcw = a.dcache ? a.dcache + ((size_t)blockIdx.x * QNW + wave) * (3 * 64 * 64) : nullptr;
+
+    // A grid of at most one workgroup per CU strides over the work items (row tile x column chunk): ordered launches
+    // enumerate (chunk, owned tile) row-major, symmetric launches only the chunks that reach the diagonal of their tile
+    const int nJ = (a.B + a.JC - 1) / a.JC;
+#pragma unroll 1
+    for (int blk = blockIdx.x; blk < a.nblocks; blk += gridDim.x) {
+    int ty = blk / nJ, cx = blk % nJ;
+    if (SYM) {
+        int rem = blk;
+        for (ty = 0;; ++ty) {
+            const int first = ((a.tile_offset + ty * a.tile_stride) * QNW) / a.JC;
+            const int cntc = nJ - first;
+            if (rem < cntc) {
+                cx = first + rem;
+                break;
+            }
+            rem -= cntc;
+        }
+    }
+    const int i0 = (a.tile_offset + ty * a.tile_stride) * QNW;
+    const int i = i0 + wave;
+    const int j0 = cx * a.JC, j1 = min(a.B, j0 + a.JC);
+    const bool row_ok = i < a.A;
 
     for (int j = j0; j < j1; ++j) {
         // per-pair copies of the thread indices that the optimiser cannot see through: every index / address vector
@@ -442,34 +449,39 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
             int rev_band = -1;
             bool kdone = false;
 
-            // visit list, 4 bits per visit: band | half << 1 | reverse << 2 | leave K[64][.] << 3
+            // visit list, 8 bits per visit: band | half << 1 | reverse << 2 | leave K[64][.] << 3 | increments << 4 (0 compute,
+            // 1 compute and keep in the launch's scratch, 2 take from there) | scratch slot << 6
             unsigned long long vis = 0;
             int nv = 0;
-            auto add = [&](int b, int h, int r, int hk) {
+            const int keep = a.dcache ? 1 : 0, take = a.dcache ? 2 : 0; // (from the uniform kernel argument: the visit codes
+                                                                        //  must stay scalar, the EXEC windows are fetched by them)
+            auto add = [&](int b, int h, int r, int hk, int dm, int ds) {
                 if ((b ? nrows1 : 64) > 0 && (h ? nrows1 : 64) > 0) {
-                    vis |= (unsigned long long)(b | (h << 1) | (r << 2) | (hk << 3)) << (4 * nv);
+                    vis |= (unsigned long long)(b | (h << 1) | (r << 2) | (hk << 3) | (dm << 4) | (ds << 6)) << (8 * nv);
                     ++nv;
                 }
             };
             if (GRAD) {
                 if (nrows1 > 0) {
                     // band 0 forward (leaves K[64][.]; the lanes' state at the end of (0,0) is kept: sv*), band 1, then band 0
-                    // again, where (0,1) restarts from the kept state instead of a third pass over (0,0)
-                    add(0, 0, 0, 1); add(0, 1, 0, 1); add(1, 0, 0, 0); add(1, 1, 1, 0); add(1, 0, 1, 0);
-                    add(0, 1, 1, 0); add(0, 0, 1, 0);
+                    // again, where (0,1) restarts from the kept state instead of a third pass over (0,0).  The increments of
+                    // the three quadrants that are visited twice make a round trip through L2 instead of being recomputed.
+                    add(0, 0, 0, 1, keep, 0); add(0, 1, 0, 1, keep, 1); add(1, 0, 0, 0, keep, 2); add(1, 1, 1, 0, 0, 0);
+                    add(1, 0, 1, 0, take, 2); add(0, 1, 1, 0, take, 1); add(0, 0, 1, 0, take, 0);
                 } else {
-                    add(0, 0, 0, 0); add(0, 1, 1, 0); add(0, 0, 1, 0);
+                    add(0, 0, 1, 0, 0, 0);
                 }
             } else {
-                add(0, 0, 0, 1); add(0, 1, 0, 1); add(1, 0, 0, 0); add(1, 1, 0, 0);
+                add(0, 0, 0, 1, 0, 0); add(0, 1, 0, 1, 0, 0); add(1, 0, 0, 0, 0, 0); add(1, 1, 0, 0, 0, 0);
             }
             const int b_last = nrows1 > 0 ? 1 : 0, h_last = nrows1 > 0 ? 1 : 0;
 
 #pragma unroll 1
             for (int v = 0; v < nv; ++v) {
-                const int code = (int)((vis >> (4 * v)) & 15);
+                const int code = (int)((vis >> (8 * v)) & 255);
                 const int b = code & 1, h = (code >> 1) & 1;
                 const bool rev = (code & 4) != 0, leave_k = (code & 8) != 0;
+                const int dmode = (code >> 4) & 3, dslot = code >> 6;
                 const int nrows = b ? nrows1 : 64, ncols = h ? nrows1 : 64;
                 QExp7 ek = qexp7_coef();
                 int lv = lanep; // per-visit copy the optimiser cannot see through: address vectors built from it stay inside
@@ -493,7 +505,11 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
 
                 SIG_QSTAMP(0)
                 // ---- phase 1: G row (skewed: local column (t - lane) & 63 on iteration t) -> D slots --------------
-                {
+                if (dmode == 2) { // second visit of the quadrant: the increments come back from the launch's scratch (L2)
+                    const float *dp = dcw + dslot * 4096 + lv;
+#pragma unroll
+                    for (int k = 0; k < 64; ++k) Dsl[k] = dp[k * 64];
+                } else {
                     const double *ybase = yd + (128 * h + 64 - lv) * YDS; // local column (t - lane) & 63 == ybase + t * YDS
                     // the point column that closes the last cell column of half 0 (column 64) is outside the ring
                     double g64v = 0.0;
@@ -546,6 +562,11 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                         }
                         rdprev = rd;
                         __builtin_amdgcn_sched_barrier(0); // one column per scheduling region: bounds live ranges
+                    }
+                    if (dmode == 1) { // visited again later: 64 coalesced 256-B stores per wave
+                        float *dp = dcw + dslot * 4096 + lv;
+#pragma unroll
+                        for (int k = 0; k < 64; ++k) dp[k * 64] = Dsl[k];
                     }
                 }
 
@@ -700,6 +721,10 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                         s0 += rg;
 #pragma unroll
                         for (int c = 0; c < DPAD / 2; ++c) acc[c] = __builtin_elementwise_fma(rg2, yr2[c], acc[c]);
+                        // pin the running sums here: the contraction must stay inside its iteration
+#pragma unroll
+                        for (int c = 0; c < DPAD / 2; ++c) asm volatile("" : "+v"(acc[c]));
+                        asm volatile("" : "+v"(s0));
                         if (SYM) {
                             const float rgw = rg * w_ji;
                             t0 = q_add_ror1(t0, rgw);
@@ -823,6 +848,7 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
             }
         }
     }
+    } // work items
 
     SIG_QSTAMP(0)
 #ifdef SIGSVGD_PHASE_STAMPS
@@ -847,9 +873,28 @@ bool quad_supported(int A, int B, int T, int d, int n, int kind, unsigned flags)
     return true;
 }
 
+namespace {
+// compute units of the current device (256 on MI355X): the grid is at most one workgroup per CU
+int quad_cu_count()
+{
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+            n = v;
+        else
+            n = 256;
+    }
+    return n;
+}
+constexpr size_t QUAD_DCACHE_PER_WG = (size_t)QNW * 3 * 64 * 64 * sizeof(float); // 384 KB
+} // namespace
+
 int quad_workspace_bytes(int A, int T, int d, int want_grad, size_t *bytes)
 {
-    *bytes = want_grad ? (size_t)A * T * d * sizeof(double) + 256 : 0;
+    // fp64 accumulation buffer + the increment scratch of a full grid (100 MB on 256 CUs; it lives in L2 / MALL)
+    *bytes = want_grad ? (size_t)A * T * d * sizeof(double) + 512 + (size_t)quad_cu_count() * QUAD_DCACHE_PER_WG : 0;
     return SIGSVGD_OK;
 }
 
@@ -863,17 +908,19 @@ int quad_launch_variant(const GramProblem &p, QuadArgs &a, bool grad, bool sym)
     int JC = 8;
     while (JC > 1 && (long long)owned * ((p.B + JC - 1) / JC) < (sym ? 2048 : 1024)) JC >>= 1;
     a.JC = JC;
-    dim3 grid((p.B + JC - 1) / JC, owned), block(QNW * 64);
+    const int nJ = (p.B + JC - 1) / JC;
+    long long total = (long long)nJ * owned;
     if (sym) { // count the chunks on or right of the diagonal of every owned tile
-        const int nJ = (p.B + JC - 1) / JC;
-        long long total = 0;
+        total = 0;
         for (int k = 0; k < owned; ++k) {
             const int first = ((a.tile_offset + k * a.tile_stride) * QNW) / JC;
             if (first < nJ) total += nJ - first;
         }
-        if (total <= 0) return SIGSVGD_OK;
-        grid = dim3((unsigned)total, 1);
     }
+    if (total <= 0) return SIGSVGD_OK;
+    a.nblocks = (int)total;
+    const int ncu = quad_cu_count();
+    dim3 grid((unsigned)(total < ncu ? total : ncu)), block(QNW * 64);
 #ifdef SIGSVGD_PHASE_STAMPS
     {
         static unsigned long long *dbg = nullptr;
@@ -921,6 +968,17 @@ void quad_fill_args(const GramProblem &p, QuadArgs &a)
     a.io64 = p.dtype == SIGSVGD_F64; a.A = p.A; a.B = p.B; a.T = p.T; a.d = p.d; a.JC = 1;
     a.symw = (p.flags & SIGSVGD_FLAG_SYM) ? 1 : 0; a.inv_h = p.inv_h;
     a.tile_offset = 0; a.tile_stride = 1;
+    a.nblocks = 0; a.dcache = nullptr;
+}
+// the increment scratch behind `used` bytes of the caller's workspace, if the workspace is large enough for a full grid
+// (sized by quad_workspace_bytes); without it the kernel recomputes the increments on the second visit of a quadrant
+float *quad_dcache_in(const GramProblem &p, size_t used)
+{
+    if (!p.ws) return nullptr;
+    const uintptr_t base = (reinterpret_cast<uintptr_t>(p.ws) + used + 255) & ~(uintptr_t)255;
+    const uintptr_t end = reinterpret_cast<uintptr_t>(p.ws) + p.ws_bytes;
+    const size_t need = (size_t)quad_cu_count() * QUAD_DCACHE_PER_WG;
+    return (base + need <= end) ? reinterpret_cast<float *>(base) : nullptr;
 }
 } // namespace
 
@@ -944,6 +1002,7 @@ int quad_launch(const GramProblem &p)
         a.gacc = reinterpret_cast<double *>((reinterpret_cast<uintptr_t>(p.ws) + 255) & ~(uintptr_t)255);
         hipError_t e = hipMemsetAsync(a.gacc, 0, nacc * sizeof(double), p.stream);
         if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(gacc)");
+        a.dcache = quad_dcache_in(p, nacc * sizeof(double) + 256);
     }
     int rc = quad_dispatch(p, a, grad, sym);
     if (rc) return rc;
@@ -976,6 +1035,7 @@ int quad_sym_partial(const GramProblem &p, int tile_offset, int tile_stride, dou
     a.gacc = grad_partial;
     a.tile_offset = tile_offset;
     a.tile_stride = tile_stride;
+    a.dcache = quad_dcache_in(p, 0); // (the accumulation buffer is the caller's: the workspace holds the scratch only)
     return quad_dispatch(p, a, true, true);
 }
 
