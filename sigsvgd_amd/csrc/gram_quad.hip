@@ -21,8 +21,11 @@
 //     band 1:  (1,0) (1,1)* (1,0)*                          * = reverse sweep + gradient pass follow the forward sweep
 //     band 0:        (0,1)* (0,0)*                          (0,1) restarts from the lanes' state at the end of the first
 //                                                           (0,0) pass: four registers per lane, kept across band 1
-// i.e. 7 static-kernel + forward-sweep quadrant passes, 4 reverse sweeps, 4 gradient passes per pair (the minimum is
-// 4 / 4 / 4; holding everything would take 4 x 128 slot registers or 100 KB of LDS per pair).
+// i.e. 7 forward sweeps, 4 reverse sweeps, 4 gradient passes per pair (the minimum is 4 / 4 / 4; holding everything
+// would take 4 x 128 slot registers or 100 KB of LDS per pair).  The static kernel (the expensive, LDS-bound part of
+// a pass) runs only 4 times: the increments of the three quadrants that are visited twice are written to a per-wave
+// scratch in global memory on the first visit (64 coalesced 256-B stores) and read back on the second -- 96 KB per
+// pair that never leave L2 / MALL, because the grid is one workgroup per CU striding over the work items.
 // The gradient pass is the 4-corner scatter of gram_fast.hip, with the static kernel re-evaluated in fp32 from the
 // centred coordinates (no G image: LDS stays small enough for 8 wavefronts).  Points on the seams between
 // quadrants need S from both sides and are done separately: point column 64 (and 0) per band from three captured
