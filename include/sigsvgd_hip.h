@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define SIGSVGD_ABI_VERSION 6
+#define SIGSVGD_ABI_VERSION 7
 
 /* dtype */
 #define SIGSVGD_F32 0
@@ -68,13 +68,8 @@ extern "C" {
 #define SIGSVGD_FLAG_SYM 2u          /* sigkernel sym=True backward weighting: go + go^T (A==B) */
 #define SIGSVGD_FLAG_Y_IS_X 4u       /* caller guarantees Y aliases X (same values): lets the   */
                                      /* library solve each unordered pair once                  */
-#define SIGSVGD_FLAG_STORED_FORWARD 32u /* long paths (65 <= T <= 128): use the quadrant kernel (gram_quad.hip), which keeps  */
-                                       /* the forward solution instead of regenerating it: no limit on the roughness of    */
-                                       /* the paths.  It is the default for T >= SIGSVGD_QUAD_MIN_T; shorter long paths    */
-                                       /* run on the streaming kernel (its cost shrinks with T^2, the quadrant kernel's    */
-                                       /* does not) and this flag is where callers send the launches it declined (NaN      */
-                                       /* gradients).                                                                      */
-#define SIGSVGD_QUAD_MIN_T 112
+#define SIGSVGD_FLAG_STORED_FORWARD 32u /* accepted and ignored: every kernel of this library keeps the forward solution   */
+                                       /* (ABI 4-6 used it to route long paths away from a kernel that regenerated it)     */
 #define SIGSVGD_FLAG_WS_CLEAN 16u     /* the caller guarantees that the workspace is ZERO on entry (fresh, or left  */
                                       /* by an earlier call with this flag); honoured by the register-resident       */
                                       /* gradient launches (dyadic order 0, T <= 64), which then issue no memset and */
@@ -82,13 +77,7 @@ extern "C" {
                                       /* launch used) -- two enqueues less per iteration, and a captured graph of    */
                                       /* the iteration consists of kernel nodes only.  Other launches ignore it and  */
                                       /* may leave the workspace dirty.                                              */
-#define SIGSVGD_FLAG_FORCE_GENERIC 8u /* use the coverage kernel (keeps the forward solution in  */
-                                      /* HBM): tests, and long paths (65 <= T <= 128) so rough    */
-                                      /* that a static-kernel increment exceeds SIGSVGD_STREAM_GMAX:*/
-                                      /* the streaming kernel regenerates the forward solution    */
-                                      /* backwards, trusts that only up to this increment size,   */
-                                      /* and returns NaN gradients for pairs beyond it            */
-#define SIGSVGD_STREAM_GMAX 0.4
+#define SIGSVGD_FLAG_FORCE_GENERIC 8u /* use the coverage kernel (forward solution in HBM scratch): tests */
 
 /* errors */
 #define SIGSVGD_OK 0
@@ -122,12 +111,12 @@ int sigsvgd_gram_fwd_bwd(const void *X, const void *Y, int A, int B, int T, int 
 
 /* Multi-GPU building block (particles sharded over ranks; new design, the reference has no
  * distributed code -- SURVEY.md §8e).  Solves the unordered pairs {i <= j} whose row tile
- * (8 consecutive rows i for T <= 64 with d <= 8 and for T >= SIGSVGD_QUAD_MIN_T, otherwise 4) has index tile_offset + k*tile_stride, on the
+ * (8 consecutive rows i; 4 for T <= 64 with d > 8) has index tile_offset + k*tile_stride, on the
  * full gathered particle tensor X[N,T,d], and ACCUMULATES into caller-zeroed buffers:
  *   K_partial[N,N]      (dtype)  both orientations K[i,j], K[j,i] of every owned pair, 0 elsewhere
  *   grad_partial[N,T,d] (fp64)   this rank's share of d sum(grad_out*K)/dX (row- and column-side)
  * Summing the buffers over tile_offset = 0..tile_stride-1 gives exactly sigsvgd_gram_fwd_bwd's
- * outputs.  Shapes of the register-resident and streaming kernels (dyadic_order 0, 3 <= T <= 128, d <= 16, RBF).
+ * outputs.  Shapes of the register-resident and quadrant kernels (dyadic_order 0, 3 <= T <= 128, d <= 16, RBF).
  * `workspace` as sized by sigsvgd_gram_workspace_bytes(N, N, T, d, 0, 1, SIGSVGD_FLAG_Y_IS_X) (work queue). */
 int sigsvgd_gram_sym_partial(const void *X, int N, int T, int d, int dtype, double inv_h,
                              int static_kind, unsigned flags, int tile_offset, int tile_stride,

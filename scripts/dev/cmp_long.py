@@ -8,7 +8,10 @@ def t(fn, n=5):
     torch.cuda.synchronize(); t0 = time.time()
     for _ in range(n): fn()
     torch.cuda.synchronize(); return (time.time() - t0) / n * 1e3
-for (N, T, d) in [(256, 128, 7), (256, 128, 3), (256, 112, 7), (256, 80, 7), (256, 128, 8), (256, 66, 7)]:
+shapes = [(256, 128, 7), (256, 128, 3), (256, 112, 7), (256, 80, 7), (256, 128, 8), (256, 66, 7)]
+if len(sys.argv) > 1:
+    shapes = [(256, int(t), int(d)) for t in sys.argv[1].split(',') for d in sys.argv[2].split(',')]
+for (N, T, d) in shapes:
     X, s = synthetic_inputs(N, T, d); X = X.to(dev)
     r = []
     for sf in (False, True):

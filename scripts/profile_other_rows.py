@@ -1,5 +1,5 @@
-"""Workload for rocprofv3 --kernel-trace --stats of the kernels bench.py does not touch: the long-path kernels (quadrant
-kernel at the C5 path shape N=256 of 4096, T=128, d=14, symmetric; streaming kernel at N=256, T=100, d=7), the coverage
+"""Workload for rocprofv3 --kernel-trace --stats of the kernels bench.py does not touch: the long-path kernel (quadrant
+kernel at the C5 path shape N=256 of 4096, T=128, d=14, symmetric, and at N=256, T=100, d=7), the coverage
 kernel at C1, the vector kernels, the truncated signature, the planning cost and the fused Adam update.  usage: rocprofv3 --kernel-trace --stats ... -- python3 scripts/profile_other_rows.py"""
 import os
 import sys

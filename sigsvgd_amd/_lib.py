@@ -14,7 +14,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_PKG, "csrc")
 # SIGSVGD_LIB_PATH: A/B benchmarking of two builds on the same GPU box (scripts/ab.py); never set in tests
 LIB_PATH = os.environ.get("SIGSVGD_LIB_PATH") or os.path.join(_PKG, "libsigsvgd_hip.so")
-SOURCES = ["capi.hip", "gram_generic.hip", "gram_fast.hip", "gram_stream.hip", "gram_quad.hip", "svgd_phi.hip",
+SOURCES = ["capi.hip", "gram_generic.hip", "gram_fast.hip", "gram_quad.hip", "svgd_phi.hip",
            "vec_kernels.hip", "vec_fused.hip", "cost_kernels.hip"]
 HEADERS = [os.path.join(_CSRC, "sig_common.h"), os.path.join(_PKG, "..", "include", "sigsvgd_hip.h")]
 
@@ -23,7 +23,7 @@ F32, F64 = 0, 1
 STATIC_RBF, STATIC_LINEAR = 0, 1
 FLAG_NAIVE_SOLVER, FLAG_SYM, FLAG_Y_IS_X, FLAG_FORCE_GENERIC, FLAG_WS_CLEAN, FLAG_STORED_FORWARD = 1, 2, 4, 8, 16, 32
 VEC_GAUSSIAN, VEC_IMQ, VEC_UNIT = 0, 1, 2
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 EXPORTS = [
     "sigsvgd_abi_version",

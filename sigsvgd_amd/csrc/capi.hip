@@ -117,16 +117,9 @@ static int dispatch(const GramProblem &p)
     (void)want_grad;
     if (!(p.flags & SIGSVGD_FLAG_FORCE_GENERIC) && fast_supported(p.A, p.B, p.T, p.d, p.n, p.kind, p.flags))
         return fast_launch(p);
-    // long paths (65 <= T <= 128): the quadrant kernel keeps the forward solution (no limit on roughness) and costs
-    // the same whatever T; it is the default from SIGSVGD_QUAD_MIN_T points on (C5: T = 128), where it is also the
-    // faster one, and on request (SIGSVGD_FLAG_STORED_FORWARD).  Shorter long paths run on the streaming kernel,
-    // whose cost shrinks with T^2; it refuses rough pairs with NaN gradients and the host repeats such launches
-    // with the flag.
-    if (!(p.flags & SIGSVGD_FLAG_FORCE_GENERIC) && ((p.flags & SIGSVGD_FLAG_STORED_FORWARD) || p.T >= SIGSVGD_QUAD_MIN_T) &&
-        quad_supported(p.A, p.B, p.T, p.d, p.n, p.kind, p.flags))
+    // long paths (65 <= T <= 128): the quadrant kernel (stored forward solution, any roughness)
+    if (!(p.flags & SIGSVGD_FLAG_FORCE_GENERIC) && quad_supported(p.A, p.B, p.T, p.d, p.n, p.kind, p.flags))
         return quad_launch(p);
-    if (!(p.flags & SIGSVGD_FLAG_FORCE_GENERIC) && stream_supported(p.A, p.B, p.T, p.d, p.n, p.kind, p.flags))
-        return stream_launch(p);
     return generic_launch(p);
 }
 
@@ -150,11 +143,8 @@ int sigsvgd_gram_workspace_bytes(int A, int B, int T, int d, int dyadic_order, i
     // size for whichever kernel dispatch() would pick; the static kind does not change the size
     if (!(flags & SIGSVGD_FLAG_FORCE_GENERIC) && fast_supported(A, B, T, d, dyadic_order, SIGSVGD_STATIC_RBF, flags))
         return fast_workspace_bytes(A, B, T, d, want_grad, flags, bytes);
-    if (!(flags & SIGSVGD_FLAG_FORCE_GENERIC) && ((flags & SIGSVGD_FLAG_STORED_FORWARD) || T >= SIGSVGD_QUAD_MIN_T) &&
-        quad_supported(A, B, T, d, dyadic_order, SIGSVGD_STATIC_RBF, flags))
+    if (!(flags & SIGSVGD_FLAG_FORCE_GENERIC) && quad_supported(A, B, T, d, dyadic_order, SIGSVGD_STATIC_RBF, flags))
         return quad_workspace_bytes(A, T, d, want_grad, bytes);
-    if (!(flags & SIGSVGD_FLAG_FORCE_GENERIC) && stream_supported(A, B, T, d, dyadic_order, SIGSVGD_STATIC_RBF, flags))
-        return stream_workspace_bytes(A, T, d, want_grad, bytes);
     return generic_workspace_bytes(A, B, T, d, dyadic_order, want_grad, bytes);
 }
 
@@ -204,11 +194,8 @@ int sigsvgd_gram_sym_partial(const void *X, int N, int T, int d, int dtype, doub
     GramProblem p{X, X, N, N, T, d, dtype, inv_h, 0, static_kind, flags | SIGSVGD_FLAG_Y_IS_X, grad_out,
                   K_partial, grad_partial, workspace, workspace_bytes, static_cast<hipStream_t>(stream)};
     Range range("sigsvgd_gram_sym_partial");
-    if (!fast_supported(N, N, T, d, 0, static_kind, flags) && ((flags & SIGSVGD_FLAG_STORED_FORWARD) || T >= SIGSVGD_QUAD_MIN_T) &&
-        quad_supported(N, N, T, d, 0, static_kind, flags))
+    if (!fast_supported(N, N, T, d, 0, static_kind, flags) && quad_supported(N, N, T, d, 0, static_kind, flags))
         return quad_sym_partial(p, tile_offset, tile_stride, grad_partial);
-    if (!fast_supported(N, N, T, d, 0, static_kind, flags) && stream_supported(N, N, T, d, 0, static_kind, flags))
-        return stream_sym_partial(p, tile_offset, tile_stride, grad_partial);
     return fast_sym_partial(p, tile_offset, tile_stride, grad_partial);
 }
 

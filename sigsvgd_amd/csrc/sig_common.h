@@ -170,14 +170,6 @@ int fast_workspace_bytes(int A, int B, int T, int d, int want_grad, unsigned fla
 int fast_launch(const GramProblem &p);
 int fast_sym_partial(const GramProblem &p, int tile_offset, int tile_stride, double *grad_partial);
 
-
-// long paths (n == 0, 65 <= T <= 128, RBF): static kernel streamed on the fly -- gram_stream.hip
-bool stream_supported(int A, int B, int T, int d, int n, int kind, unsigned flags);
-int stream_workspace_bytes(int A, int T, int d, int want_grad, size_t *bytes);
-int stream_launch(const GramProblem &p);
-int stream_sym_partial(const GramProblem &p, int tile_offset, int tile_stride, double *grad_partial);
-
-
 // long paths, stored forward solution, 2 x 2 quadrants of 64 x 64 cells at two waves per SIMD -- gram_quad.hip
 bool quad_supported(int A, int B, int T, int d, int n, int kind, unsigned flags);
 int quad_workspace_bytes(int A, int T, int d, int want_grad, size_t *bytes);

@@ -126,14 +126,6 @@ class ShardedSigSVGD:
                 self.phase_ms = mark.result()
             return out
         Kp, gp = self.partial_fn(X_full, self.inv_h, rank, world)
-        if self._guard_fired(X_full, gp):
-            # the long-path kernel declined some pairs of this input (see _guard_fired): every rank repeats the
-            # step row-wise, where `ops.gram_fwd_bwd` reroutes to the kernel that keeps the forward solution
-            out = self._step_rowwise(X_shard, X_full, s_full)
-            if mark:
-                mark("rowwise_solve_and_update")
-                self.phase_ms = mark.result()
-            return out
         if mark:
             mark("partial_solve")
         self.last_K_partial = Kp
@@ -149,30 +141,9 @@ class ShardedSigSVGD:
             self.phase_ms = mark.result()
         return out
 
-    def _guard_fired(self, X_full, grad_partial) -> bool:
-        """Paths longer than 64 points run on a kernel that may return NaN gradients for pairs it cannot solve
-        to tolerance (`ops.STREAM_GUARDED`; very rough paths).  Ranks must agree on the route, so the flag is
-        max-reduced (one 4-byte collective + one host read-back per step, long paths only)."""
-        if (not getattr(ops, "STREAM_GUARDED", False) or X_full.shape[1] <= 64 or X_full.shape[1] >= ops.QUAD_MIN_T
-                or not torch.is_tensor(grad_partial)):  # (QUAD_MIN_T points and more: the quadrant kernel, no guard)
-            return False
-        flag = torch.isnan(grad_partial).any().to(torch.int32).reshape(1)
-        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
-        if not int(flag.item()) or not bool(torch.isfinite(X_full).all()):
-            return False
-        if not ShardedSigSVGD._warned:
-            ShardedSigSVGD._warned = True
-            import warnings
-
-            warnings.warn("sigsvgd_amd: long-path partial solve declined rough pairs; this step runs row-wise on "
-                          "the coverage kernel (slower)", RuntimeWarning)
-        return True
-
-    _warned = False
-
     @staticmethod
     def _partial_supported(X_full) -> bool:
-        """shapes the register-resident and streaming symmetric kernels cover (include/sigsvgd_hip.h)"""
+        """shapes the register-resident and quadrant symmetric kernels cover (include/sigsvgd_hip.h)"""
         return 3 <= X_full.shape[1] <= 128 and X_full.shape[2] <= 16
 
     def _step_rowwise(self, X_shard, X_full, s_full):

@@ -129,38 +129,20 @@ def gram_fwd(X, Y, inv_h: float, dyadic_order: int = 0, static_kind: int = _lib.
     return K
 
 
-STREAM_GMAX = 0.4  # include/sigsvgd_hip.h SIGSVGD_STREAM_GMAX
-STREAM_GUARDED = True  # the long-path kernel for 65 <= T < QUAD_MIN_T may return NaN gradients for pairs beyond STREAM_GMAX
-
-
-QUAD_MIN_T = 112  # include/sigsvgd_hip.h SIGSVGD_QUAD_MIN_T
-
-
-def _is_streaming_shape(T: int, d: int, dyadic_order: int, static_kind: int, naive: bool) -> bool:
-    """Launches the streaming kernel serves by default (csrc/capi.hip dispatch): long paths of fewer than QUAD_MIN_T
-    points, dyadic order 0, RBF.  (Longer ones, or stored_forward=True, go to the quadrant kernel: no guard.)"""
-    return (dyadic_order == 0 and static_kind == _lib.STATIC_RBF and 65 <= T < QUAD_MIN_T and d <= 16 and not naive)
-
-
 def gram_fwd_bwd(X, Y, inv_h: float, dyadic_order: int = 0, static_kind: int = _lib.STATIC_RBF,
                  grad_out: Optional[torch.Tensor] = None, naive: bool = False, sym: bool = False,
                  y_is_x: bool = False, force_generic: bool = False,
                  check_regime: bool = True, stored_forward: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
     """(K[A,B], gradX[A,T,d]) with gradX = d sum(grad_out*K)/dX (first slot); grad_out None = ones.
 
-    Long paths (65 <= T <= 128): from QUAD_MIN_T points on, or with stored_forward=True, they run on the quadrant
-    kernel (csrc/gram_quad.hip), which keeps the forward solution and has no limit on roughness.  Shorter ones run on
-    the streaming kernel (its cost shrinks with T^2), which regenerates the forward solution backwards and
-    returns NaN gradients for the pairs whose increments exceed STREAM_GMAX (very rough paths, typically a path
-    against itself).  With check_regime such a result is detected (one scalar read-back) and, if the guard fired
-    on finite inputs, the launch is repeated with stored_forward=True (1.0-1.5x the time, more for short paths).  Skipped for T <= 64."""
+    Every kernel behind this call keeps the forward solution, so there is no limit on how rough the paths may be.
+    `check_regime` and `stored_forward` are accepted for callers written against earlier versions (when long paths
+    could run on a kernel that regenerated the forward solution and declined rough pairs) and have no effect."""
     L = _lib.load()
     dev = _require_gpu(X, Y, grad_out)
     Xc, Yc = _prep_paths(X, Y)
     A, T, d = Xc.shape
     B = Yc.shape[0]
-    guarded = (check_regime and not force_generic and not stored_forward
-               and _is_streaming_shape(T, d, dyadic_order, static_kind, naive))
     go = None
     if grad_out is not None:
         if tuple(grad_out.shape) != (A, B):
@@ -186,22 +168,7 @@ def gram_fwd_bwd(X, Y, inv_h: float, dyadic_order: int = 0, static_kind: int = _
     if rc != 0 and clean:  # a failed launch may have left the workspace dirty
         _WS_CLEAN.pop((dev.index, torch.cuda.current_stream(dev).cuda_stream), None)
     _lib.check(rc, "gram_fwd_bwd")
-    if guarded and bool(torch.isnan(gX).any()) and bool(torch.isfinite(Xc).all()) and bool(torch.isfinite(Yc).all()):
-        _warn_rough_once()
-        return gram_fwd_bwd(X, Y, inv_h, dyadic_order, static_kind, grad_out, naive, sym, y_is_x, False, False, True)
     return K, gX
-
-
-_ROUGH_WARNED = [False]
-
-
-def _warn_rough_once():
-    if not _ROUGH_WARNED[0]:
-        _ROUGH_WARNED[0] = True
-        import warnings
-
-        warnings.warn("sigsvgd_amd: the long-path streaming kernel declined pairs with very rough increments; such "
-                      "launches are repeated on the stored-forward kernel (up to 1.5x slower)", RuntimeWarning)
 
 
 def svgd_phi(K, score, grad_k, mask=None, X=None, lr: Optional[float] = None, adagrad_state=None,

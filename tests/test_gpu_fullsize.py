@@ -1,5 +1,5 @@
 """BASELINE.json configurations at their FULL sizes on the HIP path (one launch each; the small-shape
-parity matrix lives in test_gpu_fast / test_gpu_stream / test_gpu_generic).  What only shows at size:
+parity matrix lives in test_gpu_fast / test_gpu_longpaths / test_gpu_generic).  What only shows at size:
 the column-chunk selection, the persistent grid's queue scan over hundreds of row tiles, the 1-D
 symmetric enumeration, multi-hundred-MB accumulators, the 8-way tile ownership of the sharded step.
 

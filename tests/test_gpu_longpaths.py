@@ -1,5 +1,5 @@
-"""GPU parity: long-path kernel (n=0, 65 <= T <= 128: static kernel streamed on the fly, forward
-solution regenerated in the reverse sweep) vs the fp64 oracle, via the C ABI."""
+"""GPU parity: long-path kernel (n=0, 65 <= T <= 128: 2 x 2 quadrants of the register-resident scheme, stored
+forward solution -- csrc/gram_quad.hip) vs the fp64 oracle, via the C ABI."""
 import numpy as np
 import pytest
 import torch
@@ -23,7 +23,7 @@ def _rel(a, b):
 @pytest.mark.parametrize("A,B,T,d", [(5, 6, 128, 14), (3, 9, 128, 7), (6, 5, 65, 3), (4, 4, 66, 2),
                                      (7, 3, 100, 7), (2, 5, 127, 16), (9, 2, 97, 1)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
-def test_stream_fwd_bwd(gpu, A, B, T, d, dtype):
+def test_long_fwd_bwd(gpu, A, B, T, d, dtype):
     from sigsvgd_amd import ops
 
     X, Y = _paths(A, T, d, 1), _paths(B, T, d, 2)
@@ -42,7 +42,7 @@ def test_stream_fwd_bwd(gpu, A, B, T, d, dtype):
         assert _rel(g2.cpu().numpy(), g3.double().cpu().numpy()) < TOL
 
 
-def test_stream_self_gram_c5_shape(gpu):
+def test_long_self_gram_c5_shape(gpu):
     """C5 path shape (T=128, d=14) on the benchmark's synthetic particles, Y is X (sym weighting too)"""
     from sigsvgd_amd import ops
 
@@ -57,7 +57,7 @@ def test_stream_self_gram_c5_shape(gpu):
 
 @pytest.mark.parametrize("N,T,d", [(9, 128, 14), (13, 65, 3), (6, 100, 7), (5, 127, 16), (1, 96, 2), (17, 128, 1)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
-def test_stream_symmetric_solve_equals_ordered_pairs(gpu, N, T, d, dtype):
+def test_long_symmetric_solve_equals_ordered_pairs(gpu, N, T, d, dtype):
     """y_is_x=True solves every unordered pair once (mirrored K, column-side gradient through the
     travelling accumulators); with asymmetric weights it must still equal the ordered-pair result."""
     from sigsvgd_amd import ops
@@ -83,7 +83,7 @@ def test_stream_symmetric_solve_equals_ordered_pairs(gpu, N, T, d, dtype):
 
 
 @pytest.mark.parametrize("N,T,d,world", [(22, 128, 14, 3), (10, 70, 5, 2), (9, 96, 3, 4)])
-def test_stream_partials_sum_to_full(gpu, N, T, d, world):
+def test_long_partials_sum_to_full(gpu, N, T, d, world):
     """sigsvgd_gram_sym_partial on the long-path shapes: the per-rank partials (4-row tiles, cyclic) add up
     to the full symmetric solve, and each owned pair appears in exactly one partial."""
     from sigsvgd_amd import ops
@@ -107,7 +107,7 @@ def test_stream_partials_sum_to_full(gpu, N, T, d, world):
     assert _rel(gs.cpu().numpy(), gref) < TOL
 
 
-def test_stream_symmetric_large_property(gpu):
+def test_long_symmetric_large_property(gpu):
     """C5 path shape at N=96: K symmetric with unit-free diagonal structure, and the symmetric solve equals
     the ordered solve (no oracle at this size)."""
     from sigsvgd_amd import ops
@@ -127,8 +127,8 @@ def test_stream_symmetric_large_property(gpu):
                                                (3, 5, 97, 5, False, 0.3), (9, 9, 127, 8, True, 0.05), (3, 3, 65, 16, True, 0.05),
                                                (10, 10, 129 - 1, 9, True, 0.1)])
 def test_stored_forward_quadrant_kernel(gpu, A, B, T, d, sym, scale):
-    """gram_quad.hip (SIGSVGD_FLAG_STORED_FORWARD; default from 112 points on): the long-path kernel that keeps the forward solution, on smooth AND
-    rough paths (scale 0.15 / 0.3: increments far beyond what the streaming kernel accepts), ordered and symmetric,
+    """gram_quad.hip: the long-path kernel (stored forward solution), on smooth AND
+    rough paths (scale 0.15 / 0.3: increments far beyond what a regenerating kernel could accept), ordered and symmetric,
     against the C oracle; K also from the forward-only launch of the default kernel."""
     from sigsvgd_amd import ops
 
@@ -153,7 +153,7 @@ def test_stored_forward_quadrant_kernel(gpu, A, B, T, d, sym, scale):
         Kw, gw = ops.gram_fwd_bwd(Xg, Xg, 1.0, grad_out=go, y_is_x=True, stored_forward=True)
         _, gwref = C.gram_fwd_bwd(X, X, 1.0, 0, grad_out=go.double().cpu().numpy())
         assert _rel(gw.cpu().numpy(), gwref) < TOL
-        if T >= ops.QUAD_MIN_T:  # (the partial solve of shorter paths runs on the streaming kernel)
+        if True:
             Ks = torch.zeros_like(K)
             gs = torch.zeros((A, T, d), dtype=torch.float64, device=gpu)
             for off in range(2):
