@@ -908,21 +908,27 @@ int quad_launch_variant(const GramProblem &p, QuadArgs &a, bool grad, bool sym)
     const int ntile = (p.A + QNW - 1) / QNW;
     const int owned = (ntile - a.tile_offset + a.tile_stride - 1) / a.tile_stride;
     if (owned <= 0) return SIGSVGD_OK;
-    int JC = 8;
-    while (JC > 1 && (long long)owned * ((p.B + JC - 1) / JC) < (sym ? 2048 : 1024)) JC >>= 1;
-    a.JC = JC;
-    const int nJ = (p.B + JC - 1) / JC;
-    long long total = (long long)nJ * owned;
-    if (sym) { // count the chunks on or right of the diagonal of every owned tile
-        total = 0;
-        for (int k = 0; k < owned; ++k) {
-            const int first = ((a.tile_offset + k * a.tile_stride) * QNW) / JC;
-            if (first < nJ) total += nJ - first;
+    const int ncu = quad_cu_count();
+    // work items of JC columns: the grid strides over them, so a launch wants >= 16 per workgroup for an even spread
+    // (the column trajectory is staged per column whatever JC is; small launches go down to single columns)
+    auto items = [&](int jc) {
+        const int nj = (p.B + jc - 1) / jc;
+        long long t = (long long)nj * owned;
+        if (sym) { // only the chunks on or right of the diagonal of every owned tile
+            t = 0;
+            for (int k = 0; k < owned; ++k) {
+                const int first = ((a.tile_offset + k * a.tile_stride) * QNW) / jc;
+                if (first < nj) t += nj - first;
+            }
         }
-    }
+        return t;
+    };
+    int JC = 8;
+    while (JC > 1 && items(JC) < 16LL * ncu) JC >>= 1;
+    a.JC = JC;
+    const long long total = items(JC);
     if (total <= 0) return SIGSVGD_OK;
     a.nblocks = (int)total;
-    const int ncu = quad_cu_count();
     dim3 grid((unsigned)(total < ncu ? total : ncu)), block(QNW * 64);
 #ifdef SIGSVGD_PHASE_STAMPS
     {
