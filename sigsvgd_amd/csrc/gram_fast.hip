@@ -180,6 +180,22 @@ struct SweepMasks {
     }
 };
 __constant__ const SweepMasks SWEEP_MASK = SweepMasks();
+// The same for paths of <= 32 points on the 32-slot ring (RING = 32 below): lanes 32..63 mirror lanes 0..31 (they own
+// the same rows), so every window appears in both halves.
+struct SweepMasks32 {
+    unsigned long long m[32][64]; // [P][sigma]
+    constexpr SweepMasks32() : m()
+    {
+        for (int P = 1; P < 32; ++P)
+            for (int s = 0; s <= 2 * P - 2; ++s) {
+                const int lo = s - P + 1 > 0 ? s - P + 1 : 0, hi = s < P - 1 ? s : P - 1;
+                unsigned long long w = 0;
+                for (int l = lo; l <= hi; ++l) w |= (1ull << l) | (1ull << (l + 32));
+                m[P][s] = w;
+            }
+    }
+};
+__constant__ const SweepMasks32 SWEEP_MASK32 = SweepMasks32();
 
 #define SIG_FWD_STEP(UP, DIAG, G, KSL, M)                                                     \
     "s_mov_b64 exec, -1\n\t"                                                                  \
@@ -288,11 +304,17 @@ __device__ __forceinline__ void store_any(void *base, size_t idx, double v, int 
 
 // LP: the last of the DPAD channels is padding (d == DPAD - 1, e.g. the 7-DoF arm at DPAD = 8): its FMA in the
 // static kernel and its travelling column sum are dropped.
-template <int DPAD, int NW, bool GRAD, bool SYM, bool LP>
+// RING: slots per lane = length of the column ring.  64 in general; 32 for paths of <= 32 points (T <= 32, gradient
+// launches), where the skewed phases 1 and 4 then take 34 iterations instead of 66: lanes 32..63 MIRROR lanes 0..31
+// (row = lane & 31, same work, same values), which is what keeps the wave-wide machinery intact -- the boundary
+// lane of the DPP shifts at the seam is row 31, which has no cells for T <= 32 and so holds the boundary value 1,
+// and a travelling column sum meets every row exactly once in 32 consecutive lanes of the 64-lane rotation.
+template <int DPAD, int NW, bool GRAD, bool SYM, bool LP, int RING = 64>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(GRAD ? 1 : (DPAD == 4 ? 3 : 2), GRAD ? 2 : (DPAD == 4 ? 3 : 2)))) void gram_fast_kernel(FastArgs a)
 {
     constexpr int DC = LP ? DPAD - 1 : DPAD; // channels that can be non-zero
     constexpr int NT = NW * 64;
+    constexpr int RM = RING - 1;
     // y rows are stored twice (row r and r + 64) so that the skewed row (t - lane) & 63 becomes
     // (64 - lane) + t: a per-lane base plus a compile-time offset.
     // Row strides are padded (YDS doubles / YFS floats) so that the 16 lanes a ds_read_b128 services per
@@ -308,6 +330,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(GRAD ? 
     __shared__ __align__(16) float yf[GRAD ? 128 * YFS : 1];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lrow = lane & RM; // the row this lane owns
     const int T = a.T, d = a.d, P = T - 1, io64 = a.io64;
     // Work distribution: a persistent grid (one workgroup per CU) pulls column chunks from per-row-tile
     // counters.  A workgroup STAYS on a row tile while chunks remain there, so the per-lane row-side
@@ -330,7 +353,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(GRAD ? 
     // Zeroed per pair right before the forward sweep (64 moves, 0.5 % of a pair): the sweeps write a slot only while
     // its cell is inside the grid, so the slots without a grid cell (column >= P or lane >= P) read 0 in the phase-4
     // pass, which takes all 64 slots unmasked -- and the 64 registers are free during staging and phase 1.
-    float Ksl[64];
+    float Ksl[RING];
     double gacc[DPAD]; // per-lane fp64 accumulators of d sum_j w_ij k(x_i, y_j) / d x_i[lane, c]
     double xraw[DPAD]; // raw row of x_i owned by this lane (fp64 copy of the fp32/fp64 input; exact)
 
@@ -342,7 +365,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(GRAD ? 
         for (int k = 0; k < EPT; ++k) {
             const int e = tid + k * NT;
             const int t = e / DPAD, c = e % DPAD;
-            const bool ok = e < 64 * DPAD && t < T && c < d && j < a.B;
+            const bool ok = e < RING * DPAD && t < T && c < d && j < a.B;
             stage_v[k] = ok ? load_any(a.Y, ((size_t)j * T + t) * d + c, io64) : 0.0;
             stage_r[k] = ok ? load_any(a.Y, (size_t)j * T * d + c, io64) : 0.0;
         }
@@ -352,16 +375,16 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(GRAD ? 
 #pragma unroll
         for (int k = 0; k < EPT; ++k) {
             const int e = tid + k * NT;
-            if (e < 64 * DPAD) {
+            if (e < RING * DPAD) {
                 const int t = e / DPAD, c = e % DPAD;
                 const double v = stage_v[k] - stage_r[k];
                 if (!(LP && c == DPAD - 1)) { // (LP: that slot receives the norm below)
                     yd[t * YDS + c] = v;
-                    yd[(t + 64) * YDS + c] = v;
+                    yd[(t + RING) * YDS + c] = v;
                 }
                 if (GRAD) {
                     yf[t * YFS + c] = (float)v;
-                    yf[(t + 64) * YFS + c] = (float)v;
+                    yf[(t + RING) * YFS + c] = (float)v;
                 }
                 if (t == 0) yref[c] = stage_r[k];
                 double s = v * v * nscale; // -log2(e)/h * |y~_t|^2 via xor-reduction over the DPAD lanes of a row
@@ -369,10 +392,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(GRAD ? 
                 for (int off = 1; off < DPAD; off <<= 1) s += __shfl_xor(s, off, 64);
                 if (c == 0) {
                     ynd[t] = s;
-                    ynd[t + 64] = s;
+                    ynd[t + RING] = s;
                     if (LP) { // the padded channel of the fp64 row carries the norm: phase 1 needs no separate read
                         yd[t * YDS + DPAD - 1] = s;
-                        yd[(t + 64) * YDS + DPAD - 1] = s;
+                        yd[(t + RING) * YDS + DPAD - 1] = s;
                     }
                 }
             }
@@ -415,7 +438,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(GRAD ? 
 #pragma unroll
     for (int c = 0; c < DPAD; ++c) {
         gacc[c] = 0.0;
-        xraw[c] = (row_ok && lane < T && c < d) ? load_any(a.X, ((size_t)i * T + lane) * d + c, io64) : 0.0;
+        xraw[c] = (row_ok && lrow < T && c < d) ? load_any(a.X, ((size_t)i * T + lrow) * d + c, io64) : 0.0;
     }
     bool worked = false;
     for (;;) {
@@ -435,7 +458,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(GRAD ? 
         const bool pair_ok = row_ok && (!SYM || j >= i);
         if (j + 1 < j1) stage_load(j + 1); // in flight during the pair
 
-        float Dsl[64]; // increments / sqrt(12) (the scale the difference-form stencil wants), one slot per anti-diagonal
+        float Dsl[RING]; // increments / sqrt(12) (the scale the difference-form stencil wants), one slot per anti-diagonal
 
         SIG_STAMP(0)
         if (pair_ok) {
@@ -446,7 +469,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(GRAD ? 
             double xn = 0.0;
 #pragma unroll
             for (int c = 0; c < DPAD; ++c) {
-                const double xc = (lane < T && c < d) ? xraw[c] - yref[c] : 0.0;
+                const double xc = (lrow < T && c < d) ? xraw[c] - yref[c] : 0.0;
                 xn = __builtin_fma(xc, xc, xn);
                 xs[c] = xc * (-2.0 * nscale);
             }
@@ -457,8 +480,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(GRAD ? 
             // ---- phase 1: G rows (skewed: column (t - lane) & 63 on iteration t) -> D slots --------
             {
                 double g0 = 0.0, g1 = 0.0, gprev = 0.0, rdprev = 0.0;
-                const double *ybase = yd + (64 - lane) * YDS; // row (t - lane) & 63 == ybase + t*YDS
-                const double *nbase = ynd + (64 - lane);
+                const double *ybase = yd + (RING - lrow) * YDS; // row (t - lrow) & RM == ybase + t*YDS
+                const double *nbase = ynd + (RING - lrow);
                 // the y~ row of column t+1 is fetched while column t is computed (one s_waitcnt per
                 // column instead of one per ds_read, and the LDS latency is off the exp chain)
                 double ynx[DPAD], nnx;
@@ -466,14 +489,14 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(GRAD ? 
                 for (int c = 0; c < DPAD; ++c) ynx[c] = ybase[c];
                 nnx = LP ? 0.0 : nbase[0];
 #pragma unroll
-                for (int t = 0; t < 66; ++t) {
+                for (int t = 0; t < RING + 2; ++t) {
                     double g;
-                    if (t < 64) {
+                    if (t < RING) {
                         double ycu[DPAD];
 #pragma unroll
                         for (int c = 0; c < DPAD; ++c) ycu[c] = ynx[c];
                         double e2 = LP ? xn + ycu[DPAD - 1] : xn + nnx; // LP: the row's last slot is the norm
-                        if (t < 63) {
+                        if (t < RING - 1) {
                             const double *yr = ybase + (t + 1) * YDS;
 #pragma unroll
                             for (int c = 0; c < DPAD; ++c) ynx[c] = yr[c];
@@ -486,15 +509,15 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(GRAD ? 
                         if (t == 0) g0 = g;
                         if (t == 1) g1 = g;
                     } else {
-                        g = (t == 64) ? g0 : g1;
+                        g = (t == RING) ? g0 : g1;
                     }
                     const double rd = g - gprev; // G[l, q] - G[l, q-1]
                     gprev = g;
                     if (t >= 2) {
                         // lane l+1 holds the same column difference one iteration later
                         const double nb = dpp_shl1_zero(rd);
-                        Dsl[(t - 2) & 63] = (float)(nb - rdprev);
-                        asm volatile("" : "+v"(Dsl[(t - 2) & 63])); // formed HERE: hipcc otherwise sinks the fp64 difference to the sweep
+                        Dsl[(t - 2) & RM] = (float)(nb - rdprev);
+                        asm volatile("" : "+v"(Dsl[(t - 2) & RM])); // formed HERE: hipcc otherwise sinks the fp64 difference to the sweep
                     }
                     rdprev = rd;
                     __builtin_amdgcn_sched_barrier(0); // one column per scheduling region: bounds live ranges
@@ -520,16 +543,16 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(GRAD ? 
                 const int smax = 2 * P - 2;
                 if (GRAD) {
 #pragma unroll
-                    for (int k = 0; k < 64; ++k) Ksl[k] = 0.f;
+                    for (int k = 0; k < RING; ++k) Ksl[k] = 0.f;
                 }
-                for (int rnd = 0; rnd < 2; ++rnd) {
+                for (int rnd = 0; rnd < (RING == 64 ? 2 : 1); ++rnd) { // (RING = 32: 2P-2 <= 60, one round of 64 steps)
                     if (rnd * 64 > smax) break;
                     float r3 = 1.7320508075688772f;
                     asm volatile("" : "+s"(r3)); // opaque per round: nothing of the step is round-invariant
-                    const unsigned long long *mk = SWEEP_MASK.m[P] + rnd * 64; // EXEC windows of this round
+                    const unsigned long long *mk = (RING == 64 ? SWEEP_MASK.m[P] : SWEEP_MASK32.m[P]) + rnd * 64; // EXEC windows
 #pragma unroll
                     for (int k0 = 0; k0 < 64; k0 += 8) // Ksl[k] <- K[l, q]
-                        sweep_fwd8<GRAD>(cur, upA, upB, V, &Dsl[k0], &Ksl[k0], mk + k0, r3);
+                        sweep_fwd8<GRAD>(cur, upA, upB, V, &Dsl[k0 & RM], &Ksl[k0 & RM], mk + k0, r3);
                 }
                 if (lane == P - 1) { // this lane's last value is K[P, P]
                     store_any(a.K, (size_t)i * a.B + j, (double)cur, io64);
@@ -551,7 +574,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(GRAD ? 
                 f32x2 xc2[DPAD / 2];
 #pragma unroll
                 for (int c = 0; c < DPAD / 2; ++c) {
-                    const bool ok0 = lane < T && 2 * c < d, ok1 = lane < T && 2 * c + 1 < d;
+                    const bool ok0 = lrow < T && 2 * c < d, ok1 = lrow < T && 2 * c + 1 < d;
                     xc2[c] = f32x2{ok0 ? (float)(xraw[2 * c] - yref[2 * c]) : 0.f,
                                    ok1 ? (float)(xraw[2 * c + 1] - yref[2 * c + 1]) : 0.f};
                 }
@@ -564,7 +587,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(GRAD ? 
 #pragma unroll
                 for (int c = 0; c < DPAD; ++c) tacc[c] = 0.f;
 
-                int yfrow = 64 - lane;                          // row (sigma + 2 - lane) & 63 == yfrow + k2
+                int yfrow = RING - lrow;                        // row (sigma + 2 - lrow) & RM == yfrow + k2
                 int gsoff = (GRAD ? wave * GS_WAVE : 0) + lane; // this wave's [slot][lane] image
                 // one iteration of the phase-4 pass (below); `gcu`, `ycu`: G[l][n] and the y~_n row, fetched one
                 // iteration ahead so that the LDS latency is off the chain and one s_waitcnt serves the iteration
@@ -600,18 +623,18 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(GRAD ? 
                     }
                 };
 
-                for (int rnd = 1; rnd >= 0; --rnd) {
+                for (int rnd = (RING == 64 ? 1 : 0); rnd >= 0; --rnd) {
                     if (rnd * 64 > smax) continue;
                     // (keeps the phase-4 LDS addresses out of this loop's invariants: without the pin hipcc
                     //  rearranges the pass that follows and the C4 launch goes from 6.9 to 10.9 ms)
                     asm volatile("" : "+v"(yfrow), "+v"(gsoff));
                     float r3 = 1.7320508075688772f;
                     asm volatile("" : "+s"(r3));
-                    const unsigned long long *mk = SWEEP_MASK.m[P] + rnd * 64;
+                    const unsigned long long *mk = (RING == 64 ? SWEEP_MASK.m[P] : SWEEP_MASK32.m[P]) + rnd * 64;
                     // same difference form, V = U[l][q] - U[l+1][q] carried towards smaller q; `down` alternates between
                     // two registers like `up` (the diagonal neighbour U[l+1][q+1] is the lower neighbour one step ago)
 #pragma unroll
-                    for (int k0 = 56; k0 >= 0; k0 -= 8) sweep_rev8(cur, downA, downB, V, &Dsl[k0], &Ksl[k0], mk + k0, r3);
+                    for (int k0 = 56; k0 >= 0; k0 -= 8) sweep_rev8(cur, downA, downB, V, &Dsl[k0 & RM], &Ksl[k0 & RM], mk + k0, r3);
                 }
 
                 SIG_STAMP(3)
@@ -622,20 +645,20 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(GRAD ? 
                 // (column >= P, row >= P) hold S = 0 (see Ksl), which is also exactly what the scatter needs at the
                 // wrap (S[.][-1] = S[.][63] = 0).  Two warm-up iterations fill the history, the next 64 visit
                 // every column n = q + 2 once; the travelling sums rotate as before and end in lane (64 - n) & 63.
-                float gnx = 0.f, Svn = Ksl[63];
+                float gnx = 0.f, Svn = Ksl[RM];
                 f32x2 ynx[DPAD / 2];
 #pragma unroll
                 for (int c = 0; c < DPAD / 2; ++c) ynx[c] = f32x2{0.f, 0.f};
 #pragma unroll
-                for (int it = 0; it < 66; ++it) {
+                for (int it = 0; it < RING + 2; ++it) {
                     const float Sv = Svn, gcu = gnx;
                     f32x2 ycu[DPAD / 2];
 #pragma unroll
                     for (int c = 0; c < DPAD / 2; ++c) ycu[c] = ynx[c];
-                    if (it + 1 < 66) { // next iteration's operands: slot (62 - it) & 63, column slot (64 - it) & 63
-                        Svn = Ksl[(62 - it) & 63];
+                    if (it + 1 < RING + 2) { // next iteration's operands: slot (RING-2 - it) & RM, column slot (RING - it) & RM
+                        Svn = Ksl[(RING - 2 - it) & RM];
                         if (it + 1 >= 2) {
-                            const int k2n = (64 - it) & 63;
+                            const int k2n = (RING - it) & RM;
                             gnx = Gs_all[gsoff + k2n * GS_STRIDE];
                             const f32x2 *yr = reinterpret_cast<const f32x2 *>(yf + (yfrow + k2n) * YFS);
 #pragma unroll
@@ -661,9 +684,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(GRAD ? 
                     gacc[c] += (double)(w_ij * m2h * (xc2[c / 2][c % 2] * s0 - acc[c / 2][c % 2]));
                 }
 
-                if (SYM && j != i) {
+                if (SYM && j != i && lane < RING) { // (RING = 32: the mirror lanes hold the same sums in another order)
                     // park the column-side result in this wave's own G region ([lane][c]) for the block sum
-                    const int ncol = (64 - lane) & 63; // the column whose finished sums this lane ended up with
+                    const int ncol = (RING - lrow) & RM; // the column whose finished sums this lane ended up with
                     const float *yr = yf + ncol * YFS;
 #pragma unroll
                     for (int c = 0; c < DPAD; ++c)
@@ -776,7 +799,7 @@ int cu_count()
     return n;
 }
 
-template <int DPAD, int NW>
+template <int DPAD, int NW, int RING = 64>
 int launch_variant(const GramProblem &p, FastArgs &a, bool grad, bool sym)
 {
     const int ntile = (p.A + NW - 1) / NW;
@@ -818,17 +841,17 @@ int launch_variant(const GramProblem &p, FastArgs &a, bool grad, bool sym)
     constexpr bool HAS_LP = DPAD <= 8; // the d == DPAD - 1 instantiations exist for the 4- and 8-channel layouts
     const bool lp = HAS_LP && grad && p.d == DPAD - 1;
     if (!grad && sym)
-        hipLaunchKernelGGL((gram_fast_kernel<DPAD, NW, false, true, false>), grid, block, 0, p.stream, a);
+        hipLaunchKernelGGL((gram_fast_kernel<DPAD, NW, false, true, false, RING>), grid, block, 0, p.stream, a);
     else if (!grad)
-        hipLaunchKernelGGL((gram_fast_kernel<DPAD, NW, false, false, false>), grid, block, 0, p.stream, a);
+        hipLaunchKernelGGL((gram_fast_kernel<DPAD, NW, false, false, false, RING>), grid, block, 0, p.stream, a);
     else if (sym && lp)
-        hipLaunchKernelGGL((gram_fast_kernel<DPAD, NW, true, true, HAS_LP>), grid, block, 0, p.stream, a);
+        hipLaunchKernelGGL((gram_fast_kernel<DPAD, NW, true, true, HAS_LP, RING>), grid, block, 0, p.stream, a);
     else if (sym)
-        hipLaunchKernelGGL((gram_fast_kernel<DPAD, NW, true, true, false>), grid, block, 0, p.stream, a);
+        hipLaunchKernelGGL((gram_fast_kernel<DPAD, NW, true, true, false, RING>), grid, block, 0, p.stream, a);
     else if (lp)
-        hipLaunchKernelGGL((gram_fast_kernel<DPAD, NW, true, false, HAS_LP>), grid, block, 0, p.stream, a);
+        hipLaunchKernelGGL((gram_fast_kernel<DPAD, NW, true, false, HAS_LP, RING>), grid, block, 0, p.stream, a);
     else
-        hipLaunchKernelGGL((gram_fast_kernel<DPAD, NW, true, false, false>), grid, block, 0, p.stream, a);
+        hipLaunchKernelGGL((gram_fast_kernel<DPAD, NW, true, false, false, RING>), grid, block, 0, p.stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "launch gram_fast_kernel");
 #ifdef SIGSVGD_PHASE_STAMPS
@@ -886,13 +909,13 @@ int fast_launch(const GramProblem &p)
     }
     int rc;
     if (!grad && p.d <= 4) // forward only: no G image, <=168 VGPRs -> 4-wave workgroups pack 3 waves per SIMD
-        rc = launch_variant<4, 4>(p, a, false, sym);
+        rc = p.T <= 32 ? launch_variant<4, 4, 32>(p, a, false, sym) : launch_variant<4, 4>(p, a, false, sym);
     else if (!grad && p.d <= 8)
-        rc = launch_variant<8, 4>(p, a, false, sym);
+        rc = p.T <= 32 ? launch_variant<8, 4, 32>(p, a, false, sym) : launch_variant<8, 4>(p, a, false, sym);
     else if (p.d <= 4)
-        rc = launch_variant<4, 8>(p, a, grad, sym);
-    else if (p.d <= 8)
-        rc = launch_variant<8, 8>(p, a, grad, sym);
+        rc = p.T <= 32 ? launch_variant<4, 8, 32>(p, a, grad, sym) : launch_variant<4, 8>(p, a, grad, sym);
+    else if (p.d <= 8) // (paths of <= 32 points: the 32-slot ring, phases 1 and 4 in 34 iterations instead of 66)
+        rc = p.T <= 32 ? launch_variant<8, 8, 32>(p, a, grad, sym) : launch_variant<8, 8>(p, a, grad, sym);
     else
         rc = launch_variant<16, 4>(p, a, grad, sym); // 1 wave per SIMD: 512-VGPR budget, no spills
     if (rc) return rc;
@@ -938,8 +961,8 @@ int fast_sym_partial(const GramProblem &p, int tile_offset, int tile_stride, dou
         return SIGSVGD_E_WORKSPACE;
     }
     a.queue = reinterpret_cast<int *>((reinterpret_cast<uintptr_t>(p.ws) + 255) & ~(uintptr_t)255);
-    if (p.d <= 4) return launch_variant<4, 8>(p, a, true, true);
-    if (p.d <= 8) return launch_variant<8, 8>(p, a, true, true);
+    if (p.d <= 4) return p.T <= 32 ? launch_variant<4, 8, 32>(p, a, true, true) : launch_variant<4, 8>(p, a, true, true);
+    if (p.d <= 8) return p.T <= 32 ? launch_variant<8, 8, 32>(p, a, true, true) : launch_variant<8, 8>(p, a, true, true);
     return launch_variant<16, 4>(p, a, true, true);
 }
 
