@@ -135,13 +135,20 @@ __device__ __forceinline__ void st_from_f64(T *p, size_t i, double v)
     p[i] = (T)v;
 }
 
+// Neighbour-lane moves of a double as two DPP moves (wave_shr:1 / wave_shl:1; the lane without a source keeps its own
+// value).  __shfl_up / __shfl_down lower to ds_bpermute: an LDS round trip (~100 cycles) on the dependent chain of
+// every PDE step, against ~8 cycles here.
 __device__ __forceinline__ double shfl_up_f64(double v)   // lane l <- lane l-1 (lane 0 keeps own)
 {
-    return __shfl_up(v, 1, kWave);
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), 0x138, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), 0x138, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double shfl_down_f64(double v) // lane l <- lane l+1 (lane 63 keeps own)
 {
-    return __shfl_down(v, 1, kWave);
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), 0x130, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), 0x130, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
 }
 
 // ---- launch descriptors shared by host code -----------------------------------------------------
