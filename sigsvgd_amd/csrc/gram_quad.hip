@@ -66,25 +66,11 @@ struct QuadArgs {
 #endif
 
 namespace {
-constexpr int QNW = 8; // wavefronts (rows i) per workgroup
+#ifndef SIGQ_NW // (-DSIGQ_NW=4: one wavefront per SIMD, a timing experiment of scripts/dev/ab_quad.py)
+#define SIGQ_NW 8
+#endif
+constexpr int QNW = SIGQ_NW; // wavefronts (rows i) per workgroup
 using qf32x2 = __attribute__((ext_vector_type(2))) float;
-
-// EXEC windows: lanes max(0, sigma - n + 1) .. min(sigma, 63) are inside a quadrant of n cell columns on
-// anti-diagonal sigma (AND-ed with the quadrant's row mask in the step)
-struct QuadMasks {
-    unsigned long long m[65][128];
-    constexpr QuadMasks() : m()
-    {
-        for (int n = 1; n <= 64; ++n)
-            for (int s = 0; s <= n + 62; ++s) {
-                const int lo = s - n + 1 > 0 ? s - n + 1 : 0, hi = s < 63 ? s : 63;
-                unsigned long long w = 0;
-                for (int l = lo; l <= hi; ++l) w |= 1ull << l;
-                m[n][s] = w;
-            }
-    }
-};
-__constant__ const QuadMasks QUAD_MASK = QuadMasks();
 
 __device__ __forceinline__ double q_ldany(const void *b, size_t i, int io64)
 {
@@ -192,73 +178,158 @@ __device__ __forceinline__ double qexp2_p7(double t, const QExp7 &k)
     return ldexp(p, (int)kf);
 }
 
-// ---- four steps of a sweep (cf. gram_fast.hip for the scheduling rules).  Per step: DPP shift under full EXEC, the
-// stencil under the window, then -- still under the window -- the K_fwd slot store (forward) / S product (reverse),
-// the boundary value of the NEXT step into the register the next shift writes (lane 0 / 63 keeps it: no DPP source),
-// and the hand-over store.  The three trailing instructions are also the wait states between the write of `cur` /
-// of the shift destination and the next DPP instruction.
-#define SIG_Q_FWD(UP, DIAG, G, K, M, BN)                                                      \
+// ---- four steps of a sweep (cf. gram_fast.hip for the scheduling rules).  Per step: the EXEC window from one scalar
+// shift (no table: a quadrant of n cell columns has lanes max(0, sigma - n + 1) .. min(sigma, 63) on anti-diagonal
+// sigma, which is `wr` = the top n bits shifted right by 63 - sigma or left by sigma - 63), the DPP shift under full
+// EXEC, the stencil under the window AND the quadrant's row mask, then -- still under the window -- the K_fwd slot
+// store (forward) / S product (reverse), the boundary value of the NEXT step into the register the next shift
+// writes (lane 0 / 63 keeps it: no DPP source), and the hand-over store.  The boundary values of a sweep sit one per
+// lane in a VGPR (read from the hand-over row in LDS once, before the sweep) and reach the step through
+// v_readlane with a compile-time lane: a sweep has no load and no s_waitcnt at all (the table + LDS version
+// exposed an LDS and a scalar-load latency every four steps: 138 cycles per step against 59 in gram_fast).
+// The trailing VALU instructions are also the wait states between the write of `cur` and the next DPP.
+#define SIG_Q_FWD(SH, KI, W, UP, DIAG, G, K, BNA, BNB)                                        \
+    SH " %[tm], %[" W "], %[" KI "]\n\t"                                                      \
     "s_mov_b64 exec, -1\n\t"                                                                  \
-    "v_mov_b32_dpp %[" UP "], %[cur] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"               \
-    "s_and_b64 exec, %[" M "], %[rows]\n\t"                                                   \
+    "v_mov_b32_dpp %[" UP "], %[cur] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t" BNA           \
+    "s_and_b64 exec, %[tm], %[rows]\n\t"                                                      \
     "v_add_f32 %[t], %[cur], %[" UP "]\n\t"                                                   \
     "v_mul_f32 %[y], %[r3], %[t]\n\t"                                                         \
     "v_add_f32 %[t], %[t], %[" DIAG "]\n\t"                                                   \
     "v_fmac_f32 %[y], %[t], %[" G "]\n\t"                                                     \
     "v_fmac_f32 %[V], %[" G "], %[y]\n\t"                                                     \
     "v_add_f32 %[cur], %[" UP "], %[V]\n\t"                                                   \
-    "v_mov_b32 %[" K "], %[" DIAG "]\n\t"                                                     \
-    "v_mov_b32 %[" DIAG "], %[" BN "]\n\t"                                                    \
+    "v_mov_b32 %[" K "], %[" DIAG "]\n\t" BNB                                                 \
     "ds_write_b32 %[ha], %[cur]\n\t"                                                          \
     "v_add_u32 %[ha], %[hinc], %[ha]\n\t"
-#define SIG_Q_REV(DN, DDIAG, G, K, M, BN)                                                     \
+#define SIG_Q_REV(SH, KI, W, DN, DDIAG, G, K, BNA, BNB)                                       \
+    SH " %[tm], %[" W "], %[" KI "]\n\t"                                                      \
     "s_mov_b64 exec, -1\n\t"                                                                  \
-    "v_mov_b32_dpp %[" DN "], %[cur] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"               \
-    "s_and_b64 exec, %[" M "], %[rows]\n\t"                                                   \
+    "v_mov_b32_dpp %[" DN "], %[cur] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t" BNA           \
+    "s_and_b64 exec, %[tm], %[rows]\n\t"                                                      \
     "v_add_f32 %[t], %[cur], %[" DN "]\n\t"                                                   \
     "v_mul_f32 %[y], %[r3], %[t]\n\t"                                                         \
     "v_add_f32 %[t], %[t], %[" DDIAG "]\n\t"                                                  \
     "v_fmac_f32 %[y], %[t], %[" G "]\n\t"                                                     \
     "v_fmac_f32 %[V], %[" G "], %[y]\n\t"                                                     \
     "v_add_f32 %[cur], %[" DN "], %[V]\n\t"                                                   \
-    "v_mul_f32 %[" K "], %[" K "], %[" DDIAG "]\n\t"                                          \
-    "v_mov_b32 %[" DDIAG "], %[" BN "]\n\t"                                                   \
+    "v_mul_f32 %[" K "], %[" K "], %[" DDIAG "]\n\t" BNB                                      \
     "ds_write_b32 %[ha], %[cur]\n\t"                                                          \
     "v_add_u32 %[ha], %[hinc], %[ha]\n\t"
+// boundary value through a scalar: lane L of the per-sweep boundary register
+#define SIG_Q_RL(L) "v_readlane_b32 %[sb], %[hb], %[" L "]\n\t"
+#define SIG_Q_BMOV(DIAG) "v_mov_b32 %[" DIAG "], %[sb]\n\t"
 
-// steps sigma0 .. sigma0+3 (sigma0 a multiple of 4); bn[u]: boundary value of step sigma0+u+1
+// steps S0 .. S0+3 (S0 a multiple of 4).  hb: lane l holds the boundary value lane 0 needs after step l, i.e.
+// K[64 b][64 h + l + 2]; lane 0 is outside the window from step 64 on, so the later steps carry none.
+template <int S0>
 __device__ __forceinline__ void quad_fwd4(float &cur, float &upA, float &upB, float &V, const float *g, float *ksl,
-                                          const unsigned long long *mk, const unsigned long long rows, const float *bn,
+                                          const unsigned long long wr, const unsigned long long rows, const float hb,
                                           int &ha, const int hinc, const float r3)
 {
     float t, y;
-    const unsigned long long m0 = mk[0], m1 = mk[1], m2 = mk[2], m3 = mk[3];
-    asm volatile(SIG_Q_FWD("upA", "upB", "g0", "k0", "m0", "b0") SIG_Q_FWD("upB", "upA", "g1", "k1", "m1", "b1")
-                 SIG_Q_FWD("upA", "upB", "g2", "k2", "m2", "b2") SIG_Q_FWD("upB", "upA", "g3", "k3", "m3", "b3")
-                 "s_mov_b64 exec, -1\n\t"
-                 : [cur] "+v"(cur), [upA] "+v"(upA), [upB] "+v"(upB), [V] "+v"(V), [ha] "+v"(ha), [t] "=&v"(t),
-                   [y] "=&v"(y), [k0] "+v"(ksl[0]), [k1] "+v"(ksl[1]), [k2] "+v"(ksl[2]), [k3] "+v"(ksl[3])
-                 : [g0] "v"(g[0]), [g1] "v"(g[1]), [g2] "v"(g[2]), [g3] "v"(g[3]), [b0] "v"(bn[0]), [b1] "v"(bn[1]),
-                   [b2] "v"(bn[2]), [b3] "v"(bn[3]), [m0] "s"(m0), [m1] "s"(m1), [m2] "s"(m2), [m3] "s"(m3),
-                   [rows] "s"(rows), [hinc] "v"(hinc), [r3] "s"(r3)
-                 : "scc");
+    unsigned long long tm;
+    if constexpr (S0 < 64) {
+        int sb;
+        asm volatile(SIG_Q_FWD("s_lshr_b64", "i0", "wr", "upA", "upB", "g0", "k0", SIG_Q_RL("l0"), SIG_Q_BMOV("upB"))
+                     SIG_Q_FWD("s_lshr_b64", "i1", "wr", "upB", "upA", "g1", "k1", SIG_Q_RL("l1"), SIG_Q_BMOV("upA"))
+                     SIG_Q_FWD("s_lshr_b64", "i2", "wr", "upA", "upB", "g2", "k2", SIG_Q_RL("l2"), SIG_Q_BMOV("upB"))
+                     SIG_Q_FWD("s_lshr_b64", "i3", "wr", "upB", "upA", "g3", "k3", SIG_Q_RL("l3"), SIG_Q_BMOV("upA"))
+                     "s_mov_b64 exec, -1\n\t"
+                     : [cur] "+v"(cur), [upA] "+v"(upA), [upB] "+v"(upB), [V] "+v"(V), [ha] "+v"(ha), [t] "=&v"(t),
+                       [y] "=&v"(y), [k0] "+v"(ksl[0]), [k1] "+v"(ksl[1]), [k2] "+v"(ksl[2]), [k3] "+v"(ksl[3]),
+                       [tm] "=&s"(tm), [sb] "=&s"(sb)
+                     : [g0] "v"(g[0]), [g1] "v"(g[1]), [g2] "v"(g[2]), [g3] "v"(g[3]), [hb] "v"(hb), [wr] "s"(wr),
+                       [rows] "s"(rows), [hinc] "v"(hinc), [r3] "s"(r3), [i0] "n"(63 - S0), [i1] "n"(62 - S0),
+                       [i2] "n"(61 - S0), [i3] "n"(60 - S0), [l0] "n"(S0), [l1] "n"(S0 + 1), [l2] "n"(S0 + 2),
+                       [l3] "n"(S0 + 3)
+                     : "scc");
+    } else {
+        const unsigned long long wl = (S0 + 3 == 127) ? 0ull : wr; // anti-diagonal 127 has no cell (a shift by 64 is one by 0)
+        asm volatile(SIG_Q_FWD("s_lshl_b64", "i0", "wr", "upA", "upB", "g0", "k0", "", "")
+                     SIG_Q_FWD("s_lshl_b64", "i1", "wr", "upB", "upA", "g1", "k1", "", "")
+                     SIG_Q_FWD("s_lshl_b64", "i2", "wr", "upA", "upB", "g2", "k2", "", "")
+                     SIG_Q_FWD("s_lshl_b64", "i3", "wl", "upB", "upA", "g3", "k3", "", "")
+                     "s_mov_b64 exec, -1\n\t"
+                     : [cur] "+v"(cur), [upA] "+v"(upA), [upB] "+v"(upB), [V] "+v"(V), [ha] "+v"(ha), [t] "=&v"(t),
+                       [y] "=&v"(y), [k0] "+v"(ksl[0]), [k1] "+v"(ksl[1]), [k2] "+v"(ksl[2]), [k3] "+v"(ksl[3]),
+                       [tm] "=&s"(tm)
+                     : [g0] "v"(g[0]), [g1] "v"(g[1]), [g2] "v"(g[2]), [g3] "v"(g[3]), [wr] "s"(wr), [wl] "s"(wl),
+                       [rows] "s"(rows), [hinc] "v"(hinc), [r3] "s"(r3), [i0] "n"(S0 - 63), [i1] "n"(S0 - 62),
+                       [i2] "n"(S0 - 61), [i3] "n"((S0 - 60) & 63)
+                     : "scc");
+    }
 }
-// steps sigma0+3 .. sigma0 (descending); bn[u]: boundary value of the step after the u-th one executed
+// steps S0+3 .. S0 (descending).  hb: lane l holds the boundary value lane 63 needs after step l + 64, i.e.
+// U[64 b + 64][64 h + l]; bm: the one after step 63 (a right quadrant hands lane 63 the first value of the left one);
+// lane 63 is outside the window below step 63.
+template <int S0>
 __device__ __forceinline__ void quad_rev4(float &cur, float &dnA, float &dnB, float &V, const float *g, float *ksl,
-                                          const unsigned long long *mk, const unsigned long long rows, const float *bn,
-                                          int &ha, const int hinc, const float r3)
+                                          const unsigned long long wr, const unsigned long long rows, const float hb,
+                                          const float bm, int &ha, const int hinc, const float r3)
 {
     float t, y;
-    const unsigned long long m0 = mk[0], m1 = mk[1], m2 = mk[2], m3 = mk[3];
-    asm volatile(SIG_Q_REV("dnA", "dnB", "g3", "k3", "m3", "b0") SIG_Q_REV("dnB", "dnA", "g2", "k2", "m2", "b1")
-                 SIG_Q_REV("dnA", "dnB", "g1", "k1", "m1", "b2") SIG_Q_REV("dnB", "dnA", "g0", "k0", "m0", "b3")
-                 "s_mov_b64 exec, -1\n\t"
-                 : [cur] "+v"(cur), [dnA] "+v"(dnA), [dnB] "+v"(dnB), [V] "+v"(V), [ha] "+v"(ha), [t] "=&v"(t),
-                   [y] "=&v"(y), [k0] "+v"(ksl[0]), [k1] "+v"(ksl[1]), [k2] "+v"(ksl[2]), [k3] "+v"(ksl[3])
-                 : [g0] "v"(g[0]), [g1] "v"(g[1]), [g2] "v"(g[2]), [g3] "v"(g[3]), [b0] "v"(bn[0]), [b1] "v"(bn[1]),
-                   [b2] "v"(bn[2]), [b3] "v"(bn[3]), [m0] "s"(m0), [m1] "s"(m1), [m2] "s"(m2), [m3] "s"(m3),
-                   [rows] "s"(rows), [hinc] "v"(hinc), [r3] "s"(r3)
-                 : "scc");
+    unsigned long long tm;
+    if constexpr (S0 >= 64) {
+        int sb;
+        const unsigned long long wl = (S0 + 3 == 127) ? 0ull : wr;
+        asm volatile(SIG_Q_REV("s_lshl_b64", "i3", "wl", "dnA", "dnB", "g3", "k3", SIG_Q_RL("l3"), SIG_Q_BMOV("dnB"))
+                     SIG_Q_REV("s_lshl_b64", "i2", "wr", "dnB", "dnA", "g2", "k2", SIG_Q_RL("l2"), SIG_Q_BMOV("dnA"))
+                     SIG_Q_REV("s_lshl_b64", "i1", "wr", "dnA", "dnB", "g1", "k1", SIG_Q_RL("l1"), SIG_Q_BMOV("dnB"))
+                     SIG_Q_REV("s_lshl_b64", "i0", "wr", "dnB", "dnA", "g0", "k0", SIG_Q_RL("l0"), SIG_Q_BMOV("dnA"))
+                     "s_mov_b64 exec, -1\n\t"
+                     : [cur] "+v"(cur), [dnA] "+v"(dnA), [dnB] "+v"(dnB), [V] "+v"(V), [ha] "+v"(ha), [t] "=&v"(t),
+                       [y] "=&v"(y), [k0] "+v"(ksl[0]), [k1] "+v"(ksl[1]), [k2] "+v"(ksl[2]), [k3] "+v"(ksl[3]),
+                       [tm] "=&s"(tm), [sb] "=&s"(sb)
+                     : [g0] "v"(g[0]), [g1] "v"(g[1]), [g2] "v"(g[2]), [g3] "v"(g[3]), [hb] "v"(hb), [wr] "s"(wr),
+                       [wl] "s"(wl), [rows] "s"(rows), [hinc] "v"(hinc), [r3] "s"(r3), [i0] "n"(S0 - 63),
+                       [i1] "n"(S0 - 62), [i2] "n"(S0 - 61), [i3] "n"((S0 - 60) & 63), [l0] "n"(S0 - 64),
+                       [l1] "n"(S0 - 63), [l2] "n"(S0 - 62), [l3] "n"(S0 - 61)
+                     : "scc");
+    } else if constexpr (S0 == 60) {
+        asm volatile(SIG_Q_REV("s_lshr_b64", "i3", "wr", "dnA", "dnB", "g3", "k3", "", "v_mov_b32 %[dnB], %[bm]\n\t")
+                     SIG_Q_REV("s_lshr_b64", "i2", "wr", "dnB", "dnA", "g2", "k2", "", "")
+                     SIG_Q_REV("s_lshr_b64", "i1", "wr", "dnA", "dnB", "g1", "k1", "", "")
+                     SIG_Q_REV("s_lshr_b64", "i0", "wr", "dnB", "dnA", "g0", "k0", "", "")
+                     "s_mov_b64 exec, -1\n\t"
+                     : [cur] "+v"(cur), [dnA] "+v"(dnA), [dnB] "+v"(dnB), [V] "+v"(V), [ha] "+v"(ha), [t] "=&v"(t),
+                       [y] "=&v"(y), [k0] "+v"(ksl[0]), [k1] "+v"(ksl[1]), [k2] "+v"(ksl[2]), [k3] "+v"(ksl[3]),
+                       [tm] "=&s"(tm)
+                     : [g0] "v"(g[0]), [g1] "v"(g[1]), [g2] "v"(g[2]), [g3] "v"(g[3]), [bm] "v"(bm), [wr] "s"(wr),
+                       [rows] "s"(rows), [hinc] "v"(hinc), [r3] "s"(r3), [i0] "n"(63 - S0), [i1] "n"(62 - S0),
+                       [i2] "n"(61 - S0), [i3] "n"(60 - S0)
+                     : "scc");
+    } else {
+        asm volatile(SIG_Q_REV("s_lshr_b64", "i3", "wr", "dnA", "dnB", "g3", "k3", "", "")
+                     SIG_Q_REV("s_lshr_b64", "i2", "wr", "dnB", "dnA", "g2", "k2", "", "")
+                     SIG_Q_REV("s_lshr_b64", "i1", "wr", "dnA", "dnB", "g1", "k1", "", "")
+                     SIG_Q_REV("s_lshr_b64", "i0", "wr", "dnB", "dnA", "g0", "k0", "", "")
+                     "s_mov_b64 exec, -1\n\t"
+                     : [cur] "+v"(cur), [dnA] "+v"(dnA), [dnB] "+v"(dnB), [V] "+v"(V), [ha] "+v"(ha), [t] "=&v"(t),
+                       [y] "=&v"(y), [k0] "+v"(ksl[0]), [k1] "+v"(ksl[1]), [k2] "+v"(ksl[2]), [k3] "+v"(ksl[3]),
+                       [tm] "=&s"(tm)
+                     : [g0] "v"(g[0]), [g1] "v"(g[1]), [g2] "v"(g[2]), [g3] "v"(g[3]), [wr] "s"(wr), [rows] "s"(rows),
+                       [hinc] "v"(hinc), [r3] "s"(r3), [i0] "n"(63 - S0), [i1] "n"(62 - S0), [i2] "n"(61 - S0),
+                       [i3] "n"(60 - S0)
+                     : "scc");
+    }
+}
+// the unrolled sweeps (the group index has to be a compile-time constant for the shift and lane immediates)
+template <int S0>
+__device__ __forceinline__ void quad_fwd_all(float &cur, float &upA, float &upB, float &V, const float *D, float *S,
+                                             const unsigned long long wr, const unsigned long long rows, const float hb,
+                                             int &ha, const int hinc, const float r3)
+{
+    quad_fwd4<S0>(cur, upA, upB, V, D + (S0 & 63), S + (S0 & 63), wr, rows, hb, ha, hinc, r3);
+    if constexpr (S0 + 4 < 128) quad_fwd_all<S0 + 4>(cur, upA, upB, V, D, S, wr, rows, hb, ha, hinc, r3);
+}
+template <int S0>
+__device__ __forceinline__ void quad_rev_all(float &cur, float &dnA, float &dnB, float &V, const float *D, float *S,
+                                             const unsigned long long wr, const unsigned long long rows, const float hb,
+                                             const float bm, int &ha, const int hinc, const float r3)
+{
+    quad_rev4<S0>(cur, dnA, dnB, V, D + (S0 & 63), S + (S0 & 63), wr, rows, hb, bm, ha, hinc, r3);
+    if constexpr (S0 >= 4) quad_rev_all<S0 - 4>(cur, dnA, dnB, V, D, S, wr, rows, hb, bm, ha, hinc, r3);
 }
 } // namespace
 
@@ -268,7 +339,7 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
     constexpr int NT = QNW * 64;
     constexpr int CS = DPAD + 1;  // row stride of the column-side image (odd: lanes on distinct banks)
     constexpr int YDS = DPAD + 2; // fp64 row: coordinates, [DPAD] = -log2(e)/h * |y~|^2
-    constexpr int YFS = (DPAD == 4) ? 12 : DPAD + 4; // fp32 row
+    constexpr int YFS = (DPAD == 16) ? 18 : 12; // fp32 row (8-byte aligned; 18 l mod 64 visits 32 distinct even banks)
     // point column n = 64 h + c is stored at rows 128 h + c and 128 h + 64 + c: the skewed row (t - lane) & 63 of
     // half h is then base(h, lane) + t * stride
     __shared__ __align__(16) double yd[256 * YDS];
@@ -282,6 +353,10 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
         float hK[HN], hU[HN], hdummy[64], srow[256], x64[DPAD + 2];
     };
     __shared__ WaveLds wl_all[QNW];
+    // row-side gradient of the wavefront's particle, summed over the columns of the work item before it goes to memory
+    // (one coalesced flush per item instead of 128 d lane-strided fp64 atomics per pair: -8 % symmetric, -16 % ordered)
+    constexpr int RS = (DPAD == 8) ? 9 : 15; // row stride (odd); d = 15, 16 do not fit next to the rest and flush per pair
+    __shared__ float rowacc_all[GRAD ? QNW * 128 * RS : 4];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int T = a.T, d = a.d, P = T - 1, io64 = a.io64;
@@ -294,11 +369,13 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
     double *g64 = wl.g64, *rdh = wl.rdh;
     float *srow63 = wl.srow, *srow64 = wl.srow + 128;
     float *x64 = wl.x64;
+    float *rowacc = rowacc_all + (GRAD ? wave * 128 * RS : 0);
+    const bool rowlds = GRAD && d <= RS;
     for (int e = tid; e < HN; e += NT) ones[e] = 1.f;
     for (int e = lane; e < HN; e += 64) hK[e] = 1.f, hU[e] = 1.f; // (entries the sweeps do not write stay at the boundary value)
 
 #ifdef SIGSVGD_PHASE_STAMPS
-    unsigned long long ph_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast_ = __builtin_amdgcn_s_memtime();
+    unsigned long long ph_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast_ = __builtin_amdgcn_s_memtime();
 #endif
     float *dcw = a.dcache ? a.dcache + ((size_t)blockIdx.x * QNW + wave) * (3 * 64 * 64) : nullptr;
 
@@ -324,6 +401,8 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
     const int i = i0 + wave;
     const int j0 = cx * a.JC, j1 = min(a.B, j0 + a.JC);
     const bool row_ok = i < a.A;
+    if (rowlds)
+        for (int e = lane; e < 128 * RS; e += 64) rowacc[e] = 0.f;
 
     for (int j = j0; j < j1; ++j) {
         // per-pair copies of the thread indices that the optimiser cannot see through: every index / address vector
@@ -333,6 +412,7 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
         asm volatile("" : "+v"(tidp), "+v"(lanep));
         // ---- stage y_j (centred on its first point): fp64 rows + scaled norms, fp32 copy, both twice ----------
         __syncthreads();
+        SIG_QSTAMP(10)
         constexpr int EPT = (128 * DPAD) / NT; // elements per thread: all loads of a thread are issued together
         double sv[EPT], sr[EPT];
         if (io64) {
@@ -491,7 +571,7 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                 asm volatile("" : "+v"(lv)); // the visit instead of becoming spilled loop invariants
                 const int m = 64 * b + lv; // point row of this lane
                 const unsigned long long rows = nrows >= 64 ? ~0ull : ((1ull << nrows) - 1ull);
-                const unsigned long long *mk = QUAD_MASK.m[ncols];
+                const unsigned long long wr = ncols >= 64 ? ~0ull : (ncols > 0 ? ~0ull << (64 - ncols) : 0ull); // top ncols bits
 
                 // ---- x_m, centred and pre-scaled (fp64 for the static kernel, fp32 for the gradient pass); re-read on
                 // every visit (L2 hits) so that the fp64 copy is not live across the gradient pass
@@ -597,18 +677,11 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                     asm volatile("" : "+s"(r3));
 #pragma unroll
                     for (int k = 0; k < 64; ++k) Ssl[k] = 0.f; // slots without a grid cell must read as S = 0
-                    // The statements write the hand-over row in LDS but carry no "memory" clobber: with one, the boundary
-                    // values and EXEC windows of a statement could not be fetched before the previous statement has ended,
-                    // and every statement would start with an exposed LDS + scalar-load latency.  What they write is read
+                    // The statements write the hand-over row in LDS but carry no "memory" clobber; what they write is read
                     // in LATER visits only, so one compiler barrier around the sweep is enough.
+                    const float hbf = topb[lv + 2]; // lane l: the value lane 0 takes after step l
                     asm volatile("" ::: "memory");
-#pragma unroll
-                    for (int s0 = 0; s0 < 128; s0 += 4) {
-                        float bn[4];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) bn[u] = topb[(s0 + u + 2 < 66) ? s0 + u + 2 : 66];
-                        quad_fwd4(fc, fuA, fuB, fV, &Dsl[s0 & 63], &Ssl[s0 & 63], mk + s0, rows, bn, haddr, hinc, r3);
-                    }
+                    quad_fwd_all<0>(fc, fuA, fuB, fV, Dsl, Ssl, wr, rows, hbf, haddr, hinc, r3);
                     asm volatile("" ::: "memory");
                 }
                 if (b == 0 && h == 0) {
@@ -652,19 +725,11 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                     const int hinc = (lanep == 0 && leave_u) ? -4 : 0;
                     float r3 = 1.7320508075688772f;
                     asm volatile("" : "+s"(r3));
+                    // after step sigma >= 64 lane 63 takes the boundary value of step sigma - 1, U[.][64 h + sigma - 64];
+                    // after step 63 a right quadrant hands it the first value of the left one (index -1)
+                    const float hbr = botb[lv], bmr = botb[-h];
                     asm volatile("" ::: "memory");
-#pragma unroll
-                    for (int s0 = 124; s0 >= 0; s0 -= 4) {
-                        // after step sigma the boundary value of step sigma - 1: U[.][64 h + sigma - 1 - 63]
-                        float bn[4];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const int sg = s0 + 3 - u; // the step executed
-                            // (step 63 of a right quadrant hands lane 63 the first value of the left one: index -1)
-                            bn[u] = botb[(sg >= 64) ? sg - 64 : ((sg == 63) ? -h : 0)];
-                        }
-                        quad_rev4(rc, rdA, rdB, rV, &Dsl[s0 & 63], &Ssl[s0 & 63], mk + s0, rows, bn, haddr, hinc, r3);
-                    }
+                    quad_rev_all<124>(rc, rdA, rdB, rV, Dsl, Ssl, wr, rows, hbr, bmr, haddr, hinc, r3);
                     asm volatile("" ::: "memory");
                 }
                 SIG_QSTAMP(3)
@@ -754,7 +819,7 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                     }
                 }
 
-                SIG_QSTAMP(7)
+                SIG_QSTAMP(8)
                 // ---- the band's seam columns (after its left quadrant): point columns 0 and 64 ---------------------
                 if (h == 0) {
 #pragma unroll
@@ -786,11 +851,18 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                     // the band is done: its row-side gradient d k(x_i, y_j) / d x_i[m] goes to the fp64 accumulation buffer
                     // (point row 64 comes from the seam pass below)
                     if (m <= P && !(b == 1 && lv == 0)) {
+                        if (rowlds) {
+                            float *dst = rowacc + m * RS;
 #pragma unroll
-                        for (int c = 0; c < DPAD; ++c)
-                            if (c < d)
-                                unsafeAtomicAdd(&a.gacc[((size_t)i * T + m) * d + c],
-                                                (double)(w_ij * m2h * (xf[c] * s0 - acc[c / 2][c % 2])));
+                            for (int c = 0; c < RS; ++c)
+                                if (c < d) atomicAdd(dst + c, w_ij * m2h * (xf[c] * s0 - acc[c / 2][c % 2]));
+                        } else {
+#pragma unroll
+                            for (int c = 0; c < DPAD; ++c)
+                                if (c < d)
+                                    unsafeAtomicAdd(&a.gacc[((size_t)i * T + m) * d + c],
+                                                    (double)(w_ij * m2h * (xf[c] * s0 - acc[c / 2][c % 2])));
+                        }
                     }
                 }
                 SIG_QSTAMP(5)
@@ -833,7 +905,10 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
                 for (int c = 0; c < DPAD; ++c) {
                     const float v = q_wave_sum63(w_ij * m2h * (xm[c] * ps0 - part[c])); // total in lane 63
-                    if (lanep == 63 && c < d) unsafeAtomicAdd(&a.gacc[((size_t)i * T + 64) * d + c], (double)v);
+                    if (lanep == 63 && c < d) {
+                        if (rowlds) atomicAdd(rowacc + 64 * RS + min(c, RS - 1) + (lanep - 63), v);
+                        else unsafeAtomicAdd(&a.gacc[((size_t)i * T + 64) * d + c], (double)v);
+                    }
                 }
             }
             SIG_QSTAMP(6)
@@ -849,14 +924,26 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                 const float v = m2h * (yf[(128 * (n >> 6) + (n & 63)) * YFS + c] * sw - sx);
                 if (c < d && v != 0.f) unsafeAtomicAdd(&a.gacc[((size_t)j * T + n) * d + c], (double)v);
             }
+            SIG_QSTAMP(9)
         }
     }
+    if (rowlds && row_ok) { // the item's row-side sums: consecutive lanes on consecutive addresses
+        int lf = lane;
+        asm volatile("" : "+v"(lf));
+        const int tot = T * d;
+        for (int e = lf; e < tot; e += 64) {
+            const int m = e / d, c = e - m * d;
+            const float v = rowacc[m * RS + c];
+            if (v != 0.f) unsafeAtomicAdd(&a.gacc[(size_t)i * tot + e], (double)v);
+        }
+    }
+    SIG_QSTAMP(11)
     } // work items
 
     SIG_QSTAMP(0)
 #ifdef SIGSVGD_PHASE_STAMPS
     if (lane == 0 && a.stamps)
-        for (int k = 0; k < 8; ++k) atomicAdd(&a.stamps[k], ph_[k]);
+        for (int k = 0; k < 12; ++k) atomicAdd(&a.stamps[k], ph_[k]);
 #endif
 }
 
@@ -933,8 +1020,8 @@ int quad_launch_variant(const GramProblem &p, QuadArgs &a, bool grad, bool sym)
 #ifdef SIGSVGD_PHASE_STAMPS
     {
         static unsigned long long *dbg = nullptr;
-        if (!dbg) (void)hipMalloc(&dbg, 8 * sizeof(unsigned long long));
-        (void)hipMemsetAsync(dbg, 0, 8 * sizeof(unsigned long long), p.stream);
+        if (!dbg) (void)hipMalloc(&dbg, 12 * sizeof(unsigned long long));
+        (void)hipMemsetAsync(dbg, 0, 12 * sizeof(unsigned long long), p.stream);
         a.stamps = dbg;
     }
 #endif
@@ -950,15 +1037,16 @@ int quad_launch_variant(const GramProblem &p, QuadArgs &a, bool grad, bool sym)
     if (e != hipSuccess) return hip_fail(e, "launch gram_quad_kernel");
 #ifdef SIGSVGD_PHASE_STAMPS
     {
-        unsigned long long hst[8];
+        unsigned long long hst[12];
         (void)hipStreamSynchronize(p.stream);
         (void)hipMemcpy(hst, a.stamps, sizeof(hst), hipMemcpyDeviceToHost);
         double tot = 0;
-        for (int k = 0; k < 8; ++k) tot += (double)hst[k];
-        static const char *nm[8] = {"staging/other", "phase 1 static kernel", "forward sweep", "reverse sweep",
-                                    "gradient pass", "seams + row sums", "row seam (+ gradient-pass prologue)", "Y staging + barriers (+ column-sum flush)"};
+        for (int k = 0; k < 12; ++k) tot += (double)hst[k];
+        static const char *nm[12] = {"staging/other", "phase 1 static kernel", "forward sweep", "reverse sweep",
+                                     "gradient pass", "seams + row sums", "row seam (+ gradient-pass prologue)", "Y staging",
+                                     "column-sum LDS adds", "closing barrier + column-side flush", "barrier before staging", "row-side flush"};
         fprintf(stderr, "[phase stamps quad] A=%d T=%d d=%d grad=%d sym=%d: ", p.A, p.T, p.d, (int)grad, (int)sym);
-        for (int k = 0; k < 8; ++k) fprintf(stderr, "%s %.1f%% | ", nm[k], 100.0 * (double)hst[k] / tot);
+        for (int k = 0; k < 12; ++k) fprintf(stderr, "%s %.1f%% | ", nm[k], 100.0 * (double)hst[k] / tot);
         fprintf(stderr, "total %.3e wave-cycles\n", tot);
     }
 #endif
