@@ -90,7 +90,7 @@ int sigsvgd_abi_version(void);
 const char *sigsvgd_last_error(void);
 
 /* Bytes of scratch the two Gram entry points need for this problem.  Forward-only launches need some too
- * (work queues / counters of the persistent grids), so always query; the size covers every value of
+ * (accumulation buffers, scratch of the persistent grids), so always query; the size covers every value of
  * SIGSVGD_FLAG_Y_IS_X / SIGSVGD_FLAG_SYM for the given shape.
  * want_grad = 0 for sigsvgd_gram_fwd, 1 for sigsvgd_gram_fwd_bwd.  Returns 0 and sets *bytes. */
 int sigsvgd_gram_workspace_bytes(int A, int B, int T, int d, int dyadic_order, int want_grad,
@@ -117,7 +117,7 @@ int sigsvgd_gram_fwd_bwd(const void *X, const void *Y, int A, int B, int T, int 
  *   grad_partial[N,T,d] (fp64)   this rank's share of d sum(grad_out*K)/dX (row- and column-side)
  * Summing the buffers over tile_offset = 0..tile_stride-1 gives exactly sigsvgd_gram_fwd_bwd's
  * outputs.  Shapes of the register-resident and quadrant kernels (dyadic_order 0, 3 <= T <= 128, d <= 16, RBF).
- * `workspace` as sized by sigsvgd_gram_workspace_bytes(N, N, T, d, 0, 1, SIGSVGD_FLAG_Y_IS_X) (work queue). */
+ * `workspace` as sized by sigsvgd_gram_workspace_bytes(N, N, T, d, 0, 1, SIGSVGD_FLAG_Y_IS_X). */
 int sigsvgd_gram_sym_partial(const void *X, int N, int T, int d, int dtype, double inv_h,
                              int static_kind, unsigned flags, int tile_offset, int tile_stride,
                              const void *grad_out, void *K_partial, double *grad_partial,

@@ -28,7 +28,7 @@
 // and shared by the NW pairs.  With Y == X each unordered pair {i<j} is solved once: the row-side
 // contraction gives d k(x_i,x_j)/d x_i, the column-side sums (travelling accumulators, one wave
 // rotation per sum and iteration) give d k(x_j,x_i)/d x_j.  Row-side gradients stay in per-lane fp64
-// registers while a workgroup works on its row tile (work queue); column-side results of the NW waves
+// registers while a workgroup works on a row tile of its item range; column-side results of the NW waves
 // are summed in fixed order through LDS and added with one fp32 atomic per element and column.
 //
 // Reference semantics: sigkernel _SigKernelGram.forward/backward [RECALLED, SURVEY.md App. A];
@@ -45,10 +45,10 @@ struct FastArgs {
     void *K;
     double *gacc; // [A][T][d] fp64 accumulation buffer (zeroed by the launcher): row-side sums
     float *cacc;  // [A][T][d] fp32 buffer for the column-side sums (zeroed by the launcher); NULL: they go to gacc
-    int io64, A, B, T, d, JC, symw;
+    int io64, A, B, T, d, symw;
     int tile_offset, tile_stride; // row tiles owned by this launch: offset + k*stride (multi-GPU sharding)
     int owned;                    // number of owned row tiles
-    int *queue;                   // [owned] next-chunk counters (zeroed by the launcher)
+    long long nitems;             // (owned row tile, column) items of the launch
     double inv_h;
 #ifdef SIGSVGD_PHASE_STAMPS
     unsigned long long *stamps; // diagnostic build only: [8] shader-clock totals per phase, summed over waves
@@ -332,17 +332,16 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(GRAD ? 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lrow = lane & RM; // the row this lane owns
     const int T = a.T, d = a.d, P = T - 1, io64 = a.io64;
-    // Work distribution: a persistent grid (one workgroup per CU) pulls column chunks from per-row-tile
-    // counters.  A workgroup STAYS on a row tile while chunks remain there, so the per-lane row-side
-    // gradient accumulators live in registers across all of them and are flushed (one fp64 atomic per
-    // element) only when the workgroup leaves the tile -- ~10x fewer reduction atomics than one flush per
-    // chunk, and chunks can be short (fine-grained balance; the 1/G launches of the sharded step stay
-    // full).  Symmetric launches enumerate only the chunks that reach the diagonal of the row tile.
+    // Work distribution: the items of a launch -- (owned row tile, column), tile-major; symmetric launches only the
+    // columns from the tile's first row on -- all cost the same (the NW waves of a workgroup meet at a barrier per
+    // column), so they are split into contiguous equal ranges, one per workgroup of a grid that fills the chip once.
+    // A range touches few row tiles: the per-lane row-side gradient accumulators live in registers across the columns of
+    // a tile and are flushed (one fp64 atomic per element) when the range leaves it; and every next column is known
+    // in advance, so its loads are in flight during the current pair (the round-1/2 work queue exposed an atomic and a
+    // load round trip per chunk: 63 % of the wave cycles at N=128, T=32 with its single-column chunks).
 #ifdef SIGSVGD_PHASE_STAMPS
     unsigned long long ph_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast_ = __builtin_amdgcn_s_memtime();
 #endif
-    __shared__ int s_item;
-    const int nJ = (a.B + a.JC - 1) / a.JC;
     int i = 0, j0 = 0, j1 = 0;
     bool row_ok = false;
     float *Gs = Gs_all + (GRAD ? wave * GS_WAVE : 0);
@@ -402,37 +401,26 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(GRAD ? 
         }
     };
 
-    // Tile search: wave 0 looks at 64 tile counters at a time (one coalesced load + ballot) for a tile that
-    // still has chunks; a full lap without a hit means the launch is drained.
-    int kq = blockIdx.x % a.owned;
-    for (int scanned = 0; scanned < a.owned;) {
-    __syncthreads();
-    if (wave == 0) {
-        int kk = kq + lane;
-        if (kk >= a.owned) kk -= a.owned;
-        bool has = false;
-        if (lane < a.owned - scanned && kk < a.owned) {
-            const int tt = kk * a.tile_stride + a.tile_offset;
-            const int cn = nJ - (SYM ? (tt * NW) / a.JC : 0);
-            has = __hip_atomic_load(&a.queue[kk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < cn;
+    // this workgroup's range of items, and the tile / column it starts in
+    const long long it0 = a.nitems * blockIdx.x / gridDim.x, it1 = a.nitems * (blockIdx.x + 1) / gridDim.x;
+    int remaining = (int)(it1 - it0);
+    int kq = 0, cstart = 0;
+    {
+        long long rem = it0;
+        for (;; ++kq) {
+            const int cn = a.B - (SYM ? (kq * a.tile_stride + a.tile_offset) * NW : 0);
+            if (rem < cn) break;
+            rem -= cn;
         }
-        const unsigned long long m = __ballot(has);
-        if (lane == 0) s_item = m ? (int)__builtin_ctzll(m) : -1;
+        cstart = (int)rem;
     }
-    __syncthreads();
-    const int hit = s_item;
-    if (hit < 0) { // none of the next 64 tiles has work
-        scanned += 64;
-        kq += 64;
-        if (kq >= a.owned) kq %= a.owned;
-        continue;
-    }
-    kq += hit;
-    if (kq >= a.owned) kq -= a.owned;
-    scanned = 0;
+    bool staged = false;
+    while (remaining > 0) {
     const int itile = kq * a.tile_stride + a.tile_offset;
-    const int cfirst = SYM ? (itile * NW) / a.JC : 0; // first chunk that touches or crosses the diagonal
-    const int cnt = nJ - cfirst;
+    const int cfirst = SYM ? itile * NW : 0; // first column that touches or crosses the diagonal
+    const int ncol = min(a.B - cfirst - cstart, remaining);
+    const int jnext_tile = SYM ? (itile + a.tile_stride) * NW : 0; // where the range goes on, on the next owned tile
+    const bool more_tiles = remaining > ncol;
     i = itile * NW + wave;
     row_ok = i < a.A;
 #pragma unroll
@@ -440,23 +428,20 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(GRAD ? 
         gacc[c] = 0.0;
         xraw[c] = (row_ok && lrow < T && c < d) ? load_any(a.X, ((size_t)i * T + lrow) * d + c, io64) : 0.0;
     }
-    bool worked = false;
-    for (;;) {
-    __syncthreads(); // s_item (and the staging buffers) are free again
-    if (tid == 0) s_item = atomicAdd(&a.queue[kq], 1);
-    __syncthreads();
-    const int cidx = s_item;
-    if (cidx >= cnt) break;
-    worked = true;
-    j0 = (cfirst + cidx) * a.JC;
-    j1 = min(a.B, j0 + a.JC);
-    stage_load(j0);
-    stage_store();
-    __syncthreads();
+    j0 = cfirst + cstart;
+    j1 = j0 + ncol;
+    if (!staged) { // the range's first column: the only exposed load round trip
+        staged = true;
+        stage_load(j0);
+        stage_store();
+        __syncthreads();
+    }
 
     for (int j = j0; j < j1; ++j) {
         const bool pair_ok = row_ok && (!SYM || j >= i);
-        if (j + 1 < j1) stage_load(j + 1); // in flight during the pair
+        const bool last = j + 1 == j1;
+        const bool more = !last || more_tiles;
+        if (more) stage_load(last ? jnext_tile : j + 1); // in flight during the pair
 
         float Dsl[RING]; // increments / sqrt(12) (the scale the difference-form stencil wants), one slot per anti-diagonal
 
@@ -724,21 +709,21 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(GRAD ? 
                     unsafeAtomicAdd(&a.gacc[(size_t)j * T * d + e], (double)s);
             }
         }
-        if (j + 1 < j1) stage_store();
+        if (more) stage_store();
 #ifndef SIG_EXPERIMENT_NO_PAIR_BARRIER
         __syncthreads();
 #endif
     }
 
-    } // chunks of this row tile
-
-    if (GRAD && worked && row_ok && lane < T) {
+    if (GRAD && row_ok && lane < T) {
 #pragma unroll
         for (int c = 0; c < DPAD; ++c)
             if (c < d) unsafeAtomicAdd(&a.gacc[((size_t)i * T + lane) * d + c], gacc[c]);
     }
-    kq = (kq + 1 == a.owned) ? 0 : kq + 1; // this tile is drained: search on from the next one
-    } // row tiles
+    remaining -= ncol;
+    ++kq;
+    cstart = 0;
+    } // row tiles of the range
 #ifdef SIGSVGD_PHASE_STAMPS
     SIG_STAMP(0)
     if (lane == 0 && a.stamps)
@@ -746,10 +731,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(GRAD ? 
 #endif
 }
 
-// gradX = row-side (fp64) + column-side (fp32) sums.  clean: also hand the accumulators and the work queue back
-// zeroed, so that the next launch on this workspace needs no memset (SIGSVGD_FLAG_WS_CLEAN).
+// gradX = row-side (fp64) + column-side (fp32) sums.  clean: also hand the accumulators back zeroed, so that the
+// next launch on this workspace needs no memset (SIGSVGD_FLAG_WS_CLEAN).
 template <typename IO>
-__global__ void finalize_grad_kernel(double *gacc, float *cacc, IO *gradX, size_t n, int *queue, int nqueue, int clean)
+__global__ void finalize_grad_kernel(double *gacc, float *cacc, IO *gradX, size_t n, int clean)
 {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx < n) {
@@ -759,7 +744,6 @@ __global__ void finalize_grad_kernel(double *gacc, float *cacc, IO *gradX, size_
             cacc[idx] = 0.f;
         }
     }
-    if (clean && idx < (size_t)nqueue) queue[idx] = 0;
 }
 
 // ---- host side ---------------------------------------------------------------------------------
@@ -773,7 +757,7 @@ bool fast_supported(int A, int B, int T, int d, int n, int kind, unsigned flags)
 }
 
 namespace {
-inline size_t queue_bytes(int A) { return ((size_t)(A + 3) / 4 + 1) * sizeof(int) + 256; } // >= one int per row tile
+inline size_t queue_bytes(int A) { return ((size_t)(A + 3) / 4 + 1) * sizeof(int) + 256; } // (the former work queue: kept so that workspace sizes do not change within ABI 7)
 }
 
 int fast_workspace_bytes(int A, int B, int T, int d, int want_grad, unsigned flags, size_t *bytes)
@@ -805,27 +789,13 @@ int launch_variant(const GramProblem &p, FastArgs &a, bool grad, bool sym)
     const int ntile = (p.A + NW - 1) / NW;
     const int owned = (ntile - a.tile_offset + a.tile_stride - 1) / a.tile_stride;
     if (owned <= 0) return SIGSVGD_OK;
-    // Workgroups of this launch for a column chunk of jc columns (symmetric launches enumerate only the
-    // chunks on or right of the diagonal of each owned row tile).
-    auto nblocks = [&](int jc) {
-        const int nJ = (p.B + jc - 1) / jc;
-        long long total = 0;
-        for (int k = 0; k < owned; ++k)
-            total += sym ? nJ - ((k * a.tile_stride + a.tile_offset) * NW) / jc : nJ;
-        return total;
-    };
-    // Column chunk: chunks are pulled from a queue, so short ones cost only their staging prologue
-    // (~1 % at 4 columns) and buy fine-grained balance; tiny problems go down to single columns.
+    // items of this launch: (owned row tile, column); symmetric launches only the columns from the tile's first row on
+    long long total = 0;
+    for (int k = 0; k < owned; ++k) total += sym ? p.B - (k * a.tile_stride + a.tile_offset) * NW : p.B;
+    if (total <= 0) return SIGSVGD_OK;
     const int ncu = cu_count();
-    int JC = 4;
-    while (JC > 1 && nblocks(JC) < ncu * 16) JC >>= 1;
-    a.JC = JC;
     a.owned = owned;
-    // the queue lives behind the fp64 accumulation buffer in the caller's workspace
-    if (!(grad && (p.flags & SIGSVGD_FLAG_WS_CLEAN) && a.cacc)) { // (clean workspace: zero already, finalize re-zeroes)
-        hipError_t qe = hipMemsetAsync(a.queue, 0, (size_t)owned * sizeof(int), p.stream);
-        if (qe != hipSuccess) return hip_fail(qe, "hipMemsetAsync(queue)");
-    }
+    a.nitems = total;
 #ifdef SIGSVGD_PHASE_STAMPS
     {
         static unsigned long long *dbg = nullptr;
@@ -834,7 +804,6 @@ int launch_variant(const GramProblem &p, FastArgs &a, bool grad, bool sym)
         a.stamps = dbg;
     }
 #endif
-    const long long total = nblocks(JC);
     const long long resident = (long long)ncu * (grad ? 1 : (NW == 4 ? (DPAD == 4 ? 3 : 2) : 1)); // workgroups the chip holds at once (LDS / VGPR bound)
     dim3 grid((unsigned)(total < resident ? total : resident), 1);
     dim3 block(NW * 64);
@@ -861,7 +830,7 @@ int launch_variant(const GramProblem &p, FastArgs &a, bool grad, bool sym)
         (void)hipMemcpy(h, a.stamps, sizeof(h), hipMemcpyDeviceToHost);
         double tot = 0;
         for (int k = 0; k < 8; ++k) tot += (double)h[k];
-        static const char *nm[8] = {"queue/staging/other", "phase 0+1 static kernel", "phase 2 forward sweep",
+        static const char *nm[8] = {"staging/other", "phase 0+1 static kernel", "phase 2 forward sweep",
                                     "phase 3 reverse sweep", "phase 4 gradient pass", "pair epilogue",
                                     "barrier after the pair", "-"};
         fprintf(stderr, "[phase stamps] A=%d T=%d d=%d grad=%d sym=%d: ", p.A, p.T, p.d, (int)grad, (int)sym);
@@ -880,8 +849,8 @@ int fast_launch(const GramProblem &p)
     FastArgs a;
     a.X = p.X; a.Y = p.Y; a.go = p.grad_out; a.K = p.K_out;
     a.io64 = p.dtype == SIGSVGD_F64; a.A = p.A; a.B = p.B; a.T = p.T; a.d = p.d;
-    a.symw = (p.flags & SIGSVGD_FLAG_SYM) ? 1 : 0; a.inv_h = p.inv_h; a.JC = 1;
-    a.tile_offset = 0; a.tile_stride = 1; a.owned = 1; a.queue = nullptr;
+    a.symw = (p.flags & SIGSVGD_FLAG_SYM) ? 1 : 0; a.inv_h = p.inv_h;
+    a.tile_offset = 0; a.tile_stride = 1; a.owned = 1; a.nitems = 0;
     a.gacc = nullptr;
     a.cacc = nullptr;
     if (a.symw && p.A != p.B) {
@@ -903,9 +872,7 @@ int fast_launch(const GramProblem &p)
                 hipError_t e = hipMemsetAsync(a.gacc, 0, nacc * (sizeof(double) + sizeof(float)), p.stream);
                 if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(gacc)");
             }
-            base += nacc * (sizeof(double) + sizeof(float));
         }
-        a.queue = reinterpret_cast<int *>(base);
     }
     int rc;
     if (!grad && p.d <= 4) // forward only: no G image, <=168 VGPRs -> 4-wave workgroups pack 3 waves per SIMD
@@ -922,14 +889,13 @@ int fast_launch(const GramProblem &p)
     if (grad) {
         const int bs = 256;
         const int clean = (p.flags & SIGSVGD_FLAG_WS_CLEAN) ? 1 : 0;
-        const size_t nfin = nacc > (size_t)a.owned ? nacc : (size_t)a.owned;
-        const unsigned gs = (unsigned)((nfin + bs - 1) / bs);
+        const unsigned gs = (unsigned)((nacc + bs - 1) / bs);
         if (p.dtype == SIGSVGD_F64)
             hipLaunchKernelGGL(finalize_grad_kernel<double>, dim3(gs), dim3(bs), 0, p.stream, a.gacc, a.cacc,
-                               static_cast<double *>(p.gradX_out), nacc, a.queue, a.owned, clean);
+                               static_cast<double *>(p.gradX_out), nacc, clean);
         else
             hipLaunchKernelGGL(finalize_grad_kernel<float>, dim3(gs), dim3(bs), 0, p.stream, a.gacc, a.cacc,
-                               static_cast<float *>(p.gradX_out), nacc, a.queue, a.owned, clean);
+                               static_cast<float *>(p.gradX_out), nacc, clean);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return hip_fail(e, "launch finalize_grad_kernel");
     }
@@ -952,15 +918,14 @@ int fast_sym_partial(const GramProblem &p, int tile_offset, int tile_stride, dou
     FastArgs a;
     a.X = p.X; a.Y = p.X; a.go = p.grad_out; a.K = p.K_out;
     a.io64 = p.dtype == SIGSVGD_F64; a.A = p.A; a.B = p.B; a.T = p.T; a.d = p.d;
-    a.symw = (p.flags & SIGSVGD_FLAG_SYM) ? 1 : 0; a.inv_h = p.inv_h; a.JC = 1;
-    a.tile_offset = tile_offset; a.tile_stride = tile_stride; a.owned = 1;
+    a.symw = (p.flags & SIGSVGD_FLAG_SYM) ? 1 : 0; a.inv_h = p.inv_h;
+    a.tile_offset = tile_offset; a.tile_stride = tile_stride; a.owned = 1; a.nitems = 0;
     a.gacc = grad_partial;
     a.cacc = nullptr; // one caller-owned fp64 buffer receives both sides
     if (!p.ws || p.ws_bytes < queue_bytes(p.A)) {
         set_error("sym_partial: workspace %zu B < required %zu B", p.ws_bytes, queue_bytes(p.A));
         return SIGSVGD_E_WORKSPACE;
     }
-    a.queue = reinterpret_cast<int *>((reinterpret_cast<uintptr_t>(p.ws) + 255) & ~(uintptr_t)255);
     if (p.d <= 4) return p.T <= 32 ? launch_variant<4, 8, 32>(p, a, true, true) : launch_variant<4, 8>(p, a, true, true);
     if (p.d <= 8) return p.T <= 32 ? launch_variant<8, 8, 32>(p, a, true, true) : launch_variant<8, 8>(p, a, true, true);
     return launch_variant<16, 4>(p, a, true, true);
