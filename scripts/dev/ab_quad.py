@@ -42,6 +42,17 @@ def child(shape):
         e1.record()
         torch.cuda.synchronize()
         print(f"  {'sym' if sym else 'ordered'} {e0.elapsed_time(e1) / 10:.3f} ms", end="")
+    for sym in (True, False):
+        for _ in range(3):
+            ops.gram_fwd(Xg, Xg, 1.0, 0, y_is_x=sym)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            ops.gram_fwd(Xg, Xg, 1.0, 0, y_is_x=sym)
+        e1.record()
+        torch.cuda.synchronize()
+        print(f"  fwd {'sym' if sym else 'ordered'} {e0.elapsed_time(e1) / 10:.3f} ms", end="")
     print(flush=True)
 
 
