@@ -337,7 +337,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(GRAD ? 
     __shared__ double yref[DPAD];
     __shared__ __align__(16) float yf[GRAD ? 128 * YFS : 1];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // (scalar: row index, row pointers and the per-wave LDS bases then live in SGPRs; as a vector value hipcc hoists the
+    //  row's element addresses out of the column loop as 64-bit VGPR pairs and spills them)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lrow = lane & RM; // the row this lane owns
     const int T = a.T, d = a.d, P = T - 1, io64 = a.io64;
     // Work distribution: the items of a launch -- (owned row tile, column), tile-major; symmetric launches only the

@@ -358,7 +358,10 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
     constexpr int RS = (DPAD == 8) ? 9 : 15; // row stride (odd); d = 15, 16 do not fit next to the rest and flush per pair
     __shared__ float rowacc_all[GRAD ? QNW * 128 * RS : 4];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // (scalar: row index, row pointers and the per-wave LDS bases then live in SGPRs; as a vector value hipcc hoists the
+    //  row's element addresses out of the column loop as 64-bit VGPR pairs and spills them)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int T = a.T, d = a.d, P = T - 1, io64 = a.io64;
     const int nrows1 = P - 64; // cell rows of band 1 = cell columns of half 1 (0 .. 63)
     const double inv_h = a.inv_h;
