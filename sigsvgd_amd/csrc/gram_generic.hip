@@ -39,20 +39,22 @@ __host__ __device__ inline size_t generic_lds_bytes(int T, int d, int n, int wan
 {
     const int dp = (d % 2 == 0) ? d + 1 : d;
     const int Tm = T - 1, TmS = Tm | 1, P = (1 << n) * Tm;
-    size_t dbl = (size_t)2 * T * dp + 2 * T + (P + 2);
+    size_t dbl = (size_t)2 * T * dp + 2 * T + (P + 2) + 64; // (+64: per-lane dump cells of the sweeps' boundary stores)
     size_t flt = (size_t)Tm * TmS;
     if (want_grad && !big) dbl += (size_t)Tm * Tm + (size_t)T * dp; // S fp64 + gradient accumulator
     if (want_grad && big) flt += (size_t)Tm * Tm;                   // S fp32 only
     return dbl * sizeof(double) + flt * sizeof(float);
 }
 
-template <typename IO>
+// NAIVE / GRAD / BIG are compile-time: tested per sweep step, each of them was a taken branch on the one wave's
+// dependent chain.
+template <typename IO, bool NAIVE, bool GRAD, bool BIG>
 __global__ __launch_bounds__(64) void gram_generic_kernel(GenericArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int lane = threadIdx.x;
     const int T = a.T, d = a.d, dp = a.dp, Tm = a.Tm, TmS = a.TmS, P = a.P, n = a.n, r = a.r;
-    const bool naive = a.naive != 0;
+    constexpr bool naive = NAIVE;
     const bool rbf = a.kind == SIGSVGD_STATIC_RBF;
 
     double *xs = reinterpret_cast<double *>(smem_raw);
@@ -60,10 +62,11 @@ __global__ __launch_bounds__(64) void gram_generic_kernel(GenericArgs a)
     double *xn = ys + (size_t)T * dp;
     double *yn = xn + T;
     double *rowbuf = yn + T;
-    const bool big = a.big != 0;
-    double *Sm = rowbuf + (P + 2);
-    double *acc = Sm + ((a.want_grad && !big) ? (size_t)Tm * Tm : 0);
-    float *Dm = reinterpret_cast<float *>(acc + ((a.want_grad && !big) ? (size_t)T * dp : 0));
+    constexpr bool big = BIG;
+    double *dump = rowbuf + (P + 2); // [64]: where the lanes that have nothing to hand over store
+    double *Sm = dump + kWave;
+    double *acc = Sm + ((GRAD && !big) ? (size_t)Tm * Tm : 0);
+    float *Dm = reinterpret_cast<float *>(acc + ((GRAD && !big) ? (size_t)T * dp : 0));
     float *Sm32 = Dm + (size_t)Tm * TmS; // big mode: S in fp32 (dyadic order 0: each entry written once)
 
     const IO *X = static_cast<const IO *>(a.X);
@@ -89,8 +92,8 @@ __global__ __launch_bounds__(64) void gram_generic_kernel(GenericArgs a)
         const IO *xi = X + (size_t)i * T * d;
         const bool empty = a.yx && j1 <= i; // chunk entirely left of the diagonal: solved from the other side
 
-        double *slab = a.want_grad ? a.partials + ((size_t)i * a.nchunks + chunk) * T * d : nullptr;
-        if (a.want_grad && big)
+        double *slab = GRAD ? a.partials + ((size_t)i * a.nchunks + chunk) * T * d : nullptr;
+        if (GRAD && big)
             for (int e = lane; e < T * d; e += kWave) slab[e] = 0.0; // accumulated in place (L2 resident)
         // ---- stage x_i (centred on its first point for the translation-invariant RBF) ----------
         __syncthreads();
@@ -99,7 +102,7 @@ __global__ __launch_bounds__(64) void gram_generic_kernel(GenericArgs a)
             double v = 0.0;
             if (c < d) v = (double)xi[t * d + c] - (rbf ? (double)xi[c] : 0.0);
             xs[e] = v;
-            if (a.want_grad && !big) acc[e] = 0.0;
+            if (GRAD && !big) acc[e] = 0.0;
         }
         __syncthreads();
         for (int t = lane; t < T; t += kWave) {
@@ -118,7 +121,7 @@ __global__ __launch_bounds__(64) void gram_generic_kernel(GenericArgs a)
                 if (c < d) v = (double)yj[t * d + c] - (rbf ? (double)xi[c] : 0.0);
                 ys[e] = v;
             }
-            if (a.want_grad && !big)
+            if (GRAD && !big)
                 for (int e = lane; e < Tm * Tm; e += kWave) Sm[e] = 0.0;
             __syncthreads();
             for (int t = lane; t < T; t += kWave) {
@@ -149,25 +152,37 @@ __global__ __launch_bounds__(64) void gram_generic_kernel(GenericArgs a)
             __syncthreads();
 
             // ---- phase 2: forward Goursat sweep ------------------------------------------------
+            // One wave, one dependent chain: a step costs what its instruction count costs (~5 cycles each), plus every
+            // load it has to wait for.  So the step is branch-free (results of lanes outside the grid are computed and
+            // dropped by selects, the K_fwd store is unconditional -- only entries of grid cells are ever read back) and
+            // the two LDS operands of step s+1 (the lane's increment, lane 0's boundary value) are fetched during step s.
             double Kval = 1.0;
             for (int kb = 0; kb < a.nbands; ++kb) {
                 const int p = kb * kWave + lane;
                 const bool rowvalid = p < P;
+                const bool first = kb == 0;
                 const float *Drow = Dm + (size_t)(min(p, P - 1) >> n) * TmS;
+                float *wp = wsk + (size_t)kb * a.nsteps * kWave + lane;
                 double cur = 1.0, upprev = 1.0;
-                for (int s = 0; s < a.nsteps; ++s) {
-                    const int q = s - lane;
+                int q = -lane;
+                float gf = Drow[0];                     // step 0 (only lane 0 is inside the grid)
+                double rb = rowbuf[1];                  // lane 0's upper neighbour on step s: rowbuf[s + 1]
+                rb = first ? 1.0 : rb;
+                for (int s = 0; s < a.nsteps; ++s, ++q) {
                     const bool active = rowvalid && q >= 0 && q < P;
+                    const float gfn = Drow[min(max(q + 1, 0), P - 1) >> n];
+                    const double rbr = rowbuf[min(s + 2, P)];
+                    const double rbn = first ? 1.0 : rbr;
                     double up_in = shfl_up_f64(cur);
-                    if (lane == 0) up_in = (kb == 0 || !active) ? 1.0 : rowbuf[q + 1];
-                    if (active) {
-                        const double g = (double)Drow[q >> n] * a.inv_r2;
-                        const double nw = stencil(cur, up_in, upprev, g, naive);
-                        if (a.want_grad) wsk[((size_t)kb * a.nsteps + s) * kWave + lane] = (float)upprev;
-                        cur = nw;
-                        upprev = up_in;
-                        if (lane == kWave - 1) rowbuf[q + 1] = nw;
-                    }
+                    up_in = (lane == 0) ? rb : up_in;
+                    const double g = (double)gf * a.inv_r2;
+                    const double nw = stencil(cur, up_in, upprev, g, naive);
+                    if (GRAD) wp[(size_t)s * kWave] = (float)upprev;
+                    *((lane == kWave - 1 && active) ? rowbuf + (q + 1) : dump + lane) = nw; // (no branch: lane-selected address)
+                    cur = active ? nw : cur;
+                    upprev = active ? up_in : upprev;
+                    gf = gfn;
+                    rb = rbn;
                 }
                 if (p == P - 1) Kval = cur;
             }
@@ -176,40 +191,57 @@ __global__ __launch_bounds__(64) void gram_generic_kernel(GenericArgs a)
                 if (a.yx && j != i) Kout[(size_t)j * a.B + i] = (IO)Kval;
             }
 
-            if (!a.want_grad) continue;
+            if (!GRAD) continue;
             __syncthreads();
 
             // ---- phase 3: reverse sweep, GG = K_fwd[p,q] * U[p+1,q+1], block-summed into S ------
+            // (same shape as the forward sweep: branch-free step, the operands of the next steps fetched ahead -- the
+            //  stored forward solution two steps ahead, it comes from L2)
             for (int kb = a.nbands - 1; kb >= 0; --kb) {
                 const int p = kb * kWave + lane;
                 const bool rowvalid = p < P;
                 const int L = min(kWave, P - kb * kWave);
                 const int arow = min(p, P - 1) >> n;
                 const float *Drow = Dm + (size_t)arow * TmS;
+                const bool lastband = kb == a.nbands - 1;
+                const bool hands_over = lane == 0 && kb > 0;
                 double cur = 1.0, dprev = 1.0, sb = 0.0;
                 const int nsp = P + L - 1;
-                for (int sp = 0; sp < nsp; ++sp) {
-                    const int q = P - 1 - (sp - (L - 1 - lane));
+                int q = P - 1 + (L - 1 - lane);
+                // K_fwd[p, q] was stored on forward step p_local + q = lane + q: one row of 64 per reverse step, descending
+                const float *wrow = wsk + (size_t)kb * a.nsteps * kWave + lane;
+                int R = P - 1 + L - 1; // row of step sp = 0
+                float gf = Drow[min(max(q, 0), P - 1) >> n];
+                double rb = rowbuf[P - 1]; // lane L-1's lower neighbour on step sp: rowbuf[P - 1 - sp]
+                rb = lastband ? 1.0 : rb;
+                float kf0 = wrow[(size_t)R * kWave], kf1 = wrow[(size_t)max(R - 1, 0) * kWave];
+                for (int sp = 0; sp < nsp; ++sp, --q, --R) {
                     const bool active = rowvalid && q >= 0 && q < P;
+                    const float gfn = Drow[min(max(q - 1, 0), P - 1) >> n];
+                    const double rbr = rowbuf[max(P - 2 - sp, 0)];
+                    const double rbn = lastband ? 1.0 : rbr;
+                    const float kf2 = wrow[(size_t)max(R - 2, 0) * kWave];
                     double down_in = shfl_down_f64(cur);
-                    if (lane == L - 1) down_in = (kb == a.nbands - 1 || !active) ? 1.0 : rowbuf[q];
-                    if (active) {
-                        const double g = (double)Drow[q >> n] * a.inv_r2;
-                        const double kf = (double)wsk[((size_t)kb * a.nsteps + lane + q) * kWave + lane];
-                        if (big) {
-                            Sm32[arow * Tm + q] = (float)(kf * dprev); // r == 1: the block is this cell
-                        } else {
-                            sb = __builtin_fma(kf, dprev, sb);
-                            if ((q & (r - 1)) == 0) {
-                                atomicAdd(&Sm[arow * Tm + (q >> n)], sb * a.inv_r2);
-                                sb = 0.0;
-                            }
+                    down_in = (lane == L - 1) ? rb : down_in;
+                    const double g = (double)gf * a.inv_r2;
+                    const double kf = (double)kf0;
+                    if (big) {
+                        if (active) Sm32[arow * Tm + q] = (float)(kf * dprev); // r == 1: the block is this cell
+                    } else {
+                        sb = active ? __builtin_fma(kf, dprev, sb) : sb;
+                        if (active && (q & (r - 1)) == 0) {
+                            atomicAdd(&Sm[arow * Tm + (q >> n)], sb * a.inv_r2);
+                            sb = 0.0;
                         }
-                        const double nw = stencil(cur, down_in, dprev, g, naive);
-                        cur = nw;
-                        dprev = down_in;
-                        if (lane == 0 && kb > 0) rowbuf[q] = nw;
                     }
+                    const double nw = stencil(cur, down_in, dprev, g, naive);
+                    *((hands_over && active) ? rowbuf + q : dump + lane) = nw;
+                    cur = active ? nw : cur;
+                    dprev = active ? down_in : dprev;
+                    gf = gfn;
+                    rb = rbn;
+                    kf0 = kf1;
+                    kf1 = kf2;
                 }
             }
             __syncthreads();
@@ -303,7 +335,7 @@ __global__ __launch_bounds__(64) void gram_generic_kernel(GenericArgs a)
             }
         } // j
 
-        if (a.want_grad && !big) {
+        if (GRAD && !big) {
             __syncthreads();
             for (int e = lane; e < T * d; e += kWave) slab[e] = acc[(e / d) * dp + (e % d)];
         }
@@ -396,6 +428,31 @@ int generic_workspace_bytes(int A, int B, int T, int d, int n, int want_grad, si
     return SIGSVGD_OK;
 }
 
+namespace {
+template <typename IO, bool NAIVE, bool GRAD, bool BIG>
+hipError_t generic_launch_one(const GenericPlan &pl, hipStream_t stream, const GenericArgs &a)
+{
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gram_generic_kernel<IO, NAIVE, GRAD, BIG>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((gram_generic_kernel<IO, NAIVE, GRAD, BIG>), dim3(pl.grid), dim3(kWave), pl.lds, stream, a);
+    return hipSuccess;
+}
+template <typename IO, bool NAIVE>
+hipError_t generic_dispatch2(bool grad, bool big, const GenericPlan &pl, hipStream_t stream, const GenericArgs &a)
+{
+    if (!grad) return generic_launch_one<IO, NAIVE, false, false>(pl, stream, a);
+    return big ? generic_launch_one<IO, NAIVE, true, true>(pl, stream, a) : generic_launch_one<IO, NAIVE, true, false>(pl, stream, a);
+}
+hipError_t generic_dispatch(bool f64, bool naive, bool grad, bool big, const GenericPlan &pl, hipStream_t stream,
+                            const GenericArgs &a)
+{
+    if (f64)
+        return naive ? generic_dispatch2<double, true>(grad, big, pl, stream, a) : generic_dispatch2<double, false>(grad, big, pl, stream, a);
+    return naive ? generic_dispatch2<float, true>(grad, big, pl, stream, a) : generic_dispatch2<float, false>(grad, big, pl, stream, a);
+}
+} // namespace
+
 int generic_launch(const GramProblem &p)
 {
     const int want_grad = p.gradX_out != nullptr;
@@ -441,18 +498,8 @@ int generic_launch(const GramProblem &p)
     a.inv_r2 = 1.0 / ((double)pl.r * (double)pl.r);
     a.total_items = pl.items; a.wsk_per_block = pl.wsk_per_block; a.big = pl.big;
 
-    hipError_t e;
-    if (p.dtype == SIGSVGD_F64) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gram_generic_kernel<double>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
-        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(generic<f64>)");
-        hipLaunchKernelGGL(gram_generic_kernel<double>, dim3(pl.grid), dim3(kWave), pl.lds, p.stream, a);
-    } else {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gram_generic_kernel<float>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
-        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(generic<f32>)");
-        hipLaunchKernelGGL(gram_generic_kernel<float>, dim3(pl.grid), dim3(kWave), pl.lds, p.stream, a);
-    }
+    hipError_t e = generic_dispatch(p.dtype == SIGSVGD_F64, a.naive != 0, want_grad != 0, pl.big != 0, pl, p.stream, a);
+    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(generic)");
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "launch gram_generic_kernel");
     if (want_grad) {
