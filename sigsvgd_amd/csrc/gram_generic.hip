@@ -177,7 +177,10 @@ __global__ __launch_bounds__(64) void gram_generic_kernel(GenericArgs a)
                     up_in = (lane == 0) ? rb : up_in;
                     const double g = (double)gf * a.inv_r2;
                     const double nw = stencil(cur, up_in, upprev, g, naive);
-                    if (GRAD) wp[(size_t)s * kWave] = (float)upprev;
+                    if (GRAD) { // (issued from inline asm: hipcc otherwise makes every step wait for the previous step's store)
+                        const float kst = (float)upprev;
+                        asm volatile("global_store_dword %0, %1, off" ::"v"(wp + (size_t)s * kWave), "v"(kst));
+                    }
                     *((lane == kWave - 1 && active) ? rowbuf + (q + 1) : dump + lane) = nw; // (no branch: lane-selected address)
                     cur = active ? nw : cur;
                     upprev = active ? up_in : upprev;
@@ -192,6 +195,7 @@ __global__ __launch_bounds__(64) void gram_generic_kernel(GenericArgs a)
             }
 
             if (!GRAD) continue;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the forward solution is in L2 before it is read back
             __syncthreads();
 
             // ---- phase 3: reverse sweep, GG = K_fwd[p,q] * U[p+1,q+1], block-summed into S ------
@@ -214,34 +218,41 @@ __global__ __launch_bounds__(64) void gram_generic_kernel(GenericArgs a)
                 float gf = Drow[min(max(q, 0), P - 1) >> n];
                 double rb = rowbuf[P - 1]; // lane L-1's lower neighbour on step sp: rowbuf[P - 1 - sp]
                 rb = lastband ? 1.0 : rb;
-                float kf0 = wrow[(size_t)R * kWave], kf1 = wrow[(size_t)max(R - 1, 0) * kWave];
-                for (int sp = 0; sp < nsp; ++sp, --q, --R) {
-                    const bool active = rowvalid && q >= 0 && q < P;
-                    const float gfn = Drow[min(max(q - 1, 0), P - 1) >> n];
-                    const double rbr = rowbuf[max(P - 2 - sp, 0)];
-                    const double rbn = lastband ? 1.0 : rbr;
-                    const float kf2 = wrow[(size_t)max(R - 2, 0) * kWave];
-                    double down_in = shfl_down_f64(cur);
-                    down_in = (lane == L - 1) ? rb : down_in;
-                    const double g = (double)gf * a.inv_r2;
-                    const double kf = (double)kf0;
-                    if (big) {
-                        if (active) Sm32[arow * Tm + q] = (float)(kf * dprev); // r == 1: the block is this cell
-                    } else {
-                        sb = active ? __builtin_fma(kf, dprev, sb) : sb;
-                        if (active && (q & (r - 1)) == 0) {
-                            atomicAdd(&Sm[arow * Tm + (q >> n)], sb * a.inv_r2);
-                            sb = 0.0;
+                // ring of the next KPF rows of the stored forward solution (an L2 round trip is ~8 steps long); the loop
+                // runs in groups of KPF steps, the steps past nsp have no lane inside the grid and change nothing
+                constexpr int KPF = 8;
+                float kfr[KPF];
+#pragma unroll
+                for (int u = 0; u < KPF; ++u) kfr[u] = wrow[(size_t)max(R - u, 0) * kWave];
+                for (int sp0 = 0; sp0 < nsp; sp0 += KPF) {
+#pragma unroll
+                    for (int u = 0; u < KPF; ++u, --q, --R) {
+                        const int sp = sp0 + u;
+                        const bool active = rowvalid && q >= 0 && q < P;
+                        const float gfn = Drow[min(max(q - 1, 0), P - 1) >> n];
+                        const double rbr = rowbuf[max(P - 2 - sp, 0)];
+                        const double rbn = lastband ? 1.0 : rbr;
+                        const double kf = (double)kfr[u];
+                        kfr[u] = wrow[(size_t)max(R - KPF, 0) * kWave];
+                        double down_in = shfl_down_f64(cur);
+                        down_in = (lane == L - 1) ? rb : down_in;
+                        const double g = (double)gf * a.inv_r2;
+                        if (big) {
+                            if (active) Sm32[arow * Tm + q] = (float)(kf * dprev); // r == 1: the block is this cell
+                        } else {
+                            sb = active ? __builtin_fma(kf, dprev, sb) : sb;
+                            if (active && (q & (r - 1)) == 0) {
+                                atomicAdd(&Sm[arow * Tm + (q >> n)], sb * a.inv_r2);
+                                sb = 0.0;
+                            }
                         }
+                        const double nw = stencil(cur, down_in, dprev, g, naive);
+                        *((hands_over && active) ? rowbuf + q : dump + lane) = nw;
+                        cur = active ? nw : cur;
+                        dprev = active ? down_in : dprev;
+                        gf = gfn;
+                        rb = rbn;
                     }
-                    const double nw = stencil(cur, down_in, dprev, g, naive);
-                    *((hands_over && active) ? rowbuf + q : dump + lane) = nw;
-                    cur = active ? nw : cur;
-                    dprev = active ? down_in : dprev;
-                    gf = gfn;
-                    rb = rbn;
-                    kf0 = kf1;
-                    kf1 = kf2;
                 }
             }
             __syncthreads();
