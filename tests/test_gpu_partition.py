@@ -1,0 +1,77 @@
+"""GPU parity at the edges of the static work partition of the register-resident kernel (gram_fast.hip): launches with
+fewer items than workgroups, one row / one column, row tiles that are not full, ranges that cross row tiles, and the
+strided row tiles of the sharded partial solve -- against the fp64 oracle, via the C ABI."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle as C
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+def _paths(A, T, d, seed, scale=0.05):
+    rng = np.random.default_rng(seed)
+    return np.cumsum(scale * rng.standard_normal((A, T, d)), axis=1).astype(np.float32)
+
+
+def _rel(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+@pytest.mark.parametrize("A,B", [(1, 1), (1, 9), (9, 1), (3, 5), (8, 300), (300, 8), (67, 263)])
+def test_ordered_launch_shapes(gpu, A, B):
+    """X != Y: items = row tiles x all columns; 263 columns x 9 tiles = 2367 items over 256 workgroups crosses tiles."""
+    from sigsvgd_amd import ops
+
+    T, d, h = 16, 3, 0.9
+    X, Y = _paths(A, T, d, 11), _paths(B, T, d, 12)
+    go = np.random.default_rng(13).standard_normal((A, B))
+    Kref, gref = C.gram_fwd_bwd(X, Y, h, 0, grad_out=go)
+    Xg, Yg = torch.as_tensor(X, device=gpu), torch.as_tensor(Y, device=gpu)
+    K, g = ops.gram_fwd_bwd(Xg, Yg, 1.0 / h, grad_out=torch.as_tensor(go, device=gpu, dtype=torch.float32))
+    Kf = ops.gram_fwd(Xg, Yg, 1.0 / h)
+    torch.cuda.synchronize()
+    assert _rel(K.cpu().numpy(), Kref) < TOL
+    assert _rel(Kf.cpu().numpy(), Kref) < TOL
+    assert _rel(g.cpu().numpy(), gref) < TOL
+
+
+@pytest.mark.parametrize("N", [1, 2, 7, 8, 9, 63, 257])
+def test_symmetric_launch_shapes(gpu, N):
+    """Y is X: items = columns from the tile's first row on; N = 257 leaves a last tile with one row."""
+    from sigsvgd_amd import ops
+
+    T, d, h = 12, 2, 1.1
+    X = _paths(N, T, d, 21)
+    Kref, gref = C.gram_fwd_bwd(X, X, h, 0)  # first-slot gradient; Y is X only says each unordered pair is solved once
+    Xg = torch.as_tensor(X, device=gpu)
+    K, g = ops.gram_fwd_bwd(Xg, Xg, 1.0 / h, y_is_x=True)
+    Kf = ops.gram_fwd(Xg, Xg, 1.0 / h, y_is_x=True)
+    torch.cuda.synchronize()
+    assert _rel(K.cpu().numpy(), Kref) < TOL
+    assert _rel(Kf.cpu().numpy(), Kref) < TOL
+    assert _rel(g.cpu().numpy(), gref) < TOL
+    assert torch.equal(K, K.T)
+
+
+@pytest.mark.parametrize("N,stride", [(20, 3), (70, 8), (9, 2), (5, 4)])
+def test_partial_shares_sum_to_full(gpu, N, stride):
+    """Strided row tiles (more ranks than tiles included): the shares add up to the symmetric solve."""
+    from sigsvgd_amd import ops
+
+    T, d, h = 20, 7, 1.0
+    X = _paths(N, T, d, 31)
+    Xg = torch.as_tensor(X, device=gpu)
+    K, g = ops.gram_fwd_bwd(Xg, Xg, 1.0 / h, y_is_x=True)
+    Ks = torch.zeros_like(K)
+    gs = torch.zeros(N, T, d, device=gpu, dtype=torch.float64)
+    for r in range(stride):
+        Kp, gp = ops.gram_sym_partial(Xg, 1.0 / h, r, stride)
+        Ks += Kp
+        gs += gp
+    torch.cuda.synchronize()
+    assert _rel(Ks.cpu().numpy(), K.double().cpu().numpy()) < 1e-6
+    assert _rel(gs.cpu().numpy(), g.double().cpu().numpy()) < 1e-5
