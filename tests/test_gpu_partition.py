@@ -75,3 +75,28 @@ def test_partial_shares_sum_to_full(gpu, N, stride):
     torch.cuda.synchronize()
     assert _rel(Ks.cpu().numpy(), K.double().cpu().numpy()) < 1e-6
     assert _rel(gs.cpu().numpy(), g.double().cpu().numpy()) < 1e-5
+
+
+def test_paths_beyond_128_points(gpu):
+    """T > 128 (dyadic order 0) is the coverage kernel's: with the gradient up to T = 136 in its compact layout (S in
+    fp32, gradient accumulated in place; the per-pair state has to fit 160 KB of LDS), forward-only beyond; longer
+    gradient launches are refused loudly."""
+    from sigsvgd_amd import ops
+
+    A, B, h, d = 5, 4, 1.2, 2
+    X, Y = _paths(A, 136, d, 41, scale=0.03), _paths(B, 136, d, 42, scale=0.03)
+    Kref, gref = C.gram_fwd_bwd(X, Y, h, 0)
+    K, g = ops.gram_fwd_bwd(torch.as_tensor(X, device=gpu), torch.as_tensor(Y, device=gpu), 1.0 / h)
+    Ksr, gsr = C.gram_fwd_bwd(X, X, h, 0)
+    Xg = torch.as_tensor(X, device=gpu)
+    Ks, gs = ops.gram_fwd_bwd(Xg, Xg, 1.0 / h, y_is_x=True)
+    torch.cuda.synchronize()
+    assert _rel(K.cpu().numpy(), Kref) < TOL and _rel(g.cpu().numpy(), gref) < TOL
+    assert _rel(Ks.cpu().numpy(), Ksr) < TOL and _rel(gs.cpu().numpy(), gsr) < TOL
+
+    X2, Y2 = _paths(3, 190, d, 43, scale=0.03), _paths(4, 190, d, 44, scale=0.03)
+    Kref2, _ = C.gram_fwd_bwd(X2, Y2, h, 0, want_grad=False)
+    K2 = ops.gram_fwd(torch.as_tensor(X2, device=gpu), torch.as_tensor(Y2, device=gpu), 1.0 / h)
+    assert _rel(K2.cpu().numpy(), Kref2) < TOL
+    with pytest.raises(RuntimeError, match="LDS"):
+        ops.gram_fwd_bwd(torch.as_tensor(X2, device=gpu), torch.as_tensor(Y2, device=gpu), 1.0 / h)
