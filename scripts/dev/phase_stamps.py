@@ -1,7 +1,7 @@
 """Diagnostic build of the library with in-kernel phase stamps (-DSIGSVGD_PHASE_STAMPS): where a wave of
 gram_fast_kernel spends its cycles.  Builds sigsvgd_amd/libsigsvgd_stamps.so (never the product library) and
 runs a few launches; the library prints the split to stderr after each launch.
-usage (on the GPU box): python scripts/dev/phase_stamps.py [N T d [sym|ordered|fwd|fwdsym]]      (build only: --build)"""
+usage (on the GPU box): python scripts/dev/phase_stamps.py [N T d [sym|ordered|fwd|fwdsym|dyadic<k>]]      (build only: --build)"""
 import os
 import subprocess
 import sys
@@ -34,7 +34,14 @@ if __name__ == "__main__":
     from sigsvgd_amd.utils.synthetic import synthetic_inputs
 
     n, t, d = (int(v) for v in sys.argv[1:4]) if len(sys.argv) >= 4 else (1024, 64, 7)
-    mode = sys.argv[4] if len(sys.argv) >= 5 else "sym"  # sym | ordered | fwd | fwdsym
+    mode = sys.argv[4] if len(sys.argv) >= 5 else "sym"  # sym | ordered | fwd | fwdsym | dyadic<k> (coverage kernel)
+    if mode.startswith("dyadic"):
+        X, _ = synthetic_inputs(n, t, d)
+        Xg = X.cuda()
+        for _ in range(3):
+            ops.gram_fwd_bwd(Xg, Xg, 1.0, int(mode[6:]), y_is_x=True)
+        torch.cuda.synchronize()
+        sys.exit(0)
     X, _ = synthetic_inputs(n, t, d)
     Xg = X.cuda()
     for _ in range(3):

@@ -16,8 +16,24 @@
 // Reference semantics: sigkernel _SigKernelGram.forward/backward [RECALLED, SURVEY.md App. A];
 // static kernel src/kernels/_traj_kernels.py:176-195.
 #include "sig_common.h"
+#ifdef SIGSVGD_PHASE_STAMPS
+#include <cstdio>
+#endif
 
 namespace sigsvgd {
+
+// Diagnostic build (-DSIGSVGD_PHASE_STAMPS, scripts/dev/phase_stamps.py N T d dyadic<n>): s_memtime per phase, summed
+// over waves and printed after the launch.  Compiled out of the product.
+#ifdef SIGSVGD_PHASE_STAMPS
+#define SIG_GSTAMP(i)                                                        \
+    {                                                                        \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();        \
+        gph_[i] += now_ - gtl_;                                              \
+        gtl_ = now_;                                                         \
+    }
+#else
+#define SIG_GSTAMP(i)
+#endif
 
 struct GenericArgs {
     const void *X, *Y, *grad_out;
@@ -33,6 +49,9 @@ struct GenericArgs {
     double inv_h, inv_r2;
     long long total_items;
     size_t wsk_per_block;
+#ifdef SIGSVGD_PHASE_STAMPS
+    unsigned long long *stamps;
+#endif
 };
 
 __host__ __device__ inline size_t generic_lds_bytes(int T, int d, int n, int want_grad, int big)
@@ -75,6 +94,9 @@ __global__ __launch_bounds__(64) void gram_generic_kernel(GenericArgs a)
     IO *Kout = static_cast<IO *>(a.K_out);
     float *wsk = a.wsk + (size_t)blockIdx.x * a.wsk_per_block;
 
+#ifdef SIGSVGD_PHASE_STAMPS
+    unsigned long long gph_[6] = {0, 0, 0, 0, 0, 0}, gtl_ = __builtin_amdgcn_s_memtime();
+#endif
     for (long long round = 0;; ++round) {
         long long item;
         if (a.next_item) { // symmetric solve: item costs vary from nothing to JC pairs -> pull from a counter
@@ -131,6 +153,7 @@ __global__ __launch_bounds__(64) void gram_generic_kernel(GenericArgs a)
             }
             __syncthreads();
 
+            SIG_GSTAMP(0)
             // ---- phase 1: static kernel rows -> increments D (fp64 arithmetic, fp32 storage) --
             for (int rb = 0; rb < Tm; rb += kWave - 1) {
                 const int p = rb + lane;
@@ -151,6 +174,7 @@ __global__ __launch_bounds__(64) void gram_generic_kernel(GenericArgs a)
             }
             __syncthreads();
 
+            SIG_GSTAMP(1)
             // ---- phase 2: forward Goursat sweep ------------------------------------------------
             // One wave, one dependent chain: a step costs what its instruction count costs (~5 cycles each), plus every
             // load it has to wait for.  So the step is branch-free (results of lanes outside the grid are computed and
@@ -194,6 +218,7 @@ __global__ __launch_bounds__(64) void gram_generic_kernel(GenericArgs a)
                 if (a.yx && j != i) Kout[(size_t)j * a.B + i] = (IO)Kval;
             }
 
+            SIG_GSTAMP(2)
             if (!GRAD) continue;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the forward solution is in L2 before it is read back
             __syncthreads();
@@ -257,6 +282,7 @@ __global__ __launch_bounds__(64) void gram_generic_kernel(GenericArgs a)
             }
             __syncthreads();
 
+            SIG_GSTAMP(3)
             // ---- phase 4: chain S -> R -> static-kernel derivative -> per-point gradient --------
             double w = 1.0;
             if (GO) {
@@ -301,6 +327,7 @@ __global__ __launch_bounds__(64) void gram_generic_kernel(GenericArgs a)
                     }
                 }
             }
+            SIG_GSTAMP(4)
             // ---- phase 4b (Y is X, j != i): the same pair seen from x_j, d k(x_j, x_i) / d x_j ---------
             if (a.yx && j != i) {
                 double wc = 1.0;
@@ -344,6 +371,7 @@ __global__ __launch_bounds__(64) void gram_generic_kernel(GenericArgs a)
                     }
                 }
             }
+            SIG_GSTAMP(5)
         } // j
 
         if (GRAD && !big) {
@@ -351,6 +379,11 @@ __global__ __launch_bounds__(64) void gram_generic_kernel(GenericArgs a)
             for (int e = lane; e < T * d; e += kWave) slab[e] = acc[(e / d) * dp + (e % d)];
         }
     }
+#ifdef SIGSVGD_PHASE_STAMPS
+    SIG_GSTAMP(0)
+    if (lane == 0 && a.stamps)
+        for (int k = 0; k < 6; ++k) atomicAdd(&a.stamps[k], gph_[k]);
+#endif
 }
 
 // gradX[i][e] = sum_chunk partials[i][chunk][e]  (fixed order => deterministic)
@@ -509,10 +542,32 @@ int generic_launch(const GramProblem &p)
     a.inv_r2 = 1.0 / ((double)pl.r * (double)pl.r);
     a.total_items = pl.items; a.wsk_per_block = pl.wsk_per_block; a.big = pl.big;
 
+#ifdef SIGSVGD_PHASE_STAMPS
+    {
+        static unsigned long long *dbg = nullptr;
+        if (!dbg) (void)hipMalloc(&dbg, 6 * sizeof(unsigned long long));
+        (void)hipMemsetAsync(dbg, 0, 6 * sizeof(unsigned long long), p.stream);
+        a.stamps = dbg;
+    }
+#endif
     hipError_t e = generic_dispatch(p.dtype == SIGSVGD_F64, a.naive != 0, want_grad != 0, pl.big != 0, pl, p.stream, a);
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(generic)");
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "launch gram_generic_kernel");
+#ifdef SIGSVGD_PHASE_STAMPS
+    {
+        unsigned long long hs[6];
+        (void)hipStreamSynchronize(p.stream);
+        (void)hipMemcpy(hs, a.stamps, sizeof(hs), hipMemcpyDeviceToHost);
+        double tot = 0;
+        for (int k = 0; k < 6; ++k) tot += (double)hs[k];
+        static const char *nm[6] = {"staging/other", "phase 1 static kernel", "forward sweep", "reverse sweep",
+                                    "phase 4 gradient", "phase 4b column side"};
+        fprintf(stderr, "[phase stamps generic] A=%d T=%d d=%d n=%d grad=%d: ", p.A, p.T, p.d, p.n, want_grad);
+        for (int k = 0; k < 6; ++k) fprintf(stderr, "%s %.1f%% | ", nm[k], 100.0 * (double)hs[k] / tot);
+        fprintf(stderr, "total %.3e wave-cycles\n", tot);
+    }
+#endif
     if (want_grad) {
         const int TD = p.T * p.d;
         const size_t tot = (size_t)p.A * TD;
