@@ -291,13 +291,21 @@ __global__ __launch_bounds__(64) void gram_generic_kernel(GenericArgs a)
             } else if (a.sym) {
                 w = 2.0;
             }
-            for (int m = lane; m < T; m += kWave) {
+            // Short paths leave most lanes of the wave without a point row: `parts` lanes (a power of two, adjacent) then
+            // share a row, each contracting a slice of the columns; their sums meet in a fixed-order butterfly.
+            const int parts = (big || T > 32) ? 1 : (T <= 4 ? 16 : (T <= 8 ? 8 : (T <= 16 ? 4 : 2)));
+            const int cslice = (T + parts - 1) / parts;
+            const int niter = parts > 1 ? 1 : (T + kWave - 1) / kWave; // (T * parts <= 64: one pass)
+            for (int it = 0; it < niter; ++it) {
+                const int m = parts > 1 ? lane / parts : lane + it * kWave;
+                const bool mvalid = m < T;
+                const int nn0 = (lane % parts) * cslice, nn1 = mvalid ? min(T, nn0 + cslice) : nn0;
                 for (int c0 = 0; c0 < d; c0 += 16) {
                     double accv[16];
 #pragma unroll
                     for (int c = 0; c < 16; ++c) accv[c] = 0.0;
                     double s0 = 0.0;
-                    for (int nn = 0; nn < T; ++nn) {
+                    for (int nn = nn0; nn < nn1; ++nn) {
                         double R = 0.0;
                         auto Sat = [&](int aa, int bb) { return big ? (double)Sm32[aa * Tm + bb] : Sm[aa * Tm + bb]; };
                         if (m >= 1 && nn >= 1) R += Sat(m - 1, nn - 1);
@@ -315,14 +323,22 @@ __global__ __launch_bounds__(64) void gram_generic_kernel(GenericArgs a)
                         for (int c = 0; c < 16; ++c)
                             if (c0 + c < d) accv[c] = __builtin_fma(rg, ys[nn * dp + c0 + c], accv[c]);
                     }
+                    for (int off = 1; off < parts; off <<= 1) { // (every lane of the wave takes part; idle ones add zeros)
+                        s0 += __shfl_xor(s0, off, kWave);
 #pragma unroll
-                    for (int c = 0; c < 16; ++c) {
-                        if (c0 + c < d) {
-                            const double val = rbf ? (-2.0 * a.inv_h) * (xs[m * dp + c0 + c] * s0 - accv[c]) : accv[c];
-                            if (big)
-                                slab[m * d + c0 + c] = __builtin_fma(w, val, slab[m * d + c0 + c]);
-                            else
-                                acc[m * dp + c0 + c] = __builtin_fma(w, val, acc[m * dp + c0 + c]);
+                        for (int c = 0; c < 16; ++c)
+                            if (c0 + c < d) accv[c] += __shfl_xor(accv[c], off, kWave);
+                    }
+                    if (mvalid && lane % parts == 0) {
+#pragma unroll
+                        for (int c = 0; c < 16; ++c) {
+                            if (c0 + c < d) {
+                                const double val = rbf ? (-2.0 * a.inv_h) * (xs[m * dp + c0 + c] * s0 - accv[c]) : accv[c];
+                                if (big)
+                                    slab[m * d + c0 + c] = __builtin_fma(w, val, slab[m * d + c0 + c]);
+                                else
+                                    acc[m * dp + c0 + c] = __builtin_fma(w, val, acc[m * dp + c0 + c]);
+                            }
                         }
                     }
                 }
