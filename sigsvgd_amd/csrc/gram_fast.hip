@@ -318,7 +318,9 @@ __device__ __forceinline__ void store_any(void *base, size_t idx, double v, int 
 // lane of the DPP shifts at the seam is row 31, which has no cells for T <= 32 and so holds the boundary value 1,
 // and a travelling column sum meets every row exactly once in 32 consecutive lanes of the 64-lane rotation.
 template <int DPAD, int NW, bool GRAD, bool SYM, bool LP, int RING = 64>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(GRAD ? 1 : (DPAD == 4 ? 3 : 2), GRAD ? 2 : (DPAD == 4 ? 3 : 2)))) void gram_fast_kernel(FastArgs a)
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
+    GRAD ? ((RING == 32 && NW == 4 && DPAD <= 8) ? 3 : 1) : (DPAD == 4 ? 3 : 2),
+    GRAD ? ((RING == 32 && NW == 4 && DPAD <= 8) ? 3 : 2) : (DPAD == 4 ? 3 : 2)))) void gram_fast_kernel(FastArgs a)
 {
     constexpr int DC = LP ? DPAD - 1 : DPAD; // channels that can be non-zero
     constexpr int NT = NW * 64;
@@ -331,11 +333,13 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(GRAD ? 
     // cycles were bank-conflict cycles).
     constexpr int YDS = DPAD + 2; // doubles per fp64 row: 80 B at DPAD=8 -> 80*l mod 256 distinct for 16 l
     constexpr int YFS = (DPAD == 4) ? 12 : DPAD + 4; // floats per fp32 row: 48 B at DPAD<=8, 80 B at 16
-    __shared__ float Gs_all[GRAD ? NW * GS_WAVE : 1];
-    __shared__ __align__(16) double yd[128 * YDS];
-    __shared__ double ynd[128];
+    // (sized by the ring: with 32 slots a 4-wave workgroup needs 47 KB instead of 84, three of them fit a CU)
+    constexpr int GSW = RING * GS_STRIDE; // floats of a wavefront's [slot][lane] image
+    __shared__ float Gs_all[GRAD ? NW * GSW : 1];
+    __shared__ __align__(16) double yd[2 * RING * YDS];
+    __shared__ double ynd[2 * RING];
     __shared__ double yref[DPAD];
-    __shared__ __align__(16) float yf[GRAD ? 128 * YFS : 1];
+    __shared__ __align__(16) float yf[GRAD ? 2 * RING * YFS : 1];
 
     const int tid = threadIdx.x, lane = tid & 63;
     // (scalar: row index, row pointers and the per-wave LDS bases then live in SGPRs; as a vector value hipcc hoists the
@@ -355,7 +359,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(GRAD ? 
 #endif
     int i = 0, j0 = 0, j1 = 0;
     bool row_ok = false;
-    float *Gs = Gs_all + (GRAD ? wave * GS_WAVE : 0);
+    float *Gs = Gs_all + (GRAD ? wave * GSW : 0);
     const double inv_h = a.inv_h;
     const float m2h = (float)(-2.0 * inv_h * 3.46410161513775459); // the G image holds G / sqrt(12)
 
@@ -587,7 +591,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(GRAD ? 
                 for (int c = 0; c < DPAD; ++c) tacc[c] = 0.f;
 
                 int yfrow = RING - lrow;                        // row (sigma + 2 - lrow) & RM == yfrow + k2
-                int gsoff = (GRAD ? wave * GS_WAVE : 0) + lane; // this wave's [slot][lane] image
+                int gsoff = (GRAD ? wave * GSW : 0) + lane; // this wave's [slot][lane] image
                 // one iteration of the phase-4 pass (below); `gcu`, `ycu`: G[l][n] and the y~_n row, fetched one
                 // iteration ahead so that the LDS latency is off the chain and one s_waitcnt serves the iteration
                 auto grad_part = [&](float Snew, bool accumulate, float gcu, const f32x2 *ycu) {
@@ -715,7 +719,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(GRAD ? 
                 const int n = (int)(((float)e + 0.5f) * inv_d), c = e - n * d; // exact for e < 2^20
                 float s = 0.f;
 #pragma unroll
-                for (int w = 0; w < NW; ++w) s += Gs_all[w * GS_WAVE + n * DPAD + c];
+                for (int w = 0; w < NW; ++w) s += Gs_all[w * GSW + n * DPAD + c];
                 // one fp32 atomic per element and row tile, into a separate fp32 buffer that the finalize kernel
                 // adds to the fp64 row-side sums; the sharded partial solve has one caller-owned fp64 buffer for both
                 if (a.cacc)
@@ -819,7 +823,7 @@ int launch_variant(const GramProblem &p, FastArgs &a, bool grad, bool sym)
         a.stamps = dbg;
     }
 #endif
-    const long long resident = (long long)ncu * (grad ? 1 : (NW == 4 ? (DPAD == 4 ? 3 : 2) : 1)); // workgroups the chip holds at once (LDS / VGPR bound)
+    const long long resident = (long long)ncu * (grad ? ((RING == 32 && NW == 4 && DPAD <= 8) ? 3 : 1) : (NW == 4 ? (DPAD == 4 ? 3 : 2) : 1)); // workgroups the chip holds at once (LDS / VGPR bound)
     dim3 grid((unsigned)(total < resident ? total : resident), 1);
     dim3 block(NW * 64);
     constexpr bool HAS_LP = DPAD <= 8; // the d == DPAD - 1 instantiations exist for the 4- and 8-channel layouts
@@ -894,10 +898,10 @@ int fast_launch(const GramProblem &p)
         rc = p.T <= 32 ? launch_variant<4, 4, 32>(p, a, false, sym) : launch_variant<4, 4>(p, a, false, sym);
     else if (!grad && p.d <= 8)
         rc = p.T <= 32 ? launch_variant<8, 4, 32>(p, a, false, sym) : launch_variant<8, 4>(p, a, false, sym);
-    else if (p.d <= 4)
-        rc = p.T <= 32 ? launch_variant<4, 8, 32>(p, a, grad, sym) : launch_variant<4, 8>(p, a, grad, sym);
-    else if (p.d <= 8) // (paths of <= 32 points: the 32-slot ring, phases 1 and 4 in 34 iterations instead of 66)
-        rc = p.T <= 32 ? launch_variant<8, 8, 32>(p, a, grad, sym) : launch_variant<8, 8>(p, a, grad, sym);
+    else if (p.d <= 4) // (paths of <= 32 points: the 32-slot ring on 4-wave workgroups, three per CU = 3 waves per SIMD)
+        rc = p.T <= 32 ? launch_variant<4, 4, 32>(p, a, grad, sym) : launch_variant<4, 8>(p, a, grad, sym);
+    else if (p.d <= 8)
+        rc = p.T <= 32 ? launch_variant<8, 4, 32>(p, a, grad, sym) : launch_variant<8, 8>(p, a, grad, sym);
     else
         rc = launch_variant<16, 4>(p, a, grad, sym); // 1 wave per SIMD: 512-VGPR budget, no spills
     if (rc) return rc;
@@ -941,8 +945,8 @@ int fast_sym_partial(const GramProblem &p, int tile_offset, int tile_stride, dou
         set_error("sym_partial: workspace %zu B < required %zu B", p.ws_bytes, queue_bytes(p.A));
         return SIGSVGD_E_WORKSPACE;
     }
-    if (p.d <= 4) return p.T <= 32 ? launch_variant<4, 8, 32>(p, a, true, true) : launch_variant<4, 8>(p, a, true, true);
-    if (p.d <= 8) return p.T <= 32 ? launch_variant<8, 8, 32>(p, a, true, true) : launch_variant<8, 8>(p, a, true, true);
+    if (p.d <= 4) return p.T <= 32 ? launch_variant<4, 4, 32>(p, a, true, true) : launch_variant<4, 8>(p, a, true, true);
+    if (p.d <= 8) return p.T <= 32 ? launch_variant<8, 4, 32>(p, a, true, true) : launch_variant<8, 8>(p, a, true, true);
     return launch_variant<16, 4>(p, a, true, true);
 }
 
