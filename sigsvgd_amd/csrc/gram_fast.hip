@@ -43,10 +43,11 @@ namespace sigsvgd {
 // A wave's priority falls as it advances through its pair (static kernel 3, forward sweep 2, reverse sweep 1, gradient
 // pass 0), so that the wave that is behind on a SIMD gets the issue slots and the waves stay in complementary phases.
 // At C4: ordered gradient launches 8.47 -> 8.12 ms, forward-only 5.51 -> 5.12 ordered and 2.76 -> 2.59 symmetric.
-// Symmetric gradient launches lose 1 % with it (their gradient pass is twice as long) and keep the default arbitration; other priority patterns and a fixed priority for the younger half of the
+// Symmetric gradient launches lose 1 % with it at two waves per SIMD (their gradient pass is twice as long) and keep the
+// default arbitration there; at three waves per SIMD (paths of <= 32 points) they gain 3-8 % and use it; other priority patterns and a fixed priority for the younger half of the
 // workgroup changed them by less than 0.5 %.
 #define SIG_PRIO(n)                                                          \
-    if (!GRAD || !SYM) __builtin_amdgcn_s_setprio(n);
+    if (!GRAD || !SYM || (RING == 32 && NW == 4)) __builtin_amdgcn_s_setprio(n);
 
 struct FastArgs {
     const void *X, *Y, *go;
