@@ -320,8 +320,8 @@ __device__ __forceinline__ void store_any(void *base, size_t idx, double v, int 
 // and a travelling column sum meets every row exactly once in 32 consecutive lanes of the 64-lane rotation.
 template <int DPAD, int NW, bool GRAD, bool SYM, bool LP, int RING = 64>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
-    GRAD ? ((RING == 32 && NW == 4 && DPAD <= 8) ? 3 : 1) : ((DPAD == 4 || RING == 32) ? 3 : 2),
-    GRAD ? ((RING == 32 && NW == 4 && DPAD <= 8) ? 3 : 2) : ((DPAD == 4 || RING == 32) ? 3 : 2)))) void gram_fast_kernel(FastArgs a)
+    GRAD ? ((RING == 32 && NW == 4 && DPAD <= 8) ? 3 : 1) : ((DPAD <= 8) ? 3 : 2),
+    GRAD ? ((RING == 32 && NW == 4 && DPAD <= 8) ? 3 : 2) : ((DPAD <= 8) ? 3 : 2)))) void gram_fast_kernel(FastArgs a)
 {
     constexpr int DC = LP ? DPAD - 1 : DPAD; // channels that can be non-zero
     constexpr int NT = NW * 64;
@@ -824,7 +824,7 @@ int launch_variant(const GramProblem &p, FastArgs &a, bool grad, bool sym)
         a.stamps = dbg;
     }
 #endif
-    const long long resident = (long long)ncu * (grad ? ((RING == 32 && NW == 4 && DPAD <= 8) ? 3 : 1) : (NW == 4 ? ((DPAD == 4 || RING == 32) ? 3 : 2) : 1)); // workgroups the chip holds at once (LDS / VGPR bound)
+    const long long resident = (long long)ncu * (grad ? ((RING == 32 && NW == 4 && DPAD <= 8) ? 3 : 1) : (NW == 4 ? ((DPAD <= 8) ? 3 : 2) : 1)); // workgroups the chip holds at once (LDS / VGPR bound)
     dim3 grid((unsigned)(total < resident ? total : resident), 1);
     dim3 block(NW * 64);
     constexpr bool HAS_LP = DPAD <= 8; // the d == DPAD - 1 instantiations exist for the 4- and 8-channel layouts
