@@ -3,7 +3,7 @@
 (BASELINE.json metric; config C4 of SURVEY.md §8) on 1..8 MI355X.
 
 One step = one pass of the hot path over the (device-resident) particle batch:
-    K = Gram(X, X), grad_k = d sum(K)/dX           HIP: gram_fast_kernel (+ finalize)
+    K = Gram(X, X), grad_k = d sum(K)/dX           HIP: gram_fast_kernel + grad_reduce_kernel (fixed-order sums)
     X <- X - lr * v,  v = -((K @ score - grad_k)/N)  HIP: svgd_phi_kernel (fp32 MFMA + fused update)
 K and grad_k are materialised in HBM every step (they are API outputs of the reference's
 `SVGD.step`); nothing is copied to the host inside the timed region.
@@ -38,8 +38,38 @@ N, T, D_CH, H, LR = 1024, 64, 7, 1.0, 1e-3
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VALU_PEAK_TF = 78.6       # vector fp64: 256 CU x 4 SIMD x 16 FMA lanes x 2 x 2.4 GHz
 PROFILES = os.path.join(ROOT, "profiles")
-PMC_TRAFFIC_CSV = os.path.join(PROFILES, "r02_pmc_hbm_traffic.csv")   # written by scripts/pmc_summary.py
-PMC_SQ_CSV = os.path.join(PROFILES, "r02_sq_counters_gram_fast.csv")
+PMC_TRAFFIC_CSV = os.path.join(PROFILES, "r03_pmc_hbm_traffic.csv")   # written by scripts/pmc_summary.py
+PMC_SQ_CSV = os.path.join(PROFILES, "r03_sq_counters_gram_fast.csv")
+
+
+class HipBackend:
+    """What the benchmark runs on: the HIP library on the MI355X of this rank, RCCL between ranks.  (The process-plumbing
+    tests under tests/ drive `main()` with a CPU/gloo stand-in of this class; nothing in this file knows about it.)"""
+
+    label = None            # a stand-in sets a text here; it is attached to the JSON line as "rehearsal"
+    shape = (N, T, D_CH)
+    dist_backend = "nccl"
+
+    def __init__(self, local_rank: int):
+        import torch
+
+        from sigsvgd_amd import _lib, ops
+
+        _lib.load()  # fail loudly if the HIP extension is missing
+        self.compute = ops
+        self.dev = torch.device("cuda", local_rank)
+        torch.cuda.set_device(self.dev)
+        self.sync = torch.cuda.synchronize
+
+    def init_process_group(self, dist, rank, world):
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        dist.init_process_group(backend=self.dist_backend, rank=rank, world_size=world, device_id=self.dev)
+
+    def sharded(self):
+        from sigsvgd_amd.distributed import ShardedSigSVGD
+
+        return ShardedSigSVGD(1.0 / H, LR)
 
 
 def algorithmic_bytes(n, t, d):
@@ -136,11 +166,7 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-rows", type=int, default=256)
     ap.add_argument("--headline-only", action="store_true",
                     help="skip the other configurations and the eager-copy figure (clean per-kernel profiles)")
-    ap.add_argument("--force-dist", action="store_true", help="use the sharded path even with one rank (rehearsal)")
-    ap.add_argument("--rehearse-cpu", action="store_true",
-                    help="TEST ONLY: run the launcher + sharded loop on CPU tensors over gloo with the oracle-backed "
-                         "doubles of tests/helpers.py at a toy size; the line it prints is marked as a rehearsal and "
-                         "is not a measurement")
+    ap.add_argument("--force-dist", action="store_true", help="use the sharded path even with one rank")
     return ap.parse_args(argv)
 
 
@@ -150,12 +176,12 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
-def launch_ranks(args) -> int:
+def launch_ranks(args, script=None) -> int:
     """`python bench.py --gpus N` outside a launcher: start the N ranks as ONE child process tree
     (`python -m torch.distributed.run`, rendezvous on 127.0.0.1) and forward their output.  This process has
     not imported torch.cuda nor made any HIP call, so nothing GPU-initialised is ever exec'ed or forked."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), script or os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
@@ -163,13 +189,13 @@ def launch_ranks(args) -> int:
     return proc.returncode
 
 
-def main(argv=None) -> int:
+def main(argv=None, backend_cls=HipBackend, script=None) -> int:
     args = parse_args(argv)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        return launch_ranks(args)
+        return launch_ranks(args, script)
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
 
@@ -177,21 +203,10 @@ def main(argv=None) -> int:
 
     from sigsvgd_amd.utils.synthetic import synthetic_inputs
 
-    rehearse = args.rehearse_cpu
-    n, t, d = (16, 6, 2) if rehearse else (N, T, D_CH)
-    if rehearse:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import helpers as compute  # oracle-backed doubles; TEST ONLY (see --rehearse-cpu)
-
-        dev = torch.device("cpu")
-    else:
-        from sigsvgd_amd import _lib
-        from sigsvgd_amd import ops as compute
-
-        _lib.load()  # fail loudly if the HIP extension is missing
-        dev = torch.device("cuda", local_rank)
-        torch.cuda.set_device(dev)
-    sync = (lambda: None) if rehearse else torch.cuda.synchronize
+    be = backend_cls(local_rank)
+    rehearse = be.label is not None
+    n, t, d = be.shape
+    compute, dev, sync = be.compute, be.dev, be.sync
     X0, score0 = synthetic_inputs(n, t, d)
 
     use_dist = world > 1 or args.force_dist or rehearse
@@ -199,19 +214,10 @@ def main(argv=None) -> int:
     if use_dist:
         import torch.distributed as dist
 
-        from sigsvgd_amd.distributed import ShardedSigSVGD, shard_rows
+        from sigsvgd_amd.distributed import shard_rows
 
-        if rehearse:
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", str(_free_port()))
-            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-            sharded = ShardedSigSVGD(1.0 / H, LR, partial_fn=compute.gram_sym_partial, phi_fn=compute.svgd_phi,
-                                     rows_fn=compute.gram_fwd_bwd)
-        else:
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29541")
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
-            sharded = ShardedSigSVGD(1.0 / H, LR)
+        be.init_process_group(dist, rank, world)
+        sharded = be.sharded()
         r0, r1 = shard_rows(n, rank, world)
         X = X0[r0:r1].to(dev).contiguous()
         score = score0[r0:r1].to(dev).contiguous()
@@ -297,7 +303,7 @@ def main(argv=None) -> int:
         roofline = {
             "bound": "hbm",
             "kernel": "sigsvgd::gram_fast_kernel<8, 8, true, true, true> (DPAD=8, 8 waves, gradient, symmetric, "
-                      "d=DPAD-1) + finalize_grad_kernel",
+                      "d=DPAD-1) + grad_reduce_kernel (fixed-order sums of the gradient partials)",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
@@ -348,7 +354,7 @@ def main(argv=None) -> int:
                 K, gk = compute.gram_fwd_bwd(Xc, Xc, 1.0 / H, dy, y_is_x=True, check_regime=False)
                 return compute.svgd_phi(K, so, gk, X=Xc, lr=LR)[1]
 
-            for _ in range(3):
+            for _ in range(5):
                 Xo = it(Xo)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -371,6 +377,19 @@ def main(argv=None) -> int:
                 torch.cuda.synchronize()
                 others[name]["ms_per_iter_hip_graph"] = (time.perf_counter() - t0) / 50 * 1e3
 
+        # C5 at its full size on ONE GPU (its home is 8 GPUs): one warm-up + two timed Gram + gradient launches
+        Xo, _ = synthetic_inputs(4096, 128, 14)
+        Xo = Xo.to(dev)
+        compute.gram_fwd_bwd(Xo, Xo, 1.0 / H, 0, y_is_x=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            compute.gram_fwd_bwd(Xo, Xo, 1.0 / H, 0, y_is_x=True)
+        torch.cuda.synchronize()
+        others["C5 full size on one GPU"] = {"N": 4096, "T": 128, "d": 14, "dyadic_order": 0,
+                                             "ms_per_gram_and_gradient": (time.perf_counter() - t0) / 2 * 1e3}
+        del Xo
+
     if rank == 0:
         out = {
             "metric": "SVGD iters/sec, sig-kernel N=1024 T=64 d=7",
@@ -383,8 +402,9 @@ def main(argv=None) -> int:
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            # arithmetic types on the path: static kernel, increments and both PDE sweeps fp64; stored D / K_fwd / G,
-            # the gradient contraction and the velocity GEMM fp32; reduction over partners fp64; fp32 I/O
+            # arithmetic types on the path: static kernel and 4-corner increments fp64; both PDE sweeps fp32 in difference
+            # form; stored D / K_fwd / G, the gradient contraction and the velocity GEMM fp32; reduction over partners
+            # fp64 in a fixed order; fp32 I/O
             "dtype": "f64 static kernel + f32 sweeps and contraction (mixed), f32 I/O",
             "data": "synthetic",
             "config": {
@@ -401,8 +421,7 @@ def main(argv=None) -> int:
             "sharded": shard_report,
         }
         if rehearse:
-            out["rehearsal"] = ("CPU tensors over gloo with oracle-backed test doubles at a toy size: exercises the "
-                                "launcher and the sharded loop only, NOT a measurement")
+            out["rehearsal"] = be.label
             out["config"]["workload"] = f"rehearsal N={n} T={t} d={d}"
         if not args.no_cpu_baseline and world == 1 and not rehearse:
             out["cpu_baseline"] = cpu_baseline(N, T, D_CH, args.cpu_rows)

@@ -34,9 +34,13 @@
  *     (no host synchronisation, graph-capturable);
  *   - return value 0 = ok, negative = error (see SIGSVGD_E_*); sigsvgd_last_error() gives text;
  *   - `dtype` selects the I/O element type of X, Y, grad_out, K_out, gradX_out:
- *     SIGSVGD_F32 or SIGSVGD_F64.  Arithmetic is always: fp64 static kernel + increments + PDE
- *     sweeps, fp32 storage of per-pair intermediates, fp32 gradient contraction, fp64 reduction
- *     over pairs (DESIGN.md "precision plan").
+ *     SIGSVGD_F32 or SIGSVGD_F64.  Arithmetic of the register-resident and quadrant kernels
+ *     (dyadic order 0, T <= 128): fp64 static kernel + 4-corner increments, fp32 PDE sweeps in
+ *     difference form, fp32 storage of per-pair intermediates, fp32 gradient contraction, fp64
+ *     reduction over pairs; the coverage kernel (dyadic refinement, longer paths, linear kernel,
+ *     naive solver) runs its sweeps in fp64 (DESIGN.md "precision plan");
+ *   - results are bit-reproducible: every reduction over pairs runs in an order fixed by the launch
+ *     geometry (no floating-point atomics), so two calls on the same inputs return the same bits.
  */
 #ifndef SIGSVGD_HIP_H
 #define SIGSVGD_HIP_H
@@ -47,7 +51,7 @@
 extern "C" {
 #endif
 
-#define SIGSVGD_ABI_VERSION 7
+#define SIGSVGD_ABI_VERSION 8
 
 /* dtype */
 #define SIGSVGD_F32 0
@@ -70,13 +74,13 @@ extern "C" {
                                      /* library solve each unordered pair once                  */
 #define SIGSVGD_FLAG_STORED_FORWARD 32u /* accepted and ignored: every kernel of this library keeps the forward solution   */
                                        /* (ABI 4-6 used it to route long paths away from a kernel that regenerated it)     */
-#define SIGSVGD_FLAG_WS_CLEAN 16u     /* the caller guarantees that the workspace is ZERO on entry (fresh, or left  */
-                                      /* by an earlier call with this flag); honoured by the register-resident       */
-                                      /* gradient launches (dyadic order 0, T <= 64), which then issue no memset and */
-                                      /* hand the workspace back zeroed (the finalisation kernel clears what the     */
-                                      /* launch used) -- two enqueues less per iteration, and a captured graph of    */
-                                      /* the iteration consists of kernel nodes only.  Other launches ignore it and  */
-                                      /* may leave the workspace dirty.                                              */
+#define SIGSVGD_FLAG_WS_CLEAN 16u     /* accepted and ignored since ABI 8: no launch needs a zeroed workspace any more */
+                                      /* (partial sums are stored, not accumulated), none issues a memset, and a        */
+                                      /* captured graph of an iteration consists of kernel nodes only                   */
+#define SIGSVGD_FLAG_FOLD_TILES 64u    /* sigsvgd_gram_sym_partial: this launch owns the row tiles tile_offset + k*tile_stride AND  */
+                                      /* their mirror images ntile-1 - (tile_offset + k*tile_stride): a tile and its mirror image  */
+                                      /* together always hold the same number of pairs of the upper triangle, so every rank of   */
+                                      /* the sharded step gets the same share (cyclic ownership alone: +5.4 % on the first rank)    */
 #define SIGSVGD_FLAG_FORCE_GENERIC 8u /* use the coverage kernel (forward solution in HBM scratch): tests */
 
 /* errors */
@@ -111,17 +115,24 @@ int sigsvgd_gram_fwd_bwd(const void *X, const void *Y, int A, int B, int T, int 
 
 /* Multi-GPU building block (particles sharded over ranks; new design, the reference has no
  * distributed code -- SURVEY.md §8e).  Solves the unordered pairs {i <= j} whose row tile
- * (8 consecutive rows i; 4 for T <= 64 with d > 8) has index tile_offset + k*tile_stride, on the
- * full gathered particle tensor X[N,T,d], and ACCUMULATES into caller-zeroed buffers:
- *   K_partial[N,N]      (dtype)  both orientations K[i,j], K[j,i] of every owned pair, 0 elsewhere
- *   grad_partial[N,T,d] (fp64)   this rank's share of d sum(grad_out*K)/dX (row- and column-side)
- * Summing the buffers over tile_offset = 0..tile_stride-1 gives exactly sigsvgd_gram_fwd_bwd's
- * outputs.  Shapes of the register-resident and quadrant kernels (dyadic_order 0, 3 <= T <= 128, d <= 16, RBF).
+ * (sigsvgd_gram_sym_tile_rows(T, d) consecutive rows i) has index tile_offset + k*tile_stride for some k >= 0
+ * -- with SIGSVGD_FLAG_FOLD_TILES also the mirror images of those tiles, see the flag -- on the full gathered
+ * particle tensor X[N,T,d]:
+ *   K_partial[N,N]      (dtype)  caller-ZEROED; receives both orientations K[i,j], K[j,i] of every owned pair
+ *   grad_partial[N,T,d] (fp64)   OVERWRITTEN with this launch's share of d sum(grad_out*K)/dX (row- and
+ *                                column-side; rows the owned pairs do not touch get 0)
+ * Summing the buffers over tile_offset = 0..tile_stride-1 gives sigsvgd_gram_fwd_bwd's outputs (K exactly, the
+ * gradient up to the fp64 rounding of the sum).  Shapes of the register-resident and quadrant kernels
+ * (dyadic_order 0, 3 <= T <= 128, d <= 16, RBF).
  * `workspace` as sized by sigsvgd_gram_workspace_bytes(N, N, T, d, 0, 1, SIGSVGD_FLAG_Y_IS_X). */
 int sigsvgd_gram_sym_partial(const void *X, int N, int T, int d, int dtype, double inv_h,
                              int static_kind, unsigned flags, int tile_offset, int tile_stride,
                              const void *grad_out, void *K_partial, double *grad_partial,
                              void *workspace, size_t workspace_bytes, void *stream);
+
+/* Rows per tile of the symmetric / partial solve for paths of T points in d channels: 4 for T <= 32 or d > 8 (T <= 64),
+ * else 8; 0 for shapes sigsvgd_gram_sym_partial does not take.  The unit of ownership of the sharded solve. */
+int sigsvgd_gram_sym_tile_rows(int T, int d);
 
 /* v_out[N,D] = -((K[N,N] @ score[N,D] - grad_k[N,D]) / N) * (mask ? mask[N,D] : 1)   (fp32)
  * If X_in and X_out are non-NULL additionally X_out = X_in - lr * v_out (optimizer=None update).

@@ -22,8 +22,9 @@ HEADERS = [os.path.join(_CSRC, "sig_common.h"), os.path.join(_PKG, "..", "includ
 F32, F64 = 0, 1
 STATIC_RBF, STATIC_LINEAR = 0, 1
 FLAG_NAIVE_SOLVER, FLAG_SYM, FLAG_Y_IS_X, FLAG_FORCE_GENERIC, FLAG_WS_CLEAN, FLAG_STORED_FORWARD = 1, 2, 4, 8, 16, 32
+FLAG_FOLD_TILES = 64
 VEC_GAUSSIAN, VEC_IMQ, VEC_UNIT = 0, 1, 2
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 EXPORTS = [
     "sigsvgd_abi_version",
@@ -32,6 +33,7 @@ EXPORTS = [
     "sigsvgd_gram_fwd",
     "sigsvgd_gram_fwd_bwd",
     "sigsvgd_gram_sym_partial",
+    "sigsvgd_gram_sym_tile_rows",
     "sigsvgd_svgd_phi",
     "sigsvgd_svgd_step",
     "sigsvgd_svgd_adam_step",
@@ -125,6 +127,8 @@ def load():
     L.sigsvgd_gram_fwd_bwd.argtypes = [vp, vp, ci, ci, ci, ci, ci, cd, ci, ci, cu, vp, vp, vp, vp, ctypes.c_size_t, vp]
     L.sigsvgd_gram_sym_partial.restype = ci
     L.sigsvgd_gram_sym_partial.argtypes = [vp, ci, ci, ci, ci, cd, ci, cu, ci, ci, vp, vp, vp, vp, ctypes.c_size_t, vp]
+    L.sigsvgd_gram_sym_tile_rows.restype = ci
+    L.sigsvgd_gram_sym_tile_rows.argtypes = [ci, ci]
     L.sigsvgd_svgd_phi.restype = ci
     L.sigsvgd_svgd_phi.argtypes = [vp, vp, vp, vp, ci, ci, vp, vp, vp, cf, vp]
     L.sigsvgd_svgd_step.restype = ci

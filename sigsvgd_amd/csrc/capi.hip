@@ -144,7 +144,7 @@ int sigsvgd_gram_workspace_bytes(int A, int B, int T, int d, int dyadic_order, i
     if (!(flags & SIGSVGD_FLAG_FORCE_GENERIC) && fast_supported(A, B, T, d, dyadic_order, SIGSVGD_STATIC_RBF, flags))
         return fast_workspace_bytes(A, B, T, d, want_grad, flags, bytes);
     if (!(flags & SIGSVGD_FLAG_FORCE_GENERIC) && quad_supported(A, B, T, d, dyadic_order, SIGSVGD_STATIC_RBF, flags))
-        return quad_workspace_bytes(A, T, d, want_grad, bytes);
+        return quad_workspace_bytes(A, B, T, d, want_grad, bytes);
     return generic_workspace_bytes(A, B, T, d, dyadic_order, want_grad, bytes);
 }
 
@@ -195,8 +195,15 @@ int sigsvgd_gram_sym_partial(const void *X, int N, int T, int d, int dtype, doub
                   K_partial, grad_partial, workspace, workspace_bytes, static_cast<hipStream_t>(stream)};
     Range range("sigsvgd_gram_sym_partial");
     if (!fast_supported(N, N, T, d, 0, static_kind, flags) && quad_supported(N, N, T, d, 0, static_kind, flags))
-        return quad_sym_partial(p, tile_offset, tile_stride, grad_partial);
-    return fast_sym_partial(p, tile_offset, tile_stride, grad_partial);
+        return quad_sym_partial(p, tile_offset, tile_stride, (flags & SIGSVGD_FLAG_FOLD_TILES) != 0, grad_partial);
+    return fast_sym_partial(p, tile_offset, tile_stride, (flags & SIGSVGD_FLAG_FOLD_TILES) != 0, grad_partial);
+}
+
+int sigsvgd_gram_sym_tile_rows(int T, int d)
+{
+    if (fast_supported(1, 1, T, d, 0, SIGSVGD_STATIC_RBF, 0)) return sym_tile_rows_fast(T, d);
+    if (quad_supported(1, 1, T, d, 0, SIGSVGD_STATIC_RBF, 0)) return 8;
+    return 0;
 }
 
 int sigsvgd_svgd_phi(const float *K, const float *score, const float *grad_k, const float *mask, int N, int D,

@@ -154,6 +154,11 @@ int obstacle_cost_launch(const float *x, int N, int Kx, int d, const float *star
         return SIGSVGD_E_BADARG;
     }
     const size_t shmem = ((size_t)(Kx + 2) * d + (size_t)Tt * d + 4) * sizeof(float);
+    if (shmem > 64 * 1024) { // (dynamic LDS beyond 64 KB would need an opt-in attribute and fail at launch, not here)
+        set_error("obstacle_cost: knots and samples need %zu B of LDS per particle (> 64 KiB): knots=%d samples=%d d=%d", shmem,
+                  Kx, Tt, d);
+        return SIGSVGD_E_UNSUPPORTED;
+    }
     hipLaunchKernelGGL(obstacle_cost_kernel, dim3(N), dim3(CT), shmem, stream, x, N, Kx, d, start, target, basis, Tt, logw,
                        mean, stdv, M, w_obst, w_len, cost, traj, grad_x);
     hipError_t e = hipGetLastError();

@@ -13,7 +13,7 @@
 //     sweeps run in fp32 in DIFFERENCE FORM (a lane carries V = K[l+1][q] - K[l][q] along its row, see phase 2:
 //     1.5e-7 on K, 1.9e-7 on the gradient against the fp64 oracle, where the plain fp32 stencil loses 1e-5);
 //     everything that is only stored or contracted (D, K_fwd, G, S = K_fwd*U, R, gradient sums per pair) is fp32,
-//     the reduction over pairs is fp64 (row side) / fp32 atomics into a separate buffer (column side).
+//     the reduction over pairs is fp64 (row side in registers, column side in grad_reduce_kernel).
 //
 // Per pair: phase 1 static kernel + increments (wrap-around skew, all lanes busy, 66 iterations);
 // phase 2 forward sweep (K_fwd into the slots); phase 3 reverse sweep (U recurrence only, S = K_fwd*U
@@ -29,7 +29,8 @@
 // contraction gives d k(x_i,x_j)/d x_i, the column-side sums (travelling accumulators, one wave
 // rotation per sum and iteration) give d k(x_j,x_i)/d x_j.  Row-side gradients stay in per-lane fp64
 // registers while a workgroup works on a row tile of its item range; column-side results of the NW waves
-// are summed in fixed order through LDS and added with one fp32 atomic per element and column.
+// are summed in fixed order through LDS.  Both leave the kernel through plain stores into per-segment /
+// per-item slabs that grad_reduce_kernel adds up in a fixed order: no atomics, bit-reproducible results.
 //
 // Reference semantics: sigkernel _SigKernelGram.forward/backward [RECALLED, SURVEY.md App. A];
 // static kernel src/kernels/_traj_kernels.py:176-195; callers src/inference/score.py:68-69.
@@ -52,11 +53,12 @@ namespace sigsvgd {
 struct FastArgs {
     const void *X, *Y, *go;
     void *K;
-    double *gacc; // [A][T][d] fp64 accumulation buffer (zeroed by the launcher): row-side sums
-    float *cacc;  // [A][T][d] fp32 buffer for the column-side sums (zeroed by the launcher); NULL: they go to gacc
+    // Gradient partial sums leave the kernel through plain stores into slabs that the reduction kernel below adds up in
+    // a FIXED order (no atomics: the result is bit-reproducible run to run, and nothing needs zeroing):
+    double *rseg; // [owned tiles + workgroups][NW][T*d] fp64: row-side sums of one (workgroup, row tile) segment
+    float *cslab; // [items][T*d] fp32: column-side sums of one (row tile, column) item (symmetric launches)
     int io64, A, B, T, d, symw;
-    int tile_offset, tile_stride; // row tiles owned by this launch: offset + k*stride (multi-GPU sharding)
-    int owned;                    // number of owned row tiles
+    TileMap tm;                   // row tiles owned by this launch, in the order of the enumeration (multi-GPU sharding)
     long long nitems;             // (owned row tile, column) items of the launch
     double inv_h;
 #ifdef SIGSVGD_PHASE_STAMPS
@@ -352,7 +354,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
     // columns from the tile's first row on -- all cost the same (the NW waves of a workgroup meet at a barrier per
     // column), so they are split into contiguous equal ranges, one per workgroup of a grid that fills the chip once.
     // A range touches few row tiles: the per-lane row-side gradient accumulators live in registers across the columns of
-    // a tile and are flushed (one fp64 atomic per element) when the range leaves it; and every next column is known
+    // a tile and are stored to the (workgroup, tile) segment's slot when the range leaves it; and every next column is known
     // in advance, so its loads are in flight during the current pair (the round-1/2 work queue exposed an atomic and a
     // load round trip per chunk: 63 % of the wave cycles at N=128, T=32 with its single-column chunks).
 #ifdef SIGSVGD_PHASE_STAMPS
@@ -420,11 +422,12 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
     // this workgroup's range of items, and the tile / column it starts in
     const long long it0 = a.nitems * blockIdx.x / gridDim.x, it1 = a.nitems * (blockIdx.x + 1) / gridDim.x;
     int remaining = (int)(it1 - it0);
+    long long item = it0; // index of the (row tile, column) item in work
     int kq = 0, cstart = 0;
     {
         long long rem = it0;
         for (;; ++kq) {
-            const int cn = a.B - (SYM ? (kq * a.tile_stride + a.tile_offset) * NW : 0);
+            const int cn = a.B - (SYM ? a.tm.tile_of(kq) * NW : 0);
             if (rem < cn) break;
             rem -= cn;
         }
@@ -432,10 +435,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
     }
     bool staged = false;
     while (remaining > 0) {
-    const int itile = kq * a.tile_stride + a.tile_offset;
+    const int itile = a.tm.tile_of(kq);
     const int cfirst = SYM ? itile * NW : 0; // first column that touches or crosses the diagonal
     const int ncol = min(a.B - cfirst - cstart, remaining);
-    const int jnext_tile = SYM ? (itile + a.tile_stride) * NW : 0; // where the range goes on, on the next owned tile
+    const int jnext_tile = SYM ? a.tm.tile_of(kq + 1) * NW : 0; // where the range goes on, on the next owned tile
     const bool more_tiles = remaining > ncol;
     i = itile * NW + wave;
     row_ok = i < a.A;
@@ -711,34 +714,32 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
 #endif
         SIG_STAMP(6)
         if (GRAD && SYM) {
-            // thread e takes element e of the column's [T][d] block, so that the lanes of a wave-instruction address
-            // consecutive dwords (lane -> address is linear: the memory-side atomic unit then merges a wave's adds into
-            // 64-B requests; with the padded [64][DPAD] indexing 7 of 8 lanes were active and every lane was counted
-            // as a request of its own: 48 B written per add in the PMC pass)
+            // thread e takes element e of the column's [T][d] block: the NW waves' sums are added in wave order and the
+            // item's partial goes to its own row of the slab with one coalesced store per element (grad_reduce_kernel
+            // adds the rows of a column in tile order).  Rounds 1-2 sent it with one atomic per element into a shared
+            // accumulator: 29.6 M memory-side atomics per C4 launch, and a result that depended on their order.
             const float inv_d = 1.0f / (float)d;
+            float *dst = a.cslab + (size_t)item * (T * d);
             for (int e = tid; e < T * d; e += NT) {
                 const int n = (int)(((float)e + 0.5f) * inv_d), c = e - n * d; // exact for e < 2^20
                 float s = 0.f;
 #pragma unroll
                 for (int w = 0; w < NW; ++w) s += Gs_all[w * GSW + n * DPAD + c];
-                // one fp32 atomic per element and row tile, into a separate fp32 buffer that the finalize kernel
-                // adds to the fp64 row-side sums; the sharded partial solve has one caller-owned fp64 buffer for both
-                if (a.cacc)
-                    unsafeAtomicAdd(&a.cacc[(size_t)j * T * d + e], s);
-                else if (s != 0.f)
-                    unsafeAtomicAdd(&a.gacc[(size_t)j * T * d + e], (double)s);
+                dst[e] = s;
             }
         }
+        ++item;
         if (more) stage_store();
 #ifndef SIG_EXPERIMENT_NO_PAIR_BARRIER
         __syncthreads();
 #endif
     }
 
-    if (GRAD && row_ok && lane < T) {
+    if (GRAD && row_ok && lane < T) { // this (workgroup, row tile) segment's own slot: segments are numbered kq + workgroup
+        double *dst = a.rseg + (((size_t)(kq + (int)blockIdx.x)) * NW + wave) * (size_t)(T * d) + lane * d;
 #pragma unroll
         for (int c = 0; c < DPAD; ++c)
-            if (c < d) unsafeAtomicAdd(&a.gacc[((size_t)i * T + lane) * d + c], gacc[c]);
+            if (c < d) dst[c] = gacc[c];
     }
     remaining -= ncol;
     ++kq;
@@ -751,19 +752,52 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
 #endif
 }
 
-// gradX = row-side (fp64) + column-side (fp32) sums.  clean: also hand the accumulators back zeroed, so that the
-// next launch on this workspace needs no memset (SIGSVGD_FLAG_WS_CLEAN).
-template <typename IO>
-__global__ void finalize_grad_kernel(double *gacc, float *cacc, IO *gradX, size_t n, int clean)
+// ---- fixed-order reduction of the gradient partials -----------------------------------------------------------------
+// One thread per output element (i, t, c).  Row side: the segments of row i's tile, one per workgroup whose item range
+// met the tile, in workgroup order.  Column side (symmetric launches): the items (tile, column i) of every owned tile
+// whose first row is <= i, in tile order.  fp64 sums; the order is a function of the launch geometry only, so two
+// launches on the same input give the same bits.
+struct GradReduceArgs {
+    const double *rseg;
+    const float *cslab;
+    void *out; // [A][T*d]: the I/O type, or fp64 for the sharded partial solve
+    int out64, A, B, TD, NW, sym, grid;
+    TileMap tm;
+    long long nitems;
+};
+__global__ __launch_bounds__(256) void grad_reduce_kernel(GradReduceArgs r)
 {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < n) {
-        gradX[idx] = (IO)(gacc[idx] + (double)cacc[idx]);
-        if (clean) {
-            gacc[idx] = 0.0;
-            cacc[idx] = 0.f;
+    if (idx >= (size_t)r.A * r.TD) return;
+    const int i = (int)(idx / r.TD), e = (int)(idx % r.TD);
+    double s = 0.0;
+    const int ti = i / r.NW, wv = i % r.NW;
+    const int kqr = r.tm.kq_of_tile(ti);
+    if (kqr >= 0) {
+        const long long S0 = r.tm.start(kqr, r.B, r.NW, r.sym);
+        const long long cn = r.sym ? r.B - ti * r.NW : r.B;
+        // workgroup w works on the items [nitems*w/grid, nitems*(w+1)/grid): the one holding item x is
+        const int wlo = (int)(((S0 + 1) * r.grid - 1) / r.nitems), whi = (int)(((S0 + cn) * r.grid - 1) / r.nitems);
+        for (int w = wlo; w <= whi; ++w) s += r.rseg[((size_t)(kqr + w) * r.NW + wv) * r.TD + e];
+    }
+    if (r.sym) { // the items (owned tile, column i) of the tiles whose first row is <= i, in the order of the enumeration
+        for (int kq = 0; kq < r.tm.owned; kq += 4) { // four independent loads in flight
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int tu = kq + u < r.tm.owned ? r.tm.tile_of(kq + u) : r.tm.ntile;
+                const bool in = tu * r.NW <= i && tu < r.tm.ntile;
+                const long long it = in ? r.tm.start(kq + u, r.B, r.NW, 1) + (i - tu * r.NW) : 0;
+                v[u] = in ? r.cslab[(size_t)it * r.TD + e] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s += (double)v[u];
         }
     }
+    if (r.out64)
+        static_cast<double *>(r.out)[idx] = s;
+    else
+        static_cast<float *>(r.out)[idx] = (float)s;
 }
 
 // ---- host side ---------------------------------------------------------------------------------
@@ -776,20 +810,8 @@ bool fast_supported(int A, int B, int T, int d, int n, int kind, unsigned flags)
     return true;
 }
 
-namespace {
-inline size_t queue_bytes(int A) { return ((size_t)(A + 3) / 4 + 1) * sizeof(int) + 256; } // (the former work queue: kept so that workspace sizes do not change within ABI 7)
-}
-
-int fast_workspace_bytes(int A, int B, int T, int d, int want_grad, unsigned flags, size_t *bytes)
-{
-    (void)B; (void)flags;
-    *bytes = (want_grad ? (size_t)A * T * d * (sizeof(double) + sizeof(float)) + 256 : 0) + queue_bytes(A);
-    return SIGSVGD_OK;
-}
-
-namespace {
-// compute units of the current device (256 on MI355X); the persistent grid is sized from it
-int cu_count()
+// compute units of the current device (256 on MI355X); the persistent grids are sized from it
+int device_cu_count()
 {
     static int n = 0;
     if (n == 0) {
@@ -803,18 +825,94 @@ int cu_count()
     return n;
 }
 
+TileMap make_tilemap(int ntile, int off, int stride, bool fold)
+{
+    TileMap t;
+    t.off = off; t.stride = stride; t.ntile = ntile;
+    auto count_upto = [&](int hi) { return hi >= off ? (hi - off) / stride + 1 : 0; }; // tiles off + k*stride <= hi
+    if (!fold) {
+        t.m0 = t.owned = count_upto(ntile - 1);
+    } else {
+        t.m0 = count_upto((ntile - 1) / 2);                        // p <= ntile-1-p
+        t.owned = t.m0 + (ntile >= 2 ? count_upto((ntile - 2) / 2) : 0); // mirror images of the p < ntile-1-p
+    }
+    return t;
+}
+
+// Geometry of a gradient launch of the register-resident / quadrant kernels: NW rows per tile, `resident` workgroups on
+// the chip; the kernels and grad_reduce_kernel derive items, ranges and segments from the same numbers.
+GradGeom grad_geometry(int A, int B, int TD, bool sym, int off, int stride, bool fold, int NW, long long resident)
+{
+    GradGeom g;
+    g.NW = NW;
+    g.tm = make_tilemap((A + NW - 1) / NW, off, stride, fold);
+    g.nitems = g.tm.start(g.tm.owned, B, NW, sym ? 1 : 0);
+    g.grid = (int)(g.nitems < resident ? g.nitems : resident);
+    g.rseg_bytes = (((size_t)(g.tm.owned + g.grid) * NW * TD * sizeof(double)) + 255) & ~(size_t)255;
+    g.cslab_bytes = sym ? (((size_t)g.nitems * TD * sizeof(float)) + 255) & ~(size_t)255 : 0;
+    return g;
+}
+
+int grad_reduce_launch(const GradGeom &g, const double *rseg, const float *cslab, void *out, int out64, int A, int B, int TD,
+                       bool sym, hipStream_t stream)
+{
+    GradReduceArgs r;
+    r.rseg = rseg; r.cslab = cslab; r.out = out; r.out64 = out64;
+    r.A = A; r.B = B; r.TD = TD; r.NW = g.NW; r.tm = g.tm;
+    r.sym = sym ? 1 : 0; r.grid = g.grid > 0 ? g.grid : 1; r.nitems = g.nitems > 0 ? g.nitems : 1;
+    const size_t nacc = (size_t)A * TD;
+    hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)((nacc + 255) / 256)), dim3(256), 0, stream, r);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "launch grad_reduce_kernel");
+    return SIGSVGD_OK;
+}
+
+namespace {
+inline int cu_count() { return device_cu_count(); }
+// geometry of a GRADIENT launch (the forward-only launches keep no partial sums): rows per tile, workgroups a CU holds
+inline int grad_nw(int T, int d) { return (d <= 8) ? (T <= 32 ? 4 : 8) : 4; }
+inline int grad_wg_per_cu(int T, int d) { return (d <= 8 && T <= 32) ? 3 : 1; }
+using FastGeom = GradGeom;
+FastGeom fast_geometry(int A, int B, int T, int d, bool sym, const TileMap &tm)
+{
+    return grad_geometry(A, B, T * d, sym, tm.off, tm.stride, tm.owned > tm.m0, grad_nw(T, d),
+                         (long long)cu_count() * grad_wg_per_cu(T, d));
+}
+FastGeom fast_geometry(int A, int B, int T, int d, bool sym)
+{
+    return grad_geometry(A, B, T * d, sym, 0, 1, false, grad_nw(T, d), (long long)cu_count() * grad_wg_per_cu(T, d));
+}
+} // namespace
+
+int sym_tile_rows_fast(int T, int d) { return grad_nw(T, d); }
+
+int fast_workspace_bytes(int A, int B, int T, int d, int want_grad, unsigned flags, size_t *bytes)
+{
+    (void)flags;
+    *bytes = 256;
+    if (want_grad) { // the larger of the ordered and the symmetric launch (the query carries no Y_IS_X promise)
+        const FastGeom o = fast_geometry(A, B, T, d, false);
+        size_t need = o.rseg_bytes;
+        if (A == B) {
+            const FastGeom y = fast_geometry(A, B, T, d, true);
+            if (y.rseg_bytes + y.cslab_bytes > need) need = y.rseg_bytes + y.cslab_bytes;
+        }
+        *bytes += need + 256;
+    }
+    return SIGSVGD_OK;
+}
+
+namespace {
 template <int DPAD, int NW, int RING = 64>
 int launch_variant(const GramProblem &p, FastArgs &a, bool grad, bool sym)
 {
-    const int ntile = (p.A + NW - 1) / NW;
-    const int owned = (ntile - a.tile_offset + a.tile_stride - 1) / a.tile_stride;
-    if (owned <= 0) return SIGSVGD_OK;
     // items of this launch: (owned row tile, column); symmetric launches only the columns from the tile's first row on
-    long long total = 0;
-    for (int k = 0; k < owned; ++k) total += sym ? p.B - (k * a.tile_stride + a.tile_offset) * NW : p.B;
+    const TileMap tm = make_tilemap((p.A + NW - 1) / NW, a.tm.off, a.tm.stride, a.tm.owned > a.tm.m0);
+    if (tm.owned <= 0) return SIGSVGD_OK;
+    const long long total = tm.start(tm.owned, p.B, NW, sym ? 1 : 0);
     if (total <= 0) return SIGSVGD_OK;
     const int ncu = cu_count();
-    a.owned = owned;
+    a.tm = tm;
     a.nitems = total;
 #ifdef SIGSVGD_PHASE_STAMPS
     {
@@ -827,6 +925,14 @@ int launch_variant(const GramProblem &p, FastArgs &a, bool grad, bool sym)
     const long long resident = (long long)ncu * (grad ? ((RING == 32 && NW == 4 && DPAD <= 8) ? 3 : 1) : (NW == 4 ? ((DPAD <= 8) ? 3 : 2) : 1)); // workgroups the chip holds at once (LDS / VGPR bound)
     dim3 grid((unsigned)(total < resident ? total : resident), 1);
     dim3 block(NW * 64);
+    if (grad) { // the reduction kernel re-derives the segments from this geometry: it must be the one the workspace was cut for
+        const FastGeom g = fast_geometry(p.A, p.B, p.T, p.d, sym, a.tm);
+        if (g.NW != NW || g.grid != (int)grid.x || g.nitems != total) {
+            set_error("fast: launch geometry mismatch (NW %d/%d grid %d/%u items %lld/%lld)", g.NW, NW, g.grid, grid.x,
+                      g.nitems, total);
+            return SIGSVGD_E_BADARG;
+        }
+    }
     constexpr bool HAS_LP = DPAD <= 8; // the d == DPAD - 1 instantiations exist for the 4- and 8-channel layouts
     const bool lp = HAS_LP && grad && p.d == DPAD - 1;
     if (!grad && sym)
@@ -860,6 +966,46 @@ int launch_variant(const GramProblem &p, FastArgs &a, bool grad, bool sym)
 #endif
     return SIGSVGD_OK;
 }
+
+int dispatch_variant(const GramProblem &p, FastArgs &a, bool grad, bool sym)
+{
+    if (!grad && p.d <= 4) // forward only: no G image, <=168 VGPRs -> 4-wave workgroups pack 3 waves per SIMD
+        return p.T <= 32 ? launch_variant<4, 4, 32>(p, a, false, sym) : launch_variant<4, 4>(p, a, false, sym);
+    if (!grad && p.d <= 8)
+        return p.T <= 32 ? launch_variant<8, 4, 32>(p, a, false, sym) : launch_variant<8, 4>(p, a, false, sym);
+    if (p.d <= 4) // (paths of <= 32 points: the 32-slot ring on 4-wave workgroups, three per CU = 3 waves per SIMD)
+        return p.T <= 32 ? launch_variant<4, 4, 32>(p, a, grad, sym) : launch_variant<4, 8>(p, a, grad, sym);
+    if (p.d <= 8)
+        return p.T <= 32 ? launch_variant<8, 4, 32>(p, a, grad, sym) : launch_variant<8, 8>(p, a, grad, sym);
+    return launch_variant<16, 4>(p, a, grad, sym); // 1 wave per SIMD: 512-VGPR budget, no spills
+}
+
+// cut the two slabs out of the caller's workspace and enqueue kernel + reduction
+int run_grad(const GramProblem &p, FastArgs &a, bool sym, void *out, int out64)
+{
+    const FastGeom g = fast_geometry(p.A, p.B, p.T, p.d, sym, a.tm);
+    const size_t need = g.rseg_bytes + g.cslab_bytes + 256;
+    if (!p.ws || p.ws_bytes < need) {
+        set_error("fast: workspace %zu B < required %zu B", p.ws_bytes, need);
+        return SIGSVGD_E_WORKSPACE;
+    }
+    unsigned char *base = reinterpret_cast<unsigned char *>((reinterpret_cast<uintptr_t>(p.ws) + 255) & ~(uintptr_t)255);
+    a.rseg = reinterpret_cast<double *>(base);
+    a.cslab = sym ? reinterpret_cast<float *>(base + g.rseg_bytes) : nullptr;
+    int rc = dispatch_variant(p, a, true, sym);
+    if (rc) return rc;
+    return grad_reduce_launch(g, a.rseg, a.cslab, out, out64, p.A, p.B, p.T * p.d, sym, p.stream);
+}
+
+void fill_args(const GramProblem &p, FastArgs &a)
+{
+    a.X = p.X; a.Y = p.Y; a.go = p.grad_out; a.K = p.K_out;
+    a.io64 = p.dtype == SIGSVGD_F64; a.A = p.A; a.B = p.B; a.T = p.T; a.d = p.d;
+    a.symw = (p.flags & SIGSVGD_FLAG_SYM) ? 1 : 0; a.inv_h = p.inv_h;
+    a.tm = make_tilemap(1, 0, 1, false); a.nitems = 0; // (off / stride / fold are what launch_variant reads: a full launch)
+    a.rseg = nullptr;
+    a.cslab = nullptr;
+}
 } // namespace
 
 int fast_launch(const GramProblem &p)
@@ -867,65 +1013,19 @@ int fast_launch(const GramProblem &p)
     const bool grad = p.gradX_out != nullptr;
     const bool sym = (p.flags & SIGSVGD_FLAG_Y_IS_X) && p.A == p.B; // Y is X: each unordered pair once, K mirrored
     FastArgs a;
-    a.X = p.X; a.Y = p.Y; a.go = p.grad_out; a.K = p.K_out;
-    a.io64 = p.dtype == SIGSVGD_F64; a.A = p.A; a.B = p.B; a.T = p.T; a.d = p.d;
-    a.symw = (p.flags & SIGSVGD_FLAG_SYM) ? 1 : 0; a.inv_h = p.inv_h;
-    a.tile_offset = 0; a.tile_stride = 1; a.owned = 1; a.nitems = 0;
-    a.gacc = nullptr;
-    a.cacc = nullptr;
+    fill_args(p, a);
     if (a.symw && p.A != p.B) {
         set_error("sym backward needs A == B");
         return SIGSVGD_E_BADARG;
     }
-    const size_t nacc = (size_t)p.A * p.T * p.d;
-    {
-        const size_t need = (grad ? nacc * (sizeof(double) + sizeof(float)) + 256 : 0) + queue_bytes(p.A);
-        if (!p.ws || p.ws_bytes < need) {
-            set_error("fast: workspace %zu B < required %zu B", p.ws_bytes, need);
-            return SIGSVGD_E_WORKSPACE;
-        }
-        unsigned char *base = reinterpret_cast<unsigned char *>((reinterpret_cast<uintptr_t>(p.ws) + 255) & ~(uintptr_t)255);
-        if (grad) {
-            a.gacc = reinterpret_cast<double *>(base);
-            a.cacc = reinterpret_cast<float *>(base + nacc * sizeof(double));
-            if (!(p.flags & SIGSVGD_FLAG_WS_CLEAN)) {
-                hipError_t e = hipMemsetAsync(a.gacc, 0, nacc * (sizeof(double) + sizeof(float)), p.stream);
-                if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(gacc)");
-            }
-        }
-    }
-    int rc;
-    if (!grad && p.d <= 4) // forward only: no G image, <=168 VGPRs -> 4-wave workgroups pack 3 waves per SIMD
-        rc = p.T <= 32 ? launch_variant<4, 4, 32>(p, a, false, sym) : launch_variant<4, 4>(p, a, false, sym);
-    else if (!grad && p.d <= 8)
-        rc = p.T <= 32 ? launch_variant<8, 4, 32>(p, a, false, sym) : launch_variant<8, 4>(p, a, false, sym);
-    else if (p.d <= 4) // (paths of <= 32 points: the 32-slot ring on 4-wave workgroups, three per CU = 3 waves per SIMD)
-        rc = p.T <= 32 ? launch_variant<4, 4, 32>(p, a, grad, sym) : launch_variant<4, 8>(p, a, grad, sym);
-    else if (p.d <= 8)
-        rc = p.T <= 32 ? launch_variant<8, 4, 32>(p, a, grad, sym) : launch_variant<8, 8>(p, a, grad, sym);
-    else
-        rc = launch_variant<16, 4>(p, a, grad, sym); // 1 wave per SIMD: 512-VGPR budget, no spills
-    if (rc) return rc;
-    if (grad) {
-        const int bs = 256;
-        const int clean = (p.flags & SIGSVGD_FLAG_WS_CLEAN) ? 1 : 0;
-        const unsigned gs = (unsigned)((nacc + bs - 1) / bs);
-        if (p.dtype == SIGSVGD_F64)
-            hipLaunchKernelGGL(finalize_grad_kernel<double>, dim3(gs), dim3(bs), 0, p.stream, a.gacc, a.cacc,
-                               static_cast<double *>(p.gradX_out), nacc, clean);
-        else
-            hipLaunchKernelGGL(finalize_grad_kernel<float>, dim3(gs), dim3(bs), 0, p.stream, a.gacc, a.cacc,
-                               static_cast<float *>(p.gradX_out), nacc, clean);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return hip_fail(e, "launch finalize_grad_kernel");
-    }
-    return SIGSVGD_OK;
+    if (!grad) return dispatch_variant(p, a, false, sym);
+    return run_grad(p, a, sym, p.gradX_out, p.dtype == SIGSVGD_F64);
 }
 
-// Symmetric partial solve for particle sharding: this launch owns the row tiles
-// tile_offset + k*tile_stride of the upper triangle of Gram(X, X) and ACCUMULATES into caller-zeroed
-// buffers: K_partial[N,N] (both orientations of every owned pair) and grad_partial[N,T,d] (fp64).
-int fast_sym_partial(const GramProblem &p, int tile_offset, int tile_stride, double *grad_partial)
+// Symmetric partial solve for particle sharding: this launch owns the row tiles tile_offset + k*tile_stride of the upper
+// triangle of Gram(X, X).  K_partial[N,N] (caller-zeroed) receives both orientations of every owned pair;
+// grad_partial[N,T,d] (fp64) is OVERWRITTEN with this launch's share of the gradient (rows it does not touch get 0).
+int fast_sym_partial(const GramProblem &p, int tile_offset, int tile_stride, bool fold, double *grad_partial)
 {
     if (!fast_supported(p.A, p.B, p.T, p.d, p.n, p.kind, p.flags) || p.A != p.B) {
         set_error("sym_partial: shape/kernel outside the register-resident path (need n=0, 3<=T<=64, d<=16, RBF)");
@@ -936,19 +1036,10 @@ int fast_sym_partial(const GramProblem &p, int tile_offset, int tile_stride, dou
         return SIGSVGD_E_BADARG;
     }
     FastArgs a;
-    a.X = p.X; a.Y = p.X; a.go = p.grad_out; a.K = p.K_out;
-    a.io64 = p.dtype == SIGSVGD_F64; a.A = p.A; a.B = p.B; a.T = p.T; a.d = p.d;
-    a.symw = (p.flags & SIGSVGD_FLAG_SYM) ? 1 : 0; a.inv_h = p.inv_h;
-    a.tile_offset = tile_offset; a.tile_stride = tile_stride; a.owned = 1; a.nitems = 0;
-    a.gacc = grad_partial;
-    a.cacc = nullptr; // one caller-owned fp64 buffer receives both sides
-    if (!p.ws || p.ws_bytes < queue_bytes(p.A)) {
-        set_error("sym_partial: workspace %zu B < required %zu B", p.ws_bytes, queue_bytes(p.A));
-        return SIGSVGD_E_WORKSPACE;
-    }
-    if (p.d <= 4) return p.T <= 32 ? launch_variant<4, 4, 32>(p, a, true, true) : launch_variant<4, 8>(p, a, true, true);
-    if (p.d <= 8) return p.T <= 32 ? launch_variant<8, 4, 32>(p, a, true, true) : launch_variant<8, 8>(p, a, true, true);
-    return launch_variant<16, 4>(p, a, true, true);
+    fill_args(p, a);
+    a.Y = p.X;
+    a.tm = make_tilemap((p.A + grad_nw(p.T, p.d) - 1) / grad_nw(p.T, p.d), tile_offset, tile_stride, fold);
+    return run_grad(p, a, true, grad_partial, 1);
 }
 
 } // namespace sigsvgd

@@ -8,7 +8,7 @@
 //
 // With Y == X and enough pairs to fill the chip (>= 4096) each unordered pair is solved once: K is mirrored and
 // the pair's gradient with respect to x_j comes from a second contraction of the same coarse scatter, added
-// through an fp64 accumulation buffer; work items are then pulled from a counter.
+// in fixed order by the reduction kernel from a per-pair slab; work items are then pulled from a counter.
 //
 // This is the coverage kernel (reference call sites use T=3..30 with n=2..6); the
 // headline shapes (n=0, T<=64) take the register-resident kernel in gram_fast.hip.
@@ -39,7 +39,8 @@ struct GenericArgs {
     const void *X, *Y, *grad_out;
     void *K_out;
     double *partials; // [A][nchunks][T*d]
-    double *colacc;   // [B][T*d] column-side gradients of the symmetric solve (yx), zeroed by the launcher
+    double *colslab;  // [A][B][T*d] column-side gradients of the symmetric solve (yx): pair (i, j > i) writes its own block,
+                      // reduce_partials_kernel adds the blocks of a column in row order (no atomics: reproducible bits)
     float *wsk;       // [grid][nbands*nsteps*64]
     int yx;           // Y is X: solve the pairs j >= i only, mirror K, add d k(x_j, x_i)/d x_j through colacc
     unsigned long long *next_item; // work counter (zeroed by the launcher): items are pulled, not assigned, because
@@ -381,7 +382,7 @@ __global__ __launch_bounds__(64) void gram_generic_kernel(GenericArgs a)
                         for (int c = 0; c < 16; ++c) {
                             if (c0 + c < d) {
                                 const double val = rbf ? (-2.0 * a.inv_h) * (ys[nn * dp + c0 + c] * s0 - accv[c]) : accv[c];
-                                unsafeAtomicAdd(&a.colacc[((size_t)j * T + nn) * d + c0 + c], wc * val);
+                                a.colslab[(((size_t)i * a.B + j) * T + nn) * d + c0 + c] = wc * val;
                             }
                         }
                     }
@@ -402,20 +403,31 @@ __global__ __launch_bounds__(64) void gram_generic_kernel(GenericArgs a)
 #endif
 }
 
-// gradX[i][e] = sum_chunk partials[i][chunk][e]  (fixed order => deterministic)
+// gradX[i][e] = sum_chunk partials[i][chunk][e] + sum_{i' < i} colslab[i'][i][e]  (fixed order => deterministic)
 template <typename IO>
-__global__ void reduce_partials_kernel(const double *partials, const double *colacc, IO *gradX, int A, int nchunks,
+__global__ void reduce_partials_kernel(const double *partials, const double *colslab, IO *gradX, int A, int nchunks,
                                        int TD)
 {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)A * TD) return;
     const size_t i = idx / TD, e = idx % TD;
-    double s = colacc ? colacc[idx] : 0.0;
+    double s = 0.0;
     for (int c = 0; c < nchunks; ++c) s += partials[(i * nchunks + c) * TD + e];
+    if (colslab)
+        for (size_t r = 0; r < i; ++r) s += colslab[(r * A + i) * TD + e];
     gradX[idx] = (IO)s;
 }
 
 namespace {
+// Y is X: each unordered pair once -- when there are enough pairs to fill the chip (below that the launch is latency-bound
+// and the second contraction pass of the symmetric solve only lengthens the critical path) and the per-pair slab of the
+// column-side gradients stays below 1 GiB (beyond that: ordered pairs, twice the solves, no slab)
+bool generic_solves_unordered(int A, int B, int T, int d, int want_grad, unsigned flags)
+{
+    if (!(flags & SIGSVGD_FLAG_Y_IS_X) || A != B || (long long)A * B < 4096) return false;
+    if (want_grad && (size_t)A * B * T * d * sizeof(double) > ((size_t)1 << 30)) return false;
+    return true;
+}
 struct GenericPlan {
     int dp, Tm, TmS, r, P, nbands, nsteps, JC, nchunks, grid, big;
     long long items;
@@ -457,11 +469,11 @@ int make_plan(int A, int B, int T, int d, int n, int want_grad, GenericPlan &pl,
     pl.nchunks = (B + JC - 1) / JC;
     pl.items = (long long)A * pl.nchunks;
     const int per_cu = (int)((160 * 1024) / (pl.lds ? pl.lds : 1));
-    int grid = 256 * (per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu));
+    int grid = device_cu_count() * (per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu));
     if ((long long)grid > pl.items) grid = (int)pl.items;
     pl.grid = grid;
     pl.partial_bytes = want_grad ? (size_t)A * pl.nchunks * T * d * sizeof(double) : 0;
-    pl.col_bytes = want_grad ? (((size_t)B * T * d * sizeof(double) + 255) & ~(size_t)255) : 0; // symmetric solve only
+    pl.col_bytes = (want_grad && yx) ? (((size_t)A * B * T * d * sizeof(double) + 255) & ~(size_t)255) : 0; // symmetric solve only
     pl.wsk_per_block = want_grad ? (size_t)pl.nbands * pl.nsteps * kWave : 0;
     pl.wsk_bytes = pl.wsk_per_block * sizeof(float) * grid;
     return SIGSVGD_OK;
@@ -480,7 +492,7 @@ int generic_workspace_bytes(int A, int B, int T, int d, int n, int want_grad, si
     int rc = make_plan(A, B, T, d, n, want_grad, pl, false);
     if (rc) return rc;
     *bytes = plan_bytes(pl);
-    if (A == B) {
+    if (generic_solves_unordered(A, B, T, d, want_grad, SIGSVGD_FLAG_Y_IS_X)) {
         rc = make_plan(A, B, T, d, n, want_grad, pl, true);
         if (rc) return rc;
         if (plan_bytes(pl) > *bytes) *bytes = plan_bytes(pl);
@@ -516,9 +528,7 @@ hipError_t generic_dispatch(bool f64, bool naive, bool grad, bool big, const Gen
 int generic_launch(const GramProblem &p)
 {
     const int want_grad = p.gradX_out != nullptr;
-    // Y is X: each unordered pair once -- when there are enough pairs to fill the chip; below that the launch is
-    // latency-bound and the second contraction pass of the symmetric solve only lengthens the critical path
-    const bool yx = (p.flags & SIGSVGD_FLAG_Y_IS_X) && p.A == p.B && (long long)p.A * p.B >= 4096;
+    const bool yx = generic_solves_unordered(p.A, p.B, p.T, p.d, want_grad, p.flags);
     GenericPlan pl;
     int rc = make_plan(p.A, p.B, p.T, p.d, p.n, want_grad, pl, yx);
     if (rc) return rc;
@@ -543,13 +553,9 @@ int generic_launch(const GramProblem &p)
     }
     a.partials = want_grad ? reinterpret_cast<double *>(base + 256) : nullptr;
     a.yx = yx ? 1 : 0;
-    a.colacc = nullptr;
+    a.colslab = nullptr;
     unsigned char *after = want_grad ? reinterpret_cast<unsigned char *>(a.partials) + pl.partial_bytes : nullptr;
-    if (want_grad && yx) {
-        a.colacc = reinterpret_cast<double *>(after);
-        hipError_t me = hipMemsetAsync(a.colacc, 0, (size_t)p.B * p.T * p.d * sizeof(double), p.stream);
-        if (me != hipSuccess) return hip_fail(me, "hipMemsetAsync(colacc)");
-    }
+    if (want_grad && yx) a.colslab = reinterpret_cast<double *>(after);
     a.wsk = want_grad ? reinterpret_cast<float *>(after + pl.col_bytes) : nullptr;
     a.A = p.A; a.B = p.B; a.T = p.T; a.d = p.d; a.dp = pl.dp; a.n = p.n; a.r = pl.r; a.P = pl.P;
     a.Tm = pl.Tm; a.TmS = pl.TmS; a.nbands = pl.nbands; a.nsteps = pl.nsteps; a.JC = pl.JC;
@@ -591,11 +597,11 @@ int generic_launch(const GramProblem &p)
         const unsigned gs = (unsigned)((tot + bs - 1) / bs);
         if (p.dtype == SIGSVGD_F64)
             hipLaunchKernelGGL(reduce_partials_kernel<double>, dim3(gs), dim3(bs), 0, p.stream, a.partials,
-                               static_cast<const double *>(a.colacc), static_cast<double *>(p.gradX_out), p.A,
+                               static_cast<const double *>(a.colslab), static_cast<double *>(p.gradX_out), p.A,
                                pl.nchunks, TD);
         else
             hipLaunchKernelGGL(reduce_partials_kernel<float>, dim3(gs), dim3(bs), 0, p.stream, a.partials,
-                               static_cast<const double *>(a.colacc), static_cast<float *>(p.gradX_out), p.A,
+                               static_cast<const double *>(a.colslab), static_cast<float *>(p.gradX_out), p.A,
                                pl.nchunks, TD);
         e = hipGetLastError();
         if (e != hipSuccess) return hip_fail(e, "launch reduce_partials_kernel");

@@ -42,10 +42,16 @@ namespace sigsvgd {
 struct QuadArgs {
     const void *X, *Y, *go;
     void *K;
-    double *gacc; // [A][T][d] fp64, zeroed by the launcher (or the caller's accumulating buffer: partial solve)
-    int io64, A, B, T, d, JC, symw;
-    int tile_offset, tile_stride; // row tiles tile_offset + k * tile_stride are solved (sharded partial solve)
-    int nblocks;                  // work items (row tile x column chunk) of the launch; the grid strides over them
+    // gradient partial sums leave the kernel through plain stores, added up in a fixed order by grad_reduce_kernel
+    // (gram_fast.hip): no atomics anywhere, bit-reproducible results
+    double *rseg; // [owned tiles + workgroups][8][T*d]: row-side sums of one (workgroup, row tile) segment
+    float *cslab; // [items][T*d]: column-side sums of one (row tile, column) item (symmetric launches)
+    float *crec;  // [gridDim.x][8 waves][QREC]: the column-side sums of each wavefront's pair, joined after the pair's barrier
+    float *rowg;  // [gridDim.x][8 waves][128 * 16]: row-side accumulator of a segment when it does not fit LDS (d = 15, 16)
+    int io64, A, B, T, d, symw;
+    TileMap tm;                   // row tiles owned by this launch, in the order of the enumeration (sharded partial solve)
+    long long nitems;             // (owned row tile, column) items of the launch, tile-major; symmetric launches only the
+                                  // columns from the tile's first row on; each workgroup takes one contiguous range
     float *dcache;                // [gridDim.x][8 waves][3 quadrants][64 slots][64 lanes] fp32: increments kept between
                                   // the forward-only and the full pass over a quadrant (gradient launches; may be NULL)
     double inv_h;
@@ -70,6 +76,9 @@ namespace {
 #define SIGQ_NW 8
 #endif
 constexpr int QNW = SIGQ_NW; // wavefronts (rows i) per workgroup
+// floats of a wavefront's column-side records of one pair: 4 quadrant passes + 2 halves of point row 64, each
+// [DPAD + 1 values][64 lanes], + 4 seam-column records of DPAD + 1 values (sized for DPAD = 16)
+constexpr int QREC = 6656;
 using qf32x2 = __attribute__((ext_vector_type(2))) float;
 
 __device__ __forceinline__ double q_ldany(const void *b, size_t i, int io64)
@@ -333,11 +342,13 @@ __device__ __forceinline__ void quad_rev_all(float &cur, float &dnA, float &dnB,
 }
 } // namespace
 
-template <int DPAD, bool GRAD, bool SYM>
+// ROWG: the row-side sums of a segment do not fit LDS next to the rest (d = 15, 16) and live in a per-wavefront global
+// accumulator instead (a separate instantiation: its code costs the common one 40 spilled registers)
+template <int DPAD, bool GRAD, bool SYM, bool ROWG = false>
 __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void gram_quad_kernel(QuadArgs a)
 {
     constexpr int NT = QNW * 64;
-    constexpr int CS = DPAD + 1;  // row stride of the column-side image (odd: lanes on distinct banks)
+    constexpr int CS = DPAD + 1;  // values per point column of the column-side sums: DPAD channels and the weight sum
     constexpr int YDS = DPAD + 2; // fp64 row: coordinates, [DPAD] = -log2(e)/h * |y~|^2
     constexpr int YFS = (DPAD == 16) ? 18 : 12; // fp32 row (8-byte aligned; 18 l mod 64 visits 32 distinct even banks)
     // point column n = 64 h + c is stored at rows 128 h + c and 128 h + 64 + c: the skewed row (t - lane) & 63 of
@@ -345,7 +356,6 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
     __shared__ __align__(16) double yd[256 * YDS];
     __shared__ __align__(16) float yf[GRAD ? 256 * YFS : 4];
     __shared__ double yref[DPAD];
-    __shared__ float colacc[(GRAD && SYM) ? 128 * CS : 4];
     constexpr int HN = 136; // hand-over rows: entries 0 .. 129 are read
     __shared__ float ones[HN];
     struct WaveLds { // everything a wavefront keeps for itself, behind ONE base address
@@ -355,8 +365,8 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
     __shared__ WaveLds wl_all[QNW];
     // row-side gradient of the wavefront's particle, summed over the columns of the work item before it goes to memory
     // (one coalesced flush per item instead of 128 d lane-strided fp64 atomics per pair: -8 % symmetric, -16 % ordered)
-    constexpr int RS = (DPAD == 8) ? 9 : 15; // row stride (odd); d = 15, 16 do not fit next to the rest and flush per pair
-    __shared__ float rowacc_all[GRAD ? QNW * 128 * RS : 4];
+    constexpr int RS = (DPAD == 8) ? 9 : 15; // row stride (odd); d = 15, 16 do not fit next to the rest: ROWG
+    __shared__ float rowacc_all[(GRAD && !ROWG) ? QNW * 128 * RS : 4];
 
     const int tid = threadIdx.x, lane = tid & 63;
     // (scalar: row index, row pointers and the per-wave LDS bases then live in SGPRs; as a vector value hipcc hoists the
@@ -372,8 +382,8 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
     double *g64 = wl.g64, *rdh = wl.rdh;
     float *srow63 = wl.srow, *srow64 = wl.srow + 128;
     float *x64 = wl.x64;
-    float *rowacc = rowacc_all + (GRAD ? wave * 128 * RS : 0);
-    const bool rowlds = GRAD && d <= RS;
+    float *rowacc = rowacc_all + ((GRAD && !ROWG) ? wave * 128 * RS : 0);
+    constexpr bool rowlds = GRAD && !ROWG;
     for (int e = tid; e < HN; e += NT) ones[e] = 1.f;
     for (int e = lane; e < HN; e += 64) hK[e] = 1.f, hU[e] = 1.f; // (entries the sweeps do not write stay at the boundary value)
 
@@ -382,32 +392,45 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
 #endif
     float *dcw = a.dcache ? a.dcache + ((size_t)blockIdx.x * QNW + wave) * (3 * 64 * 64) : nullptr;
 
-    // A grid of at most one workgroup per CU strides over the work items (row tile x column chunk): ordered launches
-    // enumerate (chunk, owned tile) row-major, symmetric launches only the chunks that reach the diagonal of their tile
-    const int nJ = (a.B + a.JC - 1) / a.JC;
-#pragma unroll 1
-    for (int blk = blockIdx.x; blk < a.nblocks; blk += gridDim.x) {
-    int ty = blk / nJ, cx = blk % nJ;
-    if (SYM) {
-        int rem = blk;
-        for (ty = 0;; ++ty) {
-            const int first = ((a.tile_offset + ty * a.tile_stride) * QNW) / a.JC;
-            const int cntc = nJ - first;
-            if (rem < cntc) {
-                cx = first + rem;
-                break;
-            }
-            rem -= cntc;
+    // Work distribution as in gram_fast.hip: the items of a launch -- (owned row tile, column), tile-major; symmetric
+    // launches only the columns from the tile's first row on -- all cost the same (the 8 waves meet at a barrier per
+    // column), so a grid of at most one workgroup per CU cuts them into contiguous equal ranges.  A range touches few row
+    // tiles: the row-side sums of a wavefront's particle stay in LDS across the columns of a tile and are stored to the
+    // (workgroup, tile) segment's slot when the range leaves it.
+    const long long it0 = a.nitems * blockIdx.x / gridDim.x, it1 = a.nitems * (blockIdx.x + 1) / gridDim.x;
+    int remaining = (int)(it1 - it0);
+    long long item = it0; // index of the (row tile, column) item in work
+    int kq = 0, cstart = 0;
+    {
+        long long rem = it0;
+        for (;; ++kq) {
+            const int cn = a.B - (SYM ? a.tm.tile_of(kq) * QNW : 0);
+            if (rem < cn) break;
+            rem -= cn;
         }
+        cstart = (int)rem;
     }
-    const int i0 = (a.tile_offset + ty * a.tile_stride) * QNW;
+    // this wavefront's column-side records / global row accumulator (re-derived from scalars where they are used: as
+    // values living across the pair they are spilled)
+#define SIGQ_CRW (a.crec + ((size_t)blockIdx.x * QNW + wave) * QREC)
+#define SIGQ_RGW (a.rowg + ((size_t)blockIdx.x * QNW + wave) * (128 * 16))
+#pragma unroll 1
+    while (remaining > 0) {
+    const int itile = a.tm.tile_of(kq);
+    const int cfirst = SYM ? itile * QNW : 0; // first column that touches or crosses the diagonal
+    const int ncol = min(a.B - cfirst - cstart, remaining);
+    const int i0 = itile * QNW;
     const int i = i0 + wave;
-    const int j0 = cx * a.JC, j1 = min(a.B, j0 + a.JC);
+    const int j0 = cfirst + cstart, j1 = j0 + ncol;
     const bool row_ok = i < a.A;
-    if (rowlds)
+    if (rowlds) {
         for (int e = lane; e < 128 * RS; e += 64) rowacc[e] = 0.f;
+    } else if (GRAD) {
+        for (int e = lane; e < 128 * 16; e += 64) SIGQ_RGW[e] = 0.f;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
 
-    for (int j = j0; j < j1; ++j) {
+    for (int j = j0; j < j1; ++j, ++item) {
         // per-pair copies of the thread indices that the optimiser cannot see through: every index / address vector
         // built from them is recomputed inside the pair instead of becoming a loop invariant of the column loop that
         // is spilled and reloaded (one exposed scratch round trip each: measured 40 % of the kernel)
@@ -465,8 +488,6 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                 yd[(r + 64) * YDS + DPAD] = s;
             }
         }
-        if (GRAD && SYM)
-            for (int e = tidp; e < 128 * CS; e += NT) colacc[e] = 0.f;
         __syncthreads();
 
         SIG_QSTAMP(7)
@@ -824,11 +845,11 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                     } else {
                         cap0h1 = capA;
                     }
-                    if (SYM) { // the finished sums of local column (63 - lane) & 63 join the tile's image
-                        float *dst = colacc + (64 * h + ((63 - lv) & 63)) * CS;
+                    if (SYM) { // the finished sums of local column (63 - lane) & 63: this pass's record, [value][lane]
+                        float *dst = SIGQ_CRW + (2 * b + h) * (CS * 64) + lv;
 #pragma unroll
-                        for (int c = 0; c < DPAD; ++c) atomicAdd(dst + c, tacc[c]);
-                        atomicAdd(dst + DPAD, t0);
+                        for (int c = 0; c < DPAD; ++c) dst[c * 64] = tacc[c];
+                        dst[DPAD * 64] = t0;
                     }
                 }
 
@@ -854,9 +875,7 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
                             for (int c = 0; c <= DPAD; ++c) {
                                 const float vsum = q_wave_sum63((c < DPAD) ? rgw * xf[c] : rgw);
-                                // (address formed from the lane index: with a uniform address hipcc wraps the atomic in a
-                                //  scan-over-active-lanes loop, ~30 instructions per add)
-                                if (lv == 63) atomicAdd(colacc + (64 * sc) * CS + c + (lv - 63), vsum);
+                                if (lv == 63) SIGQ_CRW[6 * CS * 64 + (2 * b + sc) * CS + c] = vsum; // seam record [band][column 0 / 64]
                             }
                         }
                     }
@@ -864,17 +883,18 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                     // the band is done: its row-side gradient d k(x_i, y_j) / d x_i[m] goes to the fp64 accumulation buffer
                     // (point row 64 comes from the seam pass below)
                     if (m <= P && !(b == 1 && lv == 0)) {
+                        // (no-return adds so that nothing has to be loaded here; row m of this particle is touched by this
+                        //  lane only, so they execute in program order and the sums do not depend on timing)
                         if (rowlds) {
                             float *dst = rowacc + m * RS;
 #pragma unroll
                             for (int c = 0; c < RS; ++c)
                                 if (c < d) atomicAdd(dst + c, w_ij * m2h * (xf[c] * s0 - acc[c / 2][c % 2]));
                         } else {
+                            float *dst = SIGQ_RGW + m * 16;
 #pragma unroll
                             for (int c = 0; c < DPAD; ++c)
-                                if (c < d)
-                                    unsafeAtomicAdd(&a.gacc[((size_t)i * T + m) * d + c],
-                                                    (double)(w_ij * m2h * (xf[c] * s0 - acc[c / 2][c % 2])));
+                                if (c < d) unsafeAtomicAdd(dst + c, w_ij * m2h * (xf[c] * s0 - acc[c / 2][c % 2]));
                         }
                     }
                 }
@@ -907,20 +927,20 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                     ps0 += rgn;
 #pragma unroll
                     for (int c = 0; c < DPAD; ++c) part[c] = __builtin_fmaf(rgn, yr[c], part[c]);
-                    if (SYM) {
-                        float *dst = colacc + n * CS;
+                    if (SYM) { // record of point row 64: [half][value][lane], lane = local column
+                        float *dst = SIGQ_CRW + (4 + hh) * (CS * 64) + lanep;
 #pragma unroll
-                        for (int c = 0; c < DPAD; ++c) atomicAdd(dst + c, rgn * w_ji * xm[c]);
-                        atomicAdd(dst + DPAD, rgn * w_ji);
+                        for (int c = 0; c < DPAD; ++c) dst[c * 64] = rgn * w_ji * xm[c];
+                        dst[DPAD * 64] = rgn * w_ji;
                     }
                 }
                 // row 64 belongs to band 1's lane 0 accumulators
 #pragma unroll
                 for (int c = 0; c < DPAD; ++c) {
                     const float v = q_wave_sum63(w_ij * m2h * (xm[c] * ps0 - part[c])); // total in lane 63
-                    if (lanep == 63 && c < d) {
+                    if (lanep == 63 && c < d) { // (row 64 receives nothing else: band 1's lane 0 is masked out of the band flush)
                         if (rowlds) atomicAdd(rowacc + 64 * RS + min(c, RS - 1) + (lanep - 63), v);
-                        else unsafeAtomicAdd(&a.gacc[((size_t)i * T + 64) * d + c], (double)v);
+                        else unsafeAtomicAdd(SIGQ_RGW + 64 * 16 + c + (lanep - 63), v);
                     }
                 }
             }
@@ -930,41 +950,69 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
         if (GRAD && SYM) {
             // close the column-side sums of y_j over the rows of the tile:
             // d/dy_n = -(2/h) * (y~_n * sum_m w R G - sum_m w R G x~_m)
-            __syncthreads();
+            // The eight wavefronts' records are added in wave order (rounds 1-2 joined them with LDS atomics, whose order
+            // -- and with it the last bits of the gradient -- changed from run to run), and the item's sums go to their
+            // own row of the column slab.
+            __syncthreads(); // (also makes the other wavefronts' records visible: workgroup-scope release / acquire)
+            float *dstc = a.cslab + (size_t)item * (T * d);
             for (int e = tidp; e < T * DPAD; e += NT) {
                 const int n = e / DPAD, c = e % DPAD;
-                const float sw = colacc[n * CS + DPAD], sx = colacc[n * CS + c];
-                const float v = m2h * (yf[(128 * (n >> 6) + (n & 63)) * YFS + c] * sw - sx);
-                if (c < d && v != 0.f) unsafeAtomicAdd(&a.gacc[((size_t)j * T + n) * d + c], (double)v);
+                const int hq = n >> 6, q = n & 63, ln = (63 - q) & 63;
+                float sw = 0.f, sx = 0.f;
+#pragma unroll 1
+                for (int w = 0; w < QNW; ++w) {
+                    if (i0 + w >= a.A || j < i0 + w) continue; // that wavefront had no pair
+                    const float *rb = a.crec + ((size_t)blockIdx.x * QNW + w) * QREC;
+                    auto ldr = [&](int k) { return __hip_atomic_load(rb + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+                    if (nrows1 > 0) { // pass over quadrant (1, hq)
+                        sx += ldr(((2 + hq) * CS + c) * 64 + ln);
+                        sw += ldr(((2 + hq) * CS + DPAD) * 64 + ln);
+                    }
+                    if (hq == 0 || nrows1 > 0) { // pass over quadrant (0, hq)
+                        sx += ldr((hq * CS + c) * 64 + ln);
+                        sw += ldr((hq * CS + DPAD) * 64 + ln);
+                    }
+                    sx += ldr(((4 + hq) * CS + c) * 64 + q); // point row 64
+                    sw += ldr(((4 + hq) * CS + DPAD) * 64 + q);
+                    if (q == 0) { // seam columns 0 and 64, per band
+                        sx += ldr(6 * CS * 64 + hq * CS + c);
+                        sw += ldr(6 * CS * 64 + hq * CS + DPAD);
+                        if (nrows1 > 0) {
+                            sx += ldr(6 * CS * 64 + (2 + hq) * CS + c);
+                            sw += ldr(6 * CS * 64 + (2 + hq) * CS + DPAD);
+                        }
+                    }
+                }
+                const float v = m2h * (yf[(128 * hq + q) * YFS + c] * sw - sx);
+                if (c < d) dstc[n * d + c] = v;
             }
             SIG_QSTAMP(9)
         }
     }
-    if (rowlds && row_ok) { // the item's row-side sums: consecutive lanes on consecutive addresses
+    if (GRAD && row_ok) { // the segment's row-side sums: consecutive lanes on consecutive addresses
         int lf = lane;
         asm volatile("" : "+v"(lf));
         const int tot = T * d;
+        double *dstr = a.rseg + (((size_t)(kq + (int)blockIdx.x)) * QNW + wave) * (size_t)tot;
+        if (!rowlds) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wavefront's read-modify-writes have landed
         for (int e = lf; e < tot; e += 64) {
             const int m = e / d, c = e - m * d;
-            const float v = rowacc[m * RS + c];
-            if (v != 0.f) unsafeAtomicAdd(&a.gacc[(size_t)i * tot + e], (double)v);
+            // (the global accumulator was updated at the L2: read it there, not from a stale L1 line)
+            dstr[e] = (double)(rowlds ? rowacc[m * RS + c]
+                                      : __hip_atomic_load(SIGQ_RGW + m * 16 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         }
     }
     SIG_QSTAMP(11)
-    } // work items
+    remaining -= ncol;
+    ++kq;
+    cstart = 0;
+    } // row tiles of the range
 
     SIG_QSTAMP(0)
 #ifdef SIGSVGD_PHASE_STAMPS
     if (lane == 0 && a.stamps)
         for (int k = 0; k < 12; ++k) atomicAdd(&a.stamps[k], ph_[k]);
 #endif
-}
-
-template <typename IO>
-__global__ void quad_finalize_kernel(const double *gacc, IO *gradX, size_t n)
-{
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < n) gradX[idx] = (IO)gacc[idx];
 }
 
 bool quad_supported(int A, int B, int T, int d, int n, int kind, unsigned flags)
@@ -977,27 +1025,49 @@ bool quad_supported(int A, int B, int T, int d, int n, int kind, unsigned flags)
 }
 
 namespace {
-// compute units of the current device (256 on MI355X): the grid is at most one workgroup per CU
-int quad_cu_count()
-{
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
-            n = v;
-        else
-            n = 256;
-    }
-    return n;
-}
+inline int quad_cu_count() { return device_cu_count(); } // the grid is at most one workgroup per CU
 constexpr size_t QUAD_DCACHE_PER_WG = (size_t)QNW * 3 * 64 * 64 * sizeof(float); // 384 KB
+constexpr size_t QUAD_CREC_PER_WG = (size_t)QNW * QREC * sizeof(float);          // 208 KB
+constexpr size_t QUAD_ROWG_PER_WG = (size_t)QNW * 128 * 16 * sizeof(float);      // 64 KB (d = 15, 16 only)
+
+inline GradGeom quad_geometry(int A, int B, int T, int d, bool sym, int off = 0, int stride = 1, bool fold = false)
+{
+    return grad_geometry(A, B, T * d, sym, off, stride, fold, QNW, (long long)quad_cu_count());
+}
+inline GradGeom quad_geometry(int A, int B, int T, int d, bool sym, const TileMap &tm)
+{
+    return quad_geometry(A, B, T, d, sym, tm.off, tm.stride, tm.owned > tm.m0);
+}
+// workspace of a gradient launch: [row segments][column slab][column records][row accumulators (d >= 15)][increment scratch]
+struct QuadCut {
+    size_t rseg, cslab, crec, rowg, dcache, total;
+};
+inline QuadCut quad_cut(const GradGeom &g, int d, bool sym)
+{
+    QuadCut c;
+    const size_t ncu = (size_t)quad_cu_count();
+    c.rseg = 0;
+    c.cslab = c.rseg + g.rseg_bytes;
+    c.crec = c.cslab + g.cslab_bytes;
+    c.rowg = c.crec + (sym ? ncu * QUAD_CREC_PER_WG : 0);
+    c.dcache = c.rowg + (d > 14 ? ncu * QUAD_ROWG_PER_WG : 0);
+    c.total = c.dcache + ncu * QUAD_DCACHE_PER_WG;
+    return c;
+}
 } // namespace
 
-int quad_workspace_bytes(int A, int T, int d, int want_grad, size_t *bytes)
+int quad_workspace_bytes(int A, int B, int T, int d, int want_grad, size_t *bytes)
 {
-    // fp64 accumulation buffer + the increment scratch of a full grid (100 MB on 256 CUs; it lives in L2 / MALL)
-    *bytes = want_grad ? (size_t)A * T * d * sizeof(double) + 512 + (size_t)quad_cu_count() * QUAD_DCACHE_PER_WG : 0;
+    *bytes = 0;
+    if (!want_grad) return SIGSVGD_OK;
+    // the larger of the ordered and the symmetric launch (the query carries no Y_IS_X promise); the increment scratch of a
+    // full grid is 100 MB on 256 CUs and lives in L2 / MALL
+    size_t need = quad_cut(quad_geometry(A, B, T, d, false), d, false).total;
+    if (A == B) {
+        const size_t y = quad_cut(quad_geometry(A, B, T, d, true), d, true).total;
+        if (y > need) need = y;
+    }
+    *bytes = need + 512;
     return SIGSVGD_OK;
 }
 
@@ -1005,31 +1075,11 @@ namespace {
 template <int DPAD>
 int quad_launch_variant(const GramProblem &p, QuadArgs &a, bool grad, bool sym)
 {
-    const int ntile = (p.A + QNW - 1) / QNW;
-    const int owned = (ntile - a.tile_offset + a.tile_stride - 1) / a.tile_stride;
-    if (owned <= 0) return SIGSVGD_OK;
-    const int ncu = quad_cu_count();
-    // work items of JC columns: the grid strides over them, so a launch wants >= 16 per workgroup for an even spread
-    // (the column trajectory is staged per column whatever JC is; small launches go down to single columns)
-    auto items = [&](int jc) {
-        const int nj = (p.B + jc - 1) / jc;
-        long long t = (long long)nj * owned;
-        if (sym) { // only the chunks on or right of the diagonal of every owned tile
-            t = 0;
-            for (int k = 0; k < owned; ++k) {
-                const int first = ((a.tile_offset + k * a.tile_stride) * QNW) / jc;
-                if (first < nj) t += nj - first;
-            }
-        }
-        return t;
-    };
-    int JC = 8;
-    while (JC > 1 && items(JC) < 16LL * ncu) JC >>= 1;
-    a.JC = JC;
-    const long long total = items(JC);
-    if (total <= 0) return SIGSVGD_OK;
-    a.nblocks = (int)total;
-    dim3 grid((unsigned)(total < ncu ? total : ncu)), block(QNW * 64);
+    const GradGeom g = quad_geometry(p.A, p.B, p.T, p.d, sym, a.tm);
+    if (g.tm.owned <= 0 || g.nitems <= 0) return SIGSVGD_OK;
+    a.tm = g.tm;
+    a.nitems = g.nitems;
+    dim3 grid((unsigned)g.grid), block(QNW * 64);
 #ifdef SIGSVGD_PHASE_STAMPS
     {
         static unsigned long long *dbg = nullptr;
@@ -1038,7 +1088,13 @@ int quad_launch_variant(const GramProblem &p, QuadArgs &a, bool grad, bool sym)
         a.stamps = dbg;
     }
 #endif
-    if (grad && sym)
+    constexpr bool HAS_ROWG = DPAD == 16;
+    const bool rowg = HAS_ROWG && grad && p.d > 14;
+    if (grad && sym && rowg)
+        hipLaunchKernelGGL((gram_quad_kernel<DPAD, true, true, HAS_ROWG>), grid, block, 0, p.stream, a);
+    else if (grad && rowg)
+        hipLaunchKernelGGL((gram_quad_kernel<DPAD, true, false, HAS_ROWG>), grid, block, 0, p.stream, a);
+    else if (grad && sym)
         hipLaunchKernelGGL((gram_quad_kernel<DPAD, true, true>), grid, block, 0, p.stream, a);
     else if (grad)
         hipLaunchKernelGGL((gram_quad_kernel<DPAD, true, false>), grid, block, 0, p.stream, a);
@@ -1074,21 +1130,32 @@ int quad_dispatch(const GramProblem &p, QuadArgs &a, bool grad, bool sym)
 
 void quad_fill_args(const GramProblem &p, QuadArgs &a)
 {
-    a.X = p.X; a.Y = p.Y; a.go = p.grad_out; a.K = p.K_out; a.gacc = nullptr;
-    a.io64 = p.dtype == SIGSVGD_F64; a.A = p.A; a.B = p.B; a.T = p.T; a.d = p.d; a.JC = 1;
+    a.X = p.X; a.Y = p.Y; a.go = p.grad_out; a.K = p.K_out;
+    a.rseg = nullptr; a.cslab = nullptr; a.crec = nullptr; a.rowg = nullptr;
+    a.io64 = p.dtype == SIGSVGD_F64; a.A = p.A; a.B = p.B; a.T = p.T; a.d = p.d;
     a.symw = (p.flags & SIGSVGD_FLAG_SYM) ? 1 : 0; a.inv_h = p.inv_h;
-    a.tile_offset = 0; a.tile_stride = 1;
-    a.nblocks = 0; a.dcache = nullptr;
+    a.tm = make_tilemap(1, 0, 1, false); // (a full launch; quad_launch_variant derives the tile count)
+    a.nitems = 0; a.dcache = nullptr;
 }
-// the increment scratch behind `used` bytes of the caller's workspace, if the workspace is large enough for a full grid
-// (sized by quad_workspace_bytes); without it the kernel recomputes the increments on the second visit of a quadrant
-float *quad_dcache_in(const GramProblem &p, size_t used)
+
+// cut the workspace, enqueue kernel + fixed-order reduction into `out` (the I/O type, or fp64 for the partial solve)
+int quad_run_grad(const GramProblem &p, QuadArgs &a, bool sym, void *out, int out64)
 {
-    if (!p.ws) return nullptr;
-    const uintptr_t base = (reinterpret_cast<uintptr_t>(p.ws) + used + 255) & ~(uintptr_t)255;
-    const uintptr_t end = reinterpret_cast<uintptr_t>(p.ws) + p.ws_bytes;
-    const size_t need = (size_t)quad_cu_count() * QUAD_DCACHE_PER_WG;
-    return (base + need <= end) ? reinterpret_cast<float *>(base) : nullptr;
+    const GradGeom g = quad_geometry(p.A, p.B, p.T, p.d, sym, a.tm);
+    const QuadCut c = quad_cut(g, p.d, sym);
+    if (!p.ws || p.ws_bytes < c.total + 256) {
+        set_error("quad: workspace %zu B < required %zu B", p.ws_bytes, c.total + 256);
+        return SIGSVGD_E_WORKSPACE;
+    }
+    unsigned char *base = reinterpret_cast<unsigned char *>((reinterpret_cast<uintptr_t>(p.ws) + 255) & ~(uintptr_t)255);
+    a.rseg = reinterpret_cast<double *>(base + c.rseg);
+    a.cslab = sym ? reinterpret_cast<float *>(base + c.cslab) : nullptr;
+    a.crec = sym ? reinterpret_cast<float *>(base + c.crec) : nullptr;
+    a.rowg = p.d > 14 ? reinterpret_cast<float *>(base + c.rowg) : nullptr;
+    a.dcache = reinterpret_cast<float *>(base + c.dcache);
+    int rc = quad_dispatch(p, a, true, sym);
+    if (rc) return rc;
+    return grad_reduce_launch(g, a.rseg, a.cslab, out, out64, p.A, p.B, p.T * p.d, sym, p.stream);
 }
 } // namespace
 
@@ -1102,39 +1169,14 @@ int quad_launch(const GramProblem &p)
         set_error("sym backward needs A == B");
         return SIGSVGD_E_BADARG;
     }
-    const size_t nacc = (size_t)p.A * p.T * p.d;
-    if (grad) {
-        const size_t need = nacc * sizeof(double) + 256;
-        if (!p.ws || p.ws_bytes < need) {
-            set_error("quad: workspace %zu B < required %zu B", p.ws_bytes, need);
-            return SIGSVGD_E_WORKSPACE;
-        }
-        a.gacc = reinterpret_cast<double *>((reinterpret_cast<uintptr_t>(p.ws) + 255) & ~(uintptr_t)255);
-        hipError_t e = hipMemsetAsync(a.gacc, 0, nacc * sizeof(double), p.stream);
-        if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(gacc)");
-        a.dcache = quad_dcache_in(p, nacc * sizeof(double) + 256);
-    }
-    int rc = quad_dispatch(p, a, grad, sym);
-    if (rc) return rc;
-    if (grad) {
-        const int bs = 256;
-        const unsigned gs = (unsigned)((nacc + bs - 1) / bs);
-        if (p.dtype == SIGSVGD_F64)
-            hipLaunchKernelGGL(quad_finalize_kernel<double>, dim3(gs), dim3(bs), 0, p.stream, a.gacc,
-                               static_cast<double *>(p.gradX_out), nacc);
-        else
-            hipLaunchKernelGGL(quad_finalize_kernel<float>, dim3(gs), dim3(bs), 0, p.stream, a.gacc,
-                               static_cast<float *>(p.gradX_out), nacc);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return hip_fail(e, "launch quad_finalize_kernel");
-    }
-    return SIGSVGD_OK;
+    if (!grad) return quad_dispatch(p, a, false, sym);
+    return quad_run_grad(p, a, sym, p.gradX_out, p.dtype == SIGSVGD_F64);
 }
 
-// Sharded partial solve (sigsvgd_gram_sym_partial) for the long-path shapes: row tiles of 8 rows,
-// tiles tile_offset + k * tile_stride, both orientations of K stored into the caller-zeroed K_partial,
-// gradient shares accumulated (fp64 atomics) straight into the caller-zeroed grad_partial.
-int quad_sym_partial(const GramProblem &p, int tile_offset, int tile_stride, double *grad_partial)
+// Sharded partial solve (sigsvgd_gram_sym_partial) for the long-path shapes: row tiles of 8 rows, tiles
+// tile_offset + k * tile_stride, both orientations of K stored into the caller-zeroed K_partial; grad_partial (fp64) is
+// OVERWRITTEN with this launch's share of the gradient.
+int quad_sym_partial(const GramProblem &p, int tile_offset, int tile_stride, bool fold, double *grad_partial)
 {
     if (tile_stride < 1 || tile_offset < 0 || tile_offset >= tile_stride) {
         set_error("bad tile_offset/tile_stride %d/%d", tile_offset, tile_stride);
@@ -1142,11 +1184,8 @@ int quad_sym_partial(const GramProblem &p, int tile_offset, int tile_stride, dou
     }
     QuadArgs a;
     quad_fill_args(p, a);
-    a.gacc = grad_partial;
-    a.tile_offset = tile_offset;
-    a.tile_stride = tile_stride;
-    a.dcache = quad_dcache_in(p, 0); // (the accumulation buffer is the caller's: the workspace holds the scratch only)
-    return quad_dispatch(p, a, true, true);
+    a.tm = make_tilemap((p.A + QNW - 1) / QNW, tile_offset, tile_stride, fold);
+    return quad_run_grad(p, a, true, grad_partial, 1);
 }
 
 } // namespace sigsvgd

@@ -171,16 +171,60 @@ struct GramProblem {
 int generic_workspace_bytes(int A, int B, int T, int d, int n, int want_grad, size_t *bytes);
 int generic_launch(const GramProblem &p);
 
+// fixed-order reduction of the gradient partial sums shared by the register-resident and the quadrant kernel -- gram_fast.hip
+// Which row tiles a launch owns and the order it enumerates them in (kq = 0 .. owned-1).  A full launch owns all of
+// them (off 0, stride 1).  The sharded partial solve of rank `off` of `stride` owns the tiles off + k*stride (cyclic), or
+// -- SIGSVGD_FLAG_FOLD_TILES -- those AND their mirror images ntile-1 - (off + k*stride): in the upper triangle tile t
+// has B - t*NW columns, so a tile and its mirror image together always cost the same and every rank gets the same
+// number of items (cyclic ownership alone gives rank 0 5.4 % more than the mean at N=1024 on 8 ranks).
+struct TileMap {
+    int off, stride, ntile, owned, m0; // m0 tiles of the first kind (off + k*stride), then owned - m0 mirror images
+    __host__ __device__ int tile_of(int kq) const
+    {
+        return kq < m0 ? off + kq * stride : ntile - 1 - (off + (kq - m0) * stride);
+    }
+    __host__ __device__ int kq_of_tile(int ti) const // -1: not owned
+    {
+        if (ti >= off && (ti - off) % stride == 0 && (ti - off) / stride < m0) return (ti - off) / stride;
+        const int p = ntile - 1 - ti;
+        if (p >= off && (p - off) % stride == 0 && (p - off) / stride < owned - m0) return m0 + (p - off) / stride;
+        return -1;
+    }
+    // items of the owned tiles 0 .. kq-1 in the tile-major enumeration of the kernels: symmetric launches count the
+    // columns from the tile's first row on (B - tile*NW), ordered ones all B
+    __host__ __device__ long long start(int kq, int B, int NW, int sym) const
+    {
+        if (!sym) return (long long)kq * B;
+        const long long k1 = kq < m0 ? kq : m0, k2 = kq - k1;
+        long long s = k1 * B - (long long)NW * ((long long)stride * k1 * (k1 - 1) / 2 + (long long)off * k1);
+        s += k2 * ((long long)B - (long long)(ntile - 1 - off) * NW) + (long long)NW * stride * k2 * (k2 - 1) / 2;
+        return s;
+    }
+};
+TileMap make_tilemap(int ntile, int off, int stride, bool fold);
+
+struct GradGeom {
+    int NW, grid;
+    TileMap tm;
+    long long nitems;
+    size_t rseg_bytes, cslab_bytes;
+};
+int device_cu_count();
+GradGeom grad_geometry(int A, int B, int TD, bool sym, int off, int stride, bool fold, int NW, long long resident);
+int grad_reduce_launch(const GradGeom &g, const double *rseg, const float *cslab, void *out, int out64, int A, int B, int TD,
+                       bool sym, hipStream_t stream);
+
 // register-resident fast path (n == 0, T <= 64, RBF/linear) -- gram_fast.hip
 bool fast_supported(int A, int B, int T, int d, int n, int kind, unsigned flags);
 int fast_workspace_bytes(int A, int B, int T, int d, int want_grad, unsigned flags, size_t *bytes);
 int fast_launch(const GramProblem &p);
-int fast_sym_partial(const GramProblem &p, int tile_offset, int tile_stride, double *grad_partial);
+int fast_sym_partial(const GramProblem &p, int tile_offset, int tile_stride, bool fold, double *grad_partial);
+int sym_tile_rows_fast(int T, int d); // rows per tile of the gradient launches (ownership unit of the partial solve)
 
 // long paths, stored forward solution, 2 x 2 quadrants of 64 x 64 cells at two waves per SIMD -- gram_quad.hip
 bool quad_supported(int A, int B, int T, int d, int n, int kind, unsigned flags);
-int quad_workspace_bytes(int A, int T, int d, int want_grad, size_t *bytes);
+int quad_workspace_bytes(int A, int B, int T, int d, int want_grad, size_t *bytes);
 int quad_launch(const GramProblem &p);
-int quad_sym_partial(const GramProblem &p, int tile_offset, int tile_stride, double *grad_partial);
+int quad_sym_partial(const GramProblem &p, int tile_offset, int tile_stride, bool fold, double *grad_partial);
 
 } // namespace sigsvgd

@@ -36,7 +36,10 @@ __global__ void counter_inc_kernel(int *ctr) { *ctr += 1; }
 __global__ __launch_bounds__(256) void svgd_phi_kernel(const float *__restrict__ K, const float *__restrict__ S,
                                                        const float *__restrict__ gk, const float *__restrict__ mask,
                                                        int N, int D, float *__restrict__ v_out,
-                                                       const float *__restrict__ X_in, float *__restrict__ X_out, float lr,
+                                                       // (no __restrict__ on the particles: the in-place update passes the
+                                                       //  same buffer as X_in and X_out; every element is read and then
+                                                       //  written by the same thread)
+                                                       const float *X_in, float *X_out, float lr,
                                                        float *__restrict__ adagrad, AdamArgs adam)
 {
     __shared__ __align__(16) float kt[PM * KS];     // K tile      [row][k]

@@ -87,21 +87,30 @@ class _VectorKernel(BaseKernel):
 
     def _constant_bandwidth(self):
         """The bandwidth if `bandwidth_fn` ignores its argument (the reference's scripts pass `lambda _: 0.2`), else
-        None.  Decided once per kernel object by calling a user-supplied function on two different one-element
-        distance tensors; the median heuristic (the default) always depends on the data."""
-        if not hasattr(self, "_const_h"):
-            self._const_h = None
-            from ..utils.math import bw_median
+        None.  The function is handed a probe object that raises on ANY use (arithmetic, attribute, torch function):
+        only a function that returns without touching its argument is treated as constant -- one that reads the
+        distances in any way (`sq.median().clamp(min=c)`, `sq.shape[0] ** -0.2`, ...) is evaluated on the real
+        distance matrix every call, as in the reference (src/kernels/_kernels.py:34-42).  Re-probed whenever
+        `get_bandwidth` has been reassigned."""
+        fn = self.get_bandwidth
+        cached = getattr(self, "_const_h", None)
+        if cached is not None and cached[0] is fn:
+            return cached[1]
+        from ..sigkernel import _ConstantProbe
+        from ..utils.math import bw_median
 
-            fn = self.get_bandwidth
-            if fn is not bw_median:
-                try:
-                    a, b = float(fn(torch.tensor([1.0]))), float(fn(torch.tensor([4.0])))
-                    if a == b and a > 0 and a == a:
-                        self._const_h = a
-                except Exception:  # a function that needs a real distance matrix: data-dependent
-                    self._const_h = None
-        return self._const_h
+        h = None
+        if fn is not bw_median:
+            try:
+                v = float(fn(_ConstantProbe()))
+                if v > 0 and v == v:
+                    h = v
+            except _ConstantProbe.Touched:
+                h = None
+            except Exception:  # anything else a data-dependent function does to a non-tensor
+                h = None
+        self._const_h = (fn, h)
+        return h
 
     def _evaluate(self, X, Y, M=None, h=None, compute_grad=True):
         from .. import ops

@@ -13,9 +13,7 @@ import torch
 
 from . import _lib
 
-_WS = {}  # (device index, stream) -> uint8 workspace tensor
-_WS_CLEAN = {}  # (device index, stream) -> zero-filled workspace of the register-resident gradient launches, which
-#                 take it zeroed and hand it back zeroed (SIGSVGD_FLAG_WS_CLEAN): no memset per iteration
+_WS = {}  # (device index, stream) -> uint8 workspace tensor (never needs zeroing: partial sums are stored, not accumulated)
 
 
 def _require_gpu(*tensors) -> torch.device:
@@ -48,21 +46,6 @@ def _workspace(dev: torch.device, nbytes: int) -> Tuple[Optional[torch.Tensor], 
         ws = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=dev)
         _WS[key] = ws
     return ws, ws.numel()
-
-
-def _clean_workspace(dev: torch.device, nbytes: int) -> Tuple[torch.Tensor, int]:
-    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
-    ws = _WS_CLEAN.get(key)
-    if ws is None or ws.numel() < nbytes:
-        ws = torch.zeros(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=dev)
-        _WS_CLEAN[key] = ws
-    return ws, ws.numel()
-
-
-def _fast_path(T: int, d: int, dyadic_order: int, static_kind: int, naive: bool, force_generic: bool) -> bool:
-    """launches the register-resident kernel serves (csrc/gram_fast.hip fast_supported)"""
-    return (dyadic_order == 0 and 3 <= T <= 64 and d <= 16 and static_kind == _lib.STATIC_RBF and not naive
-            and not force_generic)
 
 
 def _io_dtype(t: torch.Tensor) -> int:
@@ -135,6 +118,9 @@ def gram_fwd_bwd(X, Y, inv_h: float, dyadic_order: int = 0, static_kind: int = _
                  check_regime: bool = True, stored_forward: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
     """(K[A,B], gradX[A,T,d]) with gradX = d sum(grad_out*K)/dX (first slot); grad_out None = ones.
 
+    Bit-reproducible: every reduction over pairs runs in an order fixed by the launch geometry (no floating-point
+    atomics), so two calls on the same input -- eager or replayed from a captured graph -- return the same bits.
+
     Every kernel behind this call keeps the forward solution, so there is no limit on how rough the paths may be.
     `check_regime` and `stored_forward` are accepted for callers written against earlier versions (when long paths
     could run on a kernel that regenerated the forward solution and declined rough pairs) and have no effect."""
@@ -152,12 +138,7 @@ def gram_fwd_bwd(X, Y, inv_h: float, dyadic_order: int = 0, static_kind: int = _
     nbytes = ctypes.c_size_t(0)
     _lib.check(L.sigsvgd_gram_workspace_bytes(A, B, T, d, dyadic_order, 1, flags, ctypes.byref(nbytes)),
                "gram_workspace_bytes")
-    clean = _fast_path(T, d, dyadic_order, static_kind, naive, force_generic)
-    if clean:  # zero on entry, handed back zeroed: the launch issues no memset
-        flags |= _lib.FLAG_WS_CLEAN
-        ws, wsn = _clean_workspace(dev, nbytes.value)
-    else:
-        ws, wsn = _workspace(dev, nbytes.value)
+    ws, wsn = _workspace(dev, nbytes.value)
     K = torch.empty((A, B), dtype=Xc.dtype, device=dev)
     gX = torch.empty((A, T, d), dtype=Xc.dtype, device=dev)
     with torch.cuda.device(dev):
@@ -165,8 +146,6 @@ def gram_fwd_bwd(X, Y, inv_h: float, dyadic_order: int = 0, static_kind: int = _
                                     int(dyadic_order), int(static_kind), flags,
                                     go.data_ptr() if go is not None else None, K.data_ptr(), gX.data_ptr(),
                                     ws.data_ptr() if ws is not None else None, wsn, _stream_ptr(dev))
-    if rc != 0 and clean:  # a failed launch may have left the workspace dirty
-        _WS_CLEAN.pop((dev.index, torch.cuda.current_stream(dev).cuda_stream), None)
     _lib.check(rc, "gram_fwd_bwd")
     return K, gX
 
@@ -275,10 +254,11 @@ def svgd_adam(K, score, grad_k, X, lr: float, state: AdamState, mask=None, inpla
 
 
 def gram_sym_partial(X, inv_h: float, tile_offset: int, tile_stride: int, static_kind: int = _lib.STATIC_RBF,
-                     grad_out: Optional[torch.Tensor] = None, sym: bool = False):
+                     grad_out: Optional[torch.Tensor] = None, sym: bool = False, out=None):
     """This rank's share of the symmetric Gram + gradient on the gathered particles X [N,T,d]:
     returns (K_partial [N,N] X.dtype, grad_partial [N,T,d] fp64), zero outside the owned pairs.
-    Summed over tile_offset = 0..tile_stride-1 they equal gram_fwd_bwd(X, X, y_is_x=True)."""
+    Summed over tile_offset = 0..tile_stride-1 they equal gram_fwd_bwd(X, X, y_is_x=True).
+    `out=(K_partial, grad_partial)` reuses the caller's buffers (K_partial is re-zeroed, grad_partial overwritten)."""
     L = _lib.load()
     dev = _require_gpu(X, grad_out)
     Xc, _ = _prep_paths(X, X)
@@ -286,8 +266,15 @@ def gram_sym_partial(X, inv_h: float, tile_offset: int, tile_stride: int, static
     go = None
     if grad_out is not None:
         go = grad_out.detach().to(Xc.dtype).contiguous()
-    Kp = torch.zeros((N, N), dtype=Xc.dtype, device=dev)
-    gp = torch.zeros((N, T, d), dtype=torch.float64, device=dev)
+    if out is not None:
+        Kp, gp = out
+        if (tuple(Kp.shape) != (N, N) or Kp.dtype != Xc.dtype or not Kp.is_contiguous() or tuple(gp.shape) != (N, T, d)
+                or gp.dtype != torch.float64 or not gp.is_contiguous()):
+            raise ValueError("out must be (K_partial [N,N] of X's dtype, grad_partial [N,T,d] float64), contiguous")
+        Kp.zero_()
+    else:
+        Kp = torch.zeros((N, N), dtype=Xc.dtype, device=dev)
+        gp = torch.empty((N, T, d), dtype=torch.float64, device=dev)  # fully overwritten by the library
     flags = _flags(False, sym, True, False)
     nbytes = ctypes.c_size_t(0)
     _lib.check(L.sigsvgd_gram_workspace_bytes(N, N, T, d, 0, 1, flags, ctypes.byref(nbytes)), "gram_workspace_bytes")

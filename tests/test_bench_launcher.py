@@ -1,6 +1,7 @@
 """`python bench.py --gpus N` must start its own ranks (the driver's SCALE run may invoke it without a
 launcher) and must also run as one rank under `torch.distributed.run`.  Rehearsed here on CPU tensors
-over gloo with the oracle-backed doubles (`--rehearse-cpu`, test only): what is checked is the process
+over gloo with the oracle-backed doubles (tests/bench_rehearsal.py drives bench.main with a stand-in backend;
+bench.py itself has no CPU path): what is checked is the process
 plumbing -- child ranks, one JSON line from rank 0, the per-rank phase report, exit codes -- not a number."""
 import json
 import os
@@ -9,7 +10,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-BENCH = os.path.join(ROOT, "bench.py")
+BENCH = os.path.join(ROOT, "tests", "bench_rehearsal.py")
 
 
 def _json_line(stdout: str) -> dict:
@@ -32,7 +33,7 @@ def _check(out: dict, world: int):
 
 def test_bench_starts_its_own_ranks():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "2", "--warmup", "1", "--rehearse-cpu"],
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "2", "--warmup", "1"],
                        capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-2000:]
     _check(_json_line(p.stdout), 2)
@@ -45,7 +46,7 @@ def test_bench_runs_as_a_rank_under_the_launcher():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", str(port), BENCH, "--gpus", "2", "--steps", "2",
-                        "--warmup", "1", "--rehearse-cpu"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+                        "--warmup", "1"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-2000:]
     _check(_json_line(p.stdout), 2)
 
@@ -53,7 +54,7 @@ def test_bench_runs_as_a_rank_under_the_launcher():
 def test_bench_reports_a_failing_rank():
     """3 ranks cannot shard the 16 rehearsal particles: every rank raises, the parent must not exit 0"""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    p = subprocess.run([sys.executable, BENCH, "--gpus", "3", "--steps", "1", "--warmup", "0", "--rehearse-cpu"],
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "3", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert p.returncode != 0
     assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]

@@ -10,11 +10,20 @@ from oracle import sigkernel_oracle as O
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
+# two fp32-sweep solves of one pair that differ in orientation (the symmetric launch solves (i, j), the ordered one also
+# (j, i)) or launch geometry agree to a few ulps PER ENTRY; both are within TOL of the fp64 oracle
+SELF = 4e-6
 
 
 def rel(a, b):
     a = a.detach().double().cpu().numpy() if hasattr(a, "detach") else np.asarray(a, np.float64)
     return float(np.abs(a - b).max() / np.abs(b).max())
+
+
+def relK(a, b):
+    """K parity as north_star states it: max over entries of |K - K_ref| / |K_ref| (K > 0 always)"""
+    a = a.detach().double().cpu().numpy() if hasattr(a, "detach") else np.asarray(a, np.float64)
+    return float((np.abs(a - b) / np.abs(b)).max())
 
 
 def _cost_fn(x, w):
@@ -32,7 +41,7 @@ def test_signature_kernel_and_score_estimator_fixtures(gpu):
     x = torch.as_tensor(G["c1_X"], device=gpu).requires_grad_(True)
     K = sk(x, x.detach())
     assert K.dtype == torch.float32 and K.device == x.device
-    assert rel(K, G["c1_K"].astype(np.float64)) < TOL
+    assert relK(K, G["c1_K"].astype(np.float64)) < TOL
     g = torch.autograd.grad(K.sum(), x)[0]
     assert rel(g, G["c1_gradk"].astype(np.float64)) < TOL
     est = ScoreEstimator(sk, _cost_fn, {"w": 0.5}, scheduler=SquareRootScheduler(1.0), ctx={"device": gpu})
@@ -177,8 +186,9 @@ def test_graphed_iteration_equals_eager(gpu, update, shape, dyadic):
         else:
             _, Xe = ops.svgd_phi(K, s0, gk, X=Xe, lr=lr, adagrad_state=ada)
         torch.cuda.synchronize()
-        assert rel(g.X, Xe.double().cpu().numpy()) < 1e-6, (update, it)
-        assert rel(g.K, K.double().cpu().numpy()) < 1e-6
+        # same kernels, same launch geometry, reductions in a fixed order: the replay is the eager iteration bit for bit
+        assert torch.equal(g.K, K) and torch.equal(g.grad_k, gk), (update, it)
+        assert torch.equal(g.X, Xe), (update, it)
     assert g.iterations == 3
     if update == "adam":
         assert int(g._adam.step.item()) == 3
@@ -220,8 +230,8 @@ def test_route_a_value_equal_buffers_take_the_symmetric_solve(gpu):
     finally:
         ops.gram_fwd_bwd, ops.gram_fwd = orig_fb, orig_f
     Kref, gref = ops.gram_fwd_bwd(Xg.detach(), Xg.detach().clone(), 1.0)  # ordered pairs
-    assert rel(K, Kref.double().cpu().numpy()) < 1e-6 and rel(g, gref.double().cpu().numpy()) < TOL
-    assert rel(K_small, Kref[:8, :8].double().cpu().numpy()) < 1e-6 and K_diff.shape == (64, 64)
+    assert relK(K, Kref.double().cpu().numpy()) < SELF and rel(g, gref.double().cpu().numpy()) < TOL
+    assert relK(K_small, Kref[:8, :8].double().cpu().numpy()) < SELF and K_diff.shape == (64, 64)
 
 
 def test_roctx_ranges_can_be_switched_on():
@@ -259,7 +269,7 @@ def test_trajectory_svgd_sigkernel_branch_on_gpu(gpu):
     # the reference's own call pattern: fp64 tensors in, fp64 out
     tau = traj[..., 1:, :2]
     K64 = sigk.compute_Gram(tau.double(), tau.detach().double(), sym=False)
-    assert K64.dtype == torch.float64 and rel(K64, G["traj_kxx"].astype(np.float64)) < TOL
+    assert K64.dtype == torch.float64 and relK(K64, G["traj_kxx"].astype(np.float64)) < TOL
 
 
 def test_compute_gram_autograd_variants(gpu):
@@ -274,7 +284,7 @@ def test_compute_gram_autograd_variants(gpu):
         y = torch.as_tensor(Yn, device=gpu)
         K = sk.compute_Gram(x, y)
         Kref, gref = O.gram_backward(Xn, Yn, None, kind, 0.8, n)
-        assert rel(K, Kref) < TOL
+        assert relK(K, Kref) < TOL
         (3.0 * K).sum().backward()  # uniform weights: scaled speculative gradient
         assert rel(x.grad, 3.0 * gref) < TOL
         x.grad = None
@@ -303,7 +313,7 @@ def test_default_median_bandwidth_on_gpu(gpu):
     X = np.cumsum(0.3 * np.random.default_rng(1).standard_normal((6, 3, 7)), axis=1).astype(np.float32)
     h = O.bw_median(O.pairwise_sqdist(X, X))
     K = SignatureKernel(depth=3)(torch.as_tensor(X, device=gpu), torch.as_tensor(X, device=gpu))
-    assert rel(K, O.gram(X, X, O.RBF, h, 3)) < TOL
+    assert relK(K, O.gram(X, X, O.RBF, h, 3)) < TOL
 
 
 @pytest.mark.parametrize("N,T,d,stride", [(24, 64, 7, 2), (40, 32, 3, 3), (20, 20, 14, 4)])
@@ -322,7 +332,7 @@ def test_sym_partials_sum_to_full(gpu, N, T, d, stride):
     nz = sum((p[0] != 0).sum().item() for p in parts)
     assert nz == N * N  # every entry owned exactly once (K > 0 everywhere)
     Kref, gref = O.gram_backward(X.numpy(), X.numpy(), None, O.RBF, 1.0, 0)
-    assert rel(Ksum, Kref) < TOL and rel(gsum, gref) < TOL
+    assert relK(Ksum, Kref) < TOL and rel(gsum, gref) < TOL
 
 
 def test_properties_at_benchmark_size(gpu):
@@ -335,18 +345,18 @@ def test_properties_at_benchmark_size(gpu):
     # (a) symmetric solve == ordered solve == forward-only solve
     K2, g2 = ops.gram_fwd_bwd(Xg, Xg, 1.0)
     K3 = ops.gram_fwd(Xg, Xg, 1.0)
-    assert rel(K2, K.double().cpu().numpy()) < 1e-6 and torch.equal(K2, K3)
+    assert relK(K2, K.double().cpu().numpy()) < SELF and torch.equal(K2, K3)
     assert rel(g2, g.double().cpu().numpy()) < TOL
     # (b) translation invariance of the RBF signature kernel
     K4, g4 = ops.gram_fwd_bwd(Xg + 3.0, Xg + 3.0, 1.0, y_is_x=True)
-    assert rel(K4, K.double().cpu().numpy()) < TOL and rel(g4, g.double().cpu().numpy()) < TOL
+    assert relK(K4, K.double().cpu().numpy()) < TOL and rel(g4, g.double().cpu().numpy()) < TOL
     # (c) k(x, constant path) = 1 and boundary: two-point constant paths
     const = Xg[:, :1, :].expand(-1, 64, -1).contiguous()
     assert float((ops.gram_fwd(Xg[:64], const[:64], 1.0) - 1).abs().max()) < 1e-6
     # (d) permutation equivariance: K[perm][:, perm], grad[perm]
     perm = torch.randperm(1024, generator=torch.Generator().manual_seed(0)).to(gpu)
     Kp, gp = ops.gram_fwd_bwd(Xg[perm].contiguous(), Xg[perm].contiguous(), 1.0, y_is_x=True)
-    assert rel(Kp, K[perm][:, perm].double().cpu().numpy()) < 1e-6
+    assert relK(Kp, K[perm][:, perm].double().cpu().numpy()) < SELF
     assert rel(gp, g[perm].double().cpu().numpy()) < TOL
     # (e) velocity: linear in (score, grad_k); fused update consistent
     v, Xn = ops.svgd_phi(K, sg, g, X=Xg, lr=1e-3)
@@ -419,7 +429,7 @@ def test_sharded_step_long_paths_on_rccl(gpu):
             _, Xb = ops.svgd_phi(K, sg, g, X=Xg, lr=1e-3)
             assert rel(Xa, Xb.double().cpu().numpy()) < 1e-6
             ref = O.svgd_iteration(X.numpy(), s.numpy(), h=1.0, n=0, lr=1e-3)
-            assert rel(K, ref["K"]) < TOL and rel(g, ref["grad_k"]) < TOL and rel(Xa, ref["X_new"]) < 1e-6
+            assert relK(K, ref["K"]) < TOL and rel(g, ref["grad_k"]) < TOL and rel(Xa, ref["X_new"]) < SELF
     finally:
         dist.destroy_process_group()
 

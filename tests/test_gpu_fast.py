@@ -9,6 +9,9 @@ from oracle import sigkernel_oracle as O
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-5  # north_star tolerance (relative; gradients relative to max-abs)
+# two fp32-sweep solves of one pair that differ in orientation (the symmetric launch solves (i, j), the ordered one also
+# (j, i)) or launch geometry agree to a few ulps PER ENTRY; both are within TOL of the fp64 oracle
+SELF = 4e-6
 
 
 def _paths(A, T, d, seed, scale=0.05, offset=0.0):
@@ -18,6 +21,12 @@ def _paths(A, T, d, seed, scale=0.05, offset=0.0):
 
 def _rel(a, b):
     return float(np.abs(np.asarray(a, np.float64) - b).max() / np.abs(b).max())
+
+
+def _relK(a, b):
+    """K parity as north_star states it: max over entries of |K - K_ref| / |K_ref| (K > 0 always)"""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float((np.abs(a - b) / np.abs(b)).max())
 
 
 SHAPES = [
@@ -47,8 +56,8 @@ def test_fast_general_xy(gpu, A, B, T, d, dtype):
     K1 = ops.gram_fwd(Xg, Yg, 1.0 / h)
     K2, g2 = ops.gram_fwd_bwd(Xg, Yg, 1.0 / h, grad_out=gog)
     torch.cuda.synchronize()
-    assert _rel(K1.cpu().numpy(), Kref) < TOL
-    assert _rel(K2.cpu().numpy(), Kref) < TOL
+    assert _relK(K1.cpu().numpy(), Kref) < TOL
+    assert _relK(K2.cpu().numpy(), Kref) < TOL
     assert _rel(g2.cpu().numpy(), gref) < TOL
     # and it agrees with the generic kernel
     K3, g3 = ops.gram_fwd_bwd(Xg, Yg, 1.0 / h, grad_out=gog, force_generic=True)
@@ -75,7 +84,7 @@ def test_fast_symmetric(gpu, N, T, d, weights):
     K, g = ops.gram_fwd_bwd(Xg, Xg, 1.0 / h, grad_out=gog, sym=sym, y_is_x=True)
     torch.cuda.synchronize()
     Kn = K.cpu().numpy()
-    assert _rel(Kn, Kref) < TOL
+    assert _relK(Kn, Kref) < TOL
     assert np.array_equal(Kn, Kn.T)  # mirrored entries are the same solve
     assert _rel(g.cpu().numpy(), gref) < TOL
 
@@ -87,7 +96,7 @@ def test_fast_far_from_origin(gpu):
     X = _paths(12, 64, 7, 11, offset=100.0)
     Kref, gref = O.gram_backward(X, X, None, O.RBF, 1.0, 0)
     K, g = ops.gram_fwd_bwd(torch.as_tensor(X, device=gpu), torch.as_tensor(X, device=gpu), 1.0, y_is_x=True)
-    assert _rel(K.cpu().numpy(), Kref) < TOL
+    assert _relK(K.cpu().numpy(), Kref) < TOL
     assert _rel(g.cpu().numpy(), gref) < TOL
 
 
@@ -105,7 +114,7 @@ def test_fast_c4_rows(gpu):
     assert np.array_equal(Kn, Kn.T)
     for rows in [(0, 4), (511, 515), (1020, 1024)]:
         Kref, gref = C.gram_fwd_bwd(X.numpy(), X.numpy(), 1.0, 0, rows=rows)
-        assert _rel(Kn[rows[0]:rows[1]], Kref) < TOL
+        assert _relK(Kn[rows[0]:rows[1]], Kref) < TOL
         assert np.abs(gn[rows[0]:rows[1]] - gref).max() / np.abs(gref).max() < TOL
 
 
@@ -118,11 +127,11 @@ def test_fast_edge_shapes(gpu, A, B, T, d):
     Kref, gref = C.gram_fwd_bwd(X, Y, 0.8, 0)
     Xg, Yg = torch.as_tensor(X, device=gpu), torch.as_tensor(Y, device=gpu)
     K, g = ops.gram_fwd_bwd(Xg, Yg, 1 / 0.8)
-    assert _rel(K.cpu().numpy(), Kref) < TOL and _rel(g.cpu().numpy(), gref) < TOL
+    assert _relK(K.cpu().numpy(), Kref) < TOL and _rel(g.cpu().numpy(), gref) < TOL
     if A == B:
         Kr, gr = C.gram_fwd_bwd(X, X, 0.8, 0)
         K2, g2 = ops.gram_fwd_bwd(Xg, Xg, 1 / 0.8, y_is_x=True)
-        assert _rel(K2.cpu().numpy(), Kr) < TOL and _rel(g2.cpu().numpy(), gr) < TOL
+        assert _relK(K2.cpu().numpy(), Kr) < TOL and _rel(g2.cpu().numpy(), gr) < TOL
 
 
 def test_fast_fp64_io_symmetric_and_noncontiguous(gpu):
@@ -136,7 +145,7 @@ def test_fast_fp64_io_symmetric_and_noncontiguous(gpu):
     Kref, gref = O.gram_backward(Xv.cpu().numpy(), Xv.cpu().numpy(), None, O.RBF, 1.0, 0)
     K, g = ops.gram_fwd_bwd(Xv, Xv, 1.0, y_is_x=True)
     assert K.dtype == torch.float64 and g.dtype == torch.float64
-    assert _rel(K.cpu().numpy(), Kref) < 1e-6 and _rel(g.cpu().numpy(), gref) < TOL
+    assert _relK(K.cpu().numpy(), Kref) < SELF and _rel(g.cpu().numpy(), gref) < TOL
 
 
 def test_argument_errors(gpu):
@@ -168,4 +177,4 @@ def test_forward_only_symmetric_solve(gpu, N, T, d):
     K1 = ops.gram_fwd(X, X, 1.0, y_is_x=True)
     K0 = ops.gram_fwd(X, X.clone(), 1.0)
     assert torch.equal(K1, K1.T)
-    assert _rel(K1.cpu().numpy(), K0.double().cpu().numpy()) < 1e-6
+    assert _relK(K1.cpu().numpy(), K0.double().cpu().numpy()) < SELF

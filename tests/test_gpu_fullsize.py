@@ -18,11 +18,20 @@ from sigsvgd_amd.utils.synthetic import synthetic_inputs
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-5  # north_star tolerance: K relative to max|K|, gradients relative to max|grad|
+# two fp32-sweep solves of one pair that differ in orientation (the symmetric launch solves (i, j), the ordered one also
+# (j, i)) or launch geometry agree to a few ulps PER ENTRY; both are within TOL of the fp64 oracle
+SELF = 4e-6
 
 
 def _rel(a, b):
     a = np.asarray(a, np.float64)
     return float(np.abs(a - b).max() / np.abs(b).max())
+
+
+def _relK(a, b):
+    """K parity as north_star states it: max over entries of |K - K_ref| / |K_ref| (K > 0 always)"""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float((np.abs(a - b) / np.abs(b)).max())
 
 
 def test_c2_full(gpu):
@@ -35,8 +44,8 @@ def test_c2_full(gpu):
     K2, g2 = ops.gram_fwd_bwd(Xg, Xg, 1.0)
     Kn, gn = K.cpu().numpy(), g.cpu().numpy()
     assert np.isfinite(Kn).all() and np.isfinite(gn).all() and np.array_equal(Kn, Kn.T)
-    assert _rel(Kn, Kref) < TOL and _rel(gn, gref) < TOL
-    assert _rel(K2.cpu().numpy(), Kref) < TOL and _rel(g2.cpu().numpy(), gref) < TOL
+    assert _relK(Kn, Kref) < TOL and _rel(gn, gref) < TOL
+    assert _relK(K2.cpu().numpy(), Kref) < TOL and _rel(g2.cpu().numpy(), gref) < TOL
     # one full iteration against the oracle's update
     v, Xn = ops.svgd_phi(K, score.to(gpu), g, X=Xg, lr=1e-3)
     vref = -((Kref @ score.numpy().astype(np.float64).reshape(128, -1) - gref.reshape(128, -1)) / 128)
@@ -55,11 +64,11 @@ def test_c3_full(gpu):
     torch.cuda.synchronize()
     Kn, gn = K.cpu().numpy(), g.cpu().numpy()
     assert np.isfinite(Kn).all() and np.isfinite(gn).all() and np.array_equal(Kn, Kn.T)
-    assert _rel(K2.cpu().numpy(), Kn.astype(np.float64)) < 1e-6 and _rel(g2.cpu().numpy(), gn.astype(np.float64)) < TOL
-    assert _rel(K3.cpu().numpy(), Kn.astype(np.float64)) < 1e-6
+    assert _relK(K2.cpu().numpy(), Kn.astype(np.float64)) < SELF and _rel(g2.cpu().numpy(), gn.astype(np.float64)) < TOL
+    assert _relK(K3.cpu().numpy(), Kn.astype(np.float64)) < SELF
     for rows in [(0, 4), (254, 258), (508, 512)]:
         Kref, gref = C.gram_fwd_bwd(X.numpy(), X.numpy(), 1.0, 0, rows=rows)
-        assert _rel(Kn[rows[0]:rows[1]], Kref) < TOL
+        assert _relK(Kn[rows[0]:rows[1]], Kref) < TOL
         assert np.abs(gn[rows[0]:rows[1]] - gref).max() / np.abs(gref).max() < TOL
     # the sharded step's ownership at this size: 4 shares
     Ksum = torch.zeros_like(K, dtype=torch.float64)
@@ -68,7 +77,7 @@ def test_c3_full(gpu):
         Kp, gp = ops.gram_sym_partial(Xg, 1.0, off, 4)
         Ksum += Kp.double()
         gsum += gp
-    assert _rel(Ksum.cpu().numpy(), Kn.astype(np.float64)) < 1e-6 and _rel(gsum.cpu().numpy(), gn.astype(np.float64)) < TOL
+    assert _relK(Ksum.cpu().numpy(), Kn.astype(np.float64)) < SELF and _rel(gsum.cpu().numpy(), gn.astype(np.float64)) < TOL
 
 
 def test_c5_full(gpu):
@@ -86,7 +95,7 @@ def test_c5_full(gpu):
     gmax = None
     for rows in [(0, 2), (2047, 2049), (4094, 4096)]:
         Kref, gref = C.gram_fwd_bwd(X.numpy(), X.numpy(), 1.0, 0, rows=rows)
-        assert _rel(Kn[rows[0]:rows[1]], Kref) < TOL
+        assert _relK(Kn[rows[0]:rows[1]], Kref) < TOL
         gmax = np.abs(gref).max()
         assert np.abs(gn[rows[0]:rows[1]] - gref).max() / gmax < TOL
     # the 8 tile-cyclic shares of the sharded step sum to the full launch (K exactly disjoint, gradient to rounding)

@@ -9,6 +9,9 @@ from oracle import sigkernel_oracle as O
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
+# two fp32-sweep solves of one pair that differ in orientation (the symmetric launch solves (i, j), the ordered one also
+# (j, i)) or launch geometry agree to a few ulps PER ENTRY; both are within TOL of the fp64 oracle
+SELF = 4e-6
 
 
 def _paths(A, T, d, seed, scale=0.05):
@@ -18,6 +21,12 @@ def _paths(A, T, d, seed, scale=0.05):
 
 def _rel(a, b):
     return float(np.abs(np.asarray(a, np.float64) - b).max() / np.abs(b).max())
+
+
+def _relK(a, b):
+    """K parity as north_star states it: max over entries of |K - K_ref| / |K_ref| (K > 0 always)"""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float((np.abs(a - b) / np.abs(b)).max())
 
 
 @pytest.mark.parametrize("A,B,T,d", [(5, 6, 128, 14), (3, 9, 128, 7), (6, 5, 65, 3), (4, 4, 66, 2),
@@ -34,8 +43,8 @@ def test_long_fwd_bwd(gpu, A, B, T, d, dtype):
     K1 = ops.gram_fwd(Xg, Yg, 1.0 / h)
     K2, g2 = ops.gram_fwd_bwd(Xg, Yg, 1.0 / h, grad_out=gog)
     torch.cuda.synchronize()
-    assert _rel(K1.cpu().numpy(), Kref) < TOL
-    assert _rel(K2.cpu().numpy(), Kref) < TOL
+    assert _relK(K1.cpu().numpy(), Kref) < TOL
+    assert _relK(K2.cpu().numpy(), Kref) < TOL
     assert _rel(g2.cpu().numpy(), gref) < TOL
     if T * d <= 128 * 14:  # the coverage kernel's compact layout tops out at T=128, d=14 (LDS)
         K3, g3 = ops.gram_fwd_bwd(Xg, Yg, 1.0 / h, grad_out=gog, force_generic=True)
@@ -50,7 +59,7 @@ def test_long_self_gram_c5_shape(gpu):
     Xg = X.to(gpu)
     K, g = ops.gram_fwd_bwd(Xg, Xg, 1.0, y_is_x=True)
     Kref, gref = C.gram_fwd_bwd(X.numpy(), X.numpy(), 1.0, 0)
-    assert _rel(K.cpu().numpy(), Kref) < TOL and _rel(g.cpu().numpy(), gref) < TOL
+    assert _relK(K.cpu().numpy(), Kref) < TOL and _rel(g.cpu().numpy(), gref) < TOL
     K2, g2 = ops.gram_fwd_bwd(Xg, Xg, 1.0, sym=True, y_is_x=True)
     assert _rel(g2.cpu().numpy(), 2 * gref) < TOL
 
@@ -68,10 +77,10 @@ def test_long_symmetric_solve_equals_ordered_pairs(gpu, N, T, d, dtype):
     Kref, gref = C.gram_fwd_bwd(X, X, h, 0, grad_out=go.astype(np.float64))
     Xg, gog = torch.as_tensor(X, device=gpu).to(dtype), torch.as_tensor(go, device=gpu).to(dtype)
     K, g = ops.gram_fwd_bwd(Xg, Xg, 1.0 / h, grad_out=gog, y_is_x=True)
-    assert _rel(K.cpu().numpy(), Kref) < TOL and _rel(g.cpu().numpy(), gref) < TOL
+    assert _relK(K.cpu().numpy(), Kref) < TOL and _rel(g.cpu().numpy(), gref) < TOL
     assert torch.equal(K, K.T)  # mirrored stores
     Ko, g_o = ops.gram_fwd_bwd(Xg, Xg, 1.0 / h, grad_out=gog)  # ordered pairs on the same kernel family
-    assert _rel(K.cpu().numpy(), Ko.double().cpu().numpy()) < 1e-6
+    assert _relK(K.cpu().numpy(), Ko.double().cpu().numpy()) < SELF
     assert _rel(g.cpu().numpy(), g_o.double().cpu().numpy()) < 1e-5
     # ones weights, and the sym=True weighting (grad_out symmetrised)
     K1, g1 = ops.gram_fwd_bwd(Xg, Xg, 1.0 / h, y_is_x=True)
@@ -117,7 +126,7 @@ def test_long_symmetric_large_property(gpu):
     K, g = ops.gram_fwd_bwd(Xg, Xg, 1.0, y_is_x=True)
     Ko, g_o = ops.gram_fwd_bwd(Xg, Xg.clone(), 1.0)
     assert torch.equal(K, K.T)
-    assert _rel(K.cpu().numpy(), Ko.double().cpu().numpy()) < 1e-6
+    assert _relK(K.cpu().numpy(), Ko.double().cpu().numpy()) < SELF
     assert _rel(g.cpu().numpy(), g_o.double().cpu().numpy()) < 1e-5
     assert torch.isfinite(g).all()
 
@@ -140,12 +149,12 @@ def test_stored_forward_quadrant_kernel(gpu, A, B, T, d, sym, scale):
     K, g = ops.gram_fwd_bwd(Xg, Xg if sym else Yg, 1.0, y_is_x=sym, stored_forward=True)
     torch.cuda.synchronize()
     assert bool(torch.isfinite(g).all())
-    assert _rel(K.cpu().numpy(), Kref) < TOL and _rel(g.cpu().numpy(), gref) < TOL
+    assert _relK(K.cpu().numpy(), Kref) < TOL and _rel(g.cpu().numpy(), gref) < TOL
     # forward-only launch of the same kernel, and fp64 I/O
     Kf = ops.gram_fwd(Xg, Xg if sym else Yg, 1.0, y_is_x=sym, stored_forward=True)
-    assert _rel(Kf.cpu().numpy(), Kref) < TOL
+    assert _relK(Kf.cpu().numpy(), Kref) < TOL
     K64, g64 = ops.gram_fwd_bwd(Xg.double(), (Xg if sym else Yg).double(), 1.0, y_is_x=sym, stored_forward=True)
-    assert K64.dtype == torch.float64 and _rel(K64.cpu().numpy(), Kref) < TOL and _rel(g64.cpu().numpy(), gref) < TOL
+    assert K64.dtype == torch.float64 and _relK(K64.cpu().numpy(), Kref) < TOL and _rel(g64.cpu().numpy(), gref) < TOL
     if sym:
         assert np.array_equal(K.cpu().numpy(), K.cpu().numpy().T)
         # weighted backward (grad_out) and the sharded partial solve: two shares sum to the full result

@@ -10,6 +10,9 @@ from oracle import c_oracle as C
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-5
+# two fp32-sweep solves of one pair that differ in orientation (the symmetric launch solves (i, j), the ordered one also
+# (j, i)) or launch geometry agree to a few ulps PER ENTRY; both are within TOL of the fp64 oracle
+SELF = 4e-6
 
 
 def _paths(A, T, d, seed, scale=0.05):
@@ -19,6 +22,12 @@ def _paths(A, T, d, seed, scale=0.05):
 
 def _rel(a, b):
     return float(np.abs(np.asarray(a, np.float64) - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+def _relK(a, b):
+    """K parity as north_star states it: max over entries of |K - K_ref| / |K_ref| (K > 0 always)"""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float((np.abs(a - b) / np.abs(b)).max())
 
 
 @pytest.mark.parametrize("A,B", [(1, 1), (1, 9), (9, 1), (3, 5), (8, 300), (300, 8), (67, 263)])
@@ -34,8 +43,8 @@ def test_ordered_launch_shapes(gpu, A, B):
     K, g = ops.gram_fwd_bwd(Xg, Yg, 1.0 / h, grad_out=torch.as_tensor(go, device=gpu, dtype=torch.float32))
     Kf = ops.gram_fwd(Xg, Yg, 1.0 / h)
     torch.cuda.synchronize()
-    assert _rel(K.cpu().numpy(), Kref) < TOL
-    assert _rel(Kf.cpu().numpy(), Kref) < TOL
+    assert _relK(K.cpu().numpy(), Kref) < TOL
+    assert _relK(Kf.cpu().numpy(), Kref) < TOL
     assert _rel(g.cpu().numpy(), gref) < TOL
 
 
@@ -51,8 +60,8 @@ def test_symmetric_launch_shapes(gpu, N):
     K, g = ops.gram_fwd_bwd(Xg, Xg, 1.0 / h, y_is_x=True)
     Kf = ops.gram_fwd(Xg, Xg, 1.0 / h, y_is_x=True)
     torch.cuda.synchronize()
-    assert _rel(K.cpu().numpy(), Kref) < TOL
-    assert _rel(Kf.cpu().numpy(), Kref) < TOL
+    assert _relK(K.cpu().numpy(), Kref) < TOL
+    assert _relK(Kf.cpu().numpy(), Kref) < TOL
     assert _rel(g.cpu().numpy(), gref) < TOL
     assert torch.equal(K, K.T)
 
@@ -73,7 +82,7 @@ def test_partial_shares_sum_to_full(gpu, N, stride):
         Ks += Kp
         gs += gp
     torch.cuda.synchronize()
-    assert _rel(Ks.cpu().numpy(), K.double().cpu().numpy()) < 1e-6
+    assert _relK(Ks.cpu().numpy(), K.double().cpu().numpy()) < SELF
     assert _rel(gs.cpu().numpy(), g.double().cpu().numpy()) < 1e-5
 
 
@@ -91,12 +100,12 @@ def test_paths_beyond_128_points(gpu):
     Xg = torch.as_tensor(X, device=gpu)
     Ks, gs = ops.gram_fwd_bwd(Xg, Xg, 1.0 / h, y_is_x=True)
     torch.cuda.synchronize()
-    assert _rel(K.cpu().numpy(), Kref) < TOL and _rel(g.cpu().numpy(), gref) < TOL
-    assert _rel(Ks.cpu().numpy(), Ksr) < TOL and _rel(gs.cpu().numpy(), gsr) < TOL
+    assert _relK(K.cpu().numpy(), Kref) < TOL and _rel(g.cpu().numpy(), gref) < TOL
+    assert _relK(Ks.cpu().numpy(), Ksr) < TOL and _rel(gs.cpu().numpy(), gsr) < TOL
 
     X2, Y2 = _paths(3, 190, d, 43, scale=0.03), _paths(4, 190, d, 44, scale=0.03)
     Kref2, _ = C.gram_fwd_bwd(X2, Y2, h, 0, want_grad=False)
     K2 = ops.gram_fwd(torch.as_tensor(X2, device=gpu), torch.as_tensor(Y2, device=gpu), 1.0 / h)
-    assert _rel(K2.cpu().numpy(), Kref2) < TOL
+    assert _relK(K2.cpu().numpy(), Kref2) < TOL
     with pytest.raises(RuntimeError, match="LDS"):
         ops.gram_fwd_bwd(torch.as_tensor(X2, device=gpu), torch.as_tensor(Y2, device=gpu), 1.0 / h)

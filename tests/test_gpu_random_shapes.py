@@ -13,6 +13,12 @@ def _rel(a, b):
     return float(np.abs(np.asarray(a, np.float64) - b).max() / max(np.abs(b).max(), 1e-300))
 
 
+def _relK(a, b):
+    """K parity as north_star states it: max over entries of |K - K_ref| / |K_ref| (K > 0 always)"""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float((np.abs(a - b) / np.abs(b)).max())
+
+
 def _cases(n, seed):
     rng = np.random.default_rng(seed)
     out = []
@@ -37,9 +43,9 @@ def test_random_shape_vs_oracle(gpu, A, B, T, d, n, h, seed):
     Kref, gref = C.gram_fwd_bwd(X, Y, h, n, grad_out=go.astype(np.float64))
     Xg, Yg, gog = (torch.as_tensor(t, device=gpu) for t in (X, Y, go))
     K, g = ops.gram_fwd_bwd(Xg, Yg, 1.0 / h, n, grad_out=gog)
-    assert _rel(K.cpu().numpy(), Kref) < TOL and _rel(g.cpu().numpy(), gref) < TOL
+    assert _relK(K.cpu().numpy(), Kref) < TOL and _rel(g.cpu().numpy(), gref) < TOL
     assert _rel(ops.gram_fwd(Xg, Yg, 1.0 / h, n).cpu().numpy(), Kref) < TOL
     if A == B:  # the symmetric solve on X itself
         Ks, gs = C.gram_fwd_bwd(X, X, h, n, grad_out=go.astype(np.float64))
         K2, g2 = ops.gram_fwd_bwd(Xg, Xg, 1.0 / h, n, grad_out=gog, y_is_x=True)
-        assert _rel(K2.cpu().numpy(), Ks) < TOL and _rel(g2.cpu().numpy(), gs) < TOL
+        assert _relK(K2.cpu().numpy(), Ks) < TOL and _rel(g2.cpu().numpy(), gs) < TOL

@@ -20,6 +20,12 @@ def _rel(a, b):
     return float(np.abs(np.asarray(a, np.float64) - b).max() / max(np.abs(b).max(), 1e-300))
 
 
+def _relK(a, b):
+    """K parity as north_star states it: max over entries of |K - K_ref| / |K_ref| (K > 0 always)"""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float((np.abs(a - b) / np.abs(b)).max())
+
+
 @pytest.mark.parametrize("T,d", [(64, 7), (33, 3), (128, 14), (96, 5)])
 @pytest.mark.parametrize("scale,h", [(0.01, 1.0), (0.05, 0.1), (0.05, 10.0), (0.15, 1.0), (0.3, 4.0), (0.02, 0.02)])
 def test_regimes_self_gram(gpu, T, d, scale, h):
@@ -35,8 +41,8 @@ def test_regimes_self_gram(gpu, T, d, scale, h):
     K, g = ops.gram_fwd_bwd(Xg, Xg, 1.0 / h, y_is_x=True)
     Ko, go_ = ops.gram_fwd_bwd(Xg, Xg.clone(), 1.0 / h)
     assert torch.isfinite(K).all() and torch.isfinite(g).all()
-    assert _rel(K.cpu().numpy(), Kref) < TOL, ("K sym", Kref.max())
-    assert _rel(Ko.cpu().numpy(), Kref) < TOL, ("K ordered", Kref.max())
+    assert _relK(K.cpu().numpy(), Kref) < TOL, ("K sym", Kref.max())
+    assert _relK(Ko.cpu().numpy(), Kref) < TOL, ("K ordered", Kref.max())
     assert _rel(g.cpu().numpy(), gref) < TOL, ("grad sym", Kref.max(), np.abs(gref).max())
     assert _rel(go_.cpu().numpy(), gref) < TOL, ("grad ordered", Kref.max(), np.abs(gref).max())
 
@@ -49,7 +55,7 @@ def test_regimes_coverage_kernel(gpu, T, d, n, scale, h):
     X, Y = _paths(6, T, d, 31, scale), _paths(7, T, d, 32, scale)
     Kref, gref = C.gram_fwd_bwd(X, Y, h, n)
     K, g = ops.gram_fwd_bwd(torch.as_tensor(X, device=gpu), torch.as_tensor(Y, device=gpu), 1.0 / h, n)
-    assert _rel(K.cpu().numpy(), Kref) < TOL and _rel(g.cpu().numpy(), gref) < TOL
+    assert _relK(K.cpu().numpy(), Kref) < TOL and _rel(g.cpu().numpy(), gref) < TOL
 
 
 @pytest.mark.parametrize("T,d", [(64, 7), (128, 14), (40, 2)])
@@ -74,7 +80,7 @@ def test_degenerate_paths(gpu, T, d):
     rep[:, T // 2] = rep[:, T // 2 - 1]
     Kref, gref = C.gram_fwd_bwd(rep, mov, 1.0, 0)
     K4, g4 = ops.gram_fwd_bwd(torch.as_tensor(rep, device=gpu), torch.as_tensor(mov, device=gpu), 1.0)
-    assert _rel(K4.cpu().numpy(), Kref) < TOL and _rel(g4.cpu().numpy(), gref) < TOL
+    assert _relK(K4.cpu().numpy(), Kref) < TOL and _rel(g4.cpu().numpy(), gref) < TOL
 
 
 def test_non_finite_inputs_propagate_without_hanging(gpu):
@@ -104,6 +110,6 @@ def test_rough_long_paths_are_solved(gpu):
         Xg = torch.as_tensor(X, device=gpu)
         K, g = ops.gram_fwd_bwd(Xg, Xg, 1.0, y_is_x=True)
         assert torch.isfinite(g).all()
-        assert _rel(K.cpu().numpy(), Kref) < TOL and _rel(g.cpu().numpy(), gref) < TOL, (T, d, float(Kref.max()))
+        assert _relK(K.cpu().numpy(), Kref) < TOL and _rel(g.cpu().numpy(), gref) < TOL, (T, d, float(Kref.max()))
         K2, g2 = ops.gram_fwd_bwd(Xg, Xg.clone(), 1.0)
-        assert _rel(K2.cpu().numpy(), Kref) < TOL and _rel(g2.cpu().numpy(), gref) < TOL
+        assert _relK(K2.cpu().numpy(), Kref) < TOL and _rel(g2.cpu().numpy(), gref) < TOL

@@ -309,3 +309,15 @@ def test_constant_bandwidth_detection():
     assert k._constant_bandwidth() is None and k._constant_bandwidth() is None
     assert len(calls) == 1  # probed once (the first probe raised), then cached
     assert GaussianKernel(bandwidth_fn=lambda _: -1.0)._constant_bandwidth() is None  # not a usable bandwidth
+    # functions that depend on the data or the shape but would agree on two one-element probes are NOT frozen
+    # (they used to be): any touch of the argument means data-dependent
+    for fn in (lambda sq: sq.median().clamp(min=3.0), lambda sq: max(float(sq.median()), 5.0),
+               lambda sq: sq.shape[0] ** -0.2, lambda sq: 0.3 if sq.numel() < 10 else 0.7):
+        assert GaussianKernel(bandwidth_fn=fn)._constant_bandwidth() is None
+    # reassigning get_bandwidth re-probes instead of keeping the old constant
+    k2 = GaussianKernel(bandwidth_fn=lambda _: 0.2)
+    assert k2._constant_bandwidth() == 0.2
+    k2.get_bandwidth = lambda _: 0.5
+    assert k2._constant_bandwidth() == 0.5
+    k2.get_bandwidth = lambda sq: sq.mean()
+    assert k2._constant_bandwidth() is None
