@@ -25,6 +25,8 @@
  *   sigsvgd_vec_kernel_fused  the same classes with a fixed bandwidth: distance, kernel and summed gradient in one launch
  *   sigsvgd_signature      signatory.signature(path, depth, basepoint) [third-party, absent] as
  *                          called by PathSigKernel, src/kernels/_traj_kernels.py:124-125
+ *   sigsvgd_signature_backward  its autograd backward: PathSigKernel has analytic_grad=False (:92), so the reference
+ *                          differentiates K THROUGH the signature (src/inference/score.py:50-55, svgd.py:41-43)
  *
  * Conventions
  *   - all pointers are DEVICE pointers (HIP), row-major contiguous; the caller owns every buffer
@@ -208,6 +210,13 @@ int sigsvgd_obstacle_cost(const float *x, int N, int knots, int d, const float *
  * with out == NULL only that query is performed. */
 int sigsvgd_signature(const void *X, int N, int L, int C, int depth, int basepoint, int dtype, void *out,
                       long long *channels, void *stream);
+
+/* grad_X[N,L,C] = d( sum_{n,e} grad_sig[n,e] * signature(X)[n,e] ) / dX: the adjoint of sigsvgd_signature for the same
+ * (depth, basepoint).  grad_sig is [N, channels]; fp64 arithmetic (the signature is rebuilt forwards, then unwound point by
+ * point with the group inverse exp(-increment): nothing per point is stored), I/O in `dtype`.  depth <= 8 and
+ * 6 * channels doubles of LDS (channels <= ~3000), else SIGSVGD_E_UNSUPPORTED. */
+int sigsvgd_signature_backward(const void *X, const void *grad_sig, int N, int L, int C, int depth, int basepoint, int dtype,
+                               void *grad_X, void *stream);
 
 #ifdef __cplusplus
 }

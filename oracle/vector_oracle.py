@@ -138,6 +138,35 @@ def signature(X, depth, basepoint=True):
     return out
 
 
+def signature_vjp(X, grad_sig, depth, basepoint=True):
+    """d sum(grad_sig * signature(X)) / dX by reverse-mode differentiation of the SAME recursion (torch fp64 autograd over
+    Chen's identity written with tensor products): the reference for the HIP adjoint `sigsvgd_signature_backward`.  What
+    the reference itself runs here is signatory's backward (absent); tests pin this function with central finite
+    differences of `signature` above."""
+    import torch
+
+    x = torch.tensor(np.asarray(X, np.float64), requires_grad=True)
+    N, L, C = x.shape
+    pts = torch.cat([torch.zeros(N, 1, C, dtype=torch.float64), x], 1) if basepoint else x
+    inc = pts[:, 1:] - pts[:, :-1]
+    S = [torch.zeros(N, C**k, dtype=torch.float64) for k in range(1, depth + 1)]
+    for t in range(inc.shape[1]):
+        D = inc[:, t]
+        E = [D]
+        for m in range(2, depth + 1):
+            E.append((E[-1][:, :, None] * D[:, None, :]).reshape(N, -1) / m)
+        new = []
+        for k in range(1, depth + 1):
+            acc = S[k - 1] + E[k - 1]
+            for j in range(1, k):
+                acc = acc + (S[j - 1][:, :, None] * E[k - j - 1][:, None, :]).reshape(N, -1)
+            new.append(acc)
+        S = new
+    sig = torch.cat(S, 1)
+    (g,) = torch.autograd.grad((sig * torch.as_tensor(np.asarray(grad_sig, np.float64))).sum(), x)
+    return sig.detach().numpy(), g.numpy()
+
+
 def signature_bruteforce(x, depth, basepoint=True):
     """Independent check for ONE small path [L, C]: level k as the iterated integral over the simplex
     of the piecewise-linear path = sum over non-decreasing segment tuples t_1 <= ... <= t_k of

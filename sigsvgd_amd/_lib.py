@@ -15,7 +15,7 @@ _CSRC = os.path.join(_PKG, "csrc")
 # SIGSVGD_LIB_PATH: A/B benchmarking of two builds on the same GPU box (scripts/ab.py); never set in tests
 LIB_PATH = os.environ.get("SIGSVGD_LIB_PATH") or os.path.join(_PKG, "libsigsvgd_hip.so")
 SOURCES = ["capi.hip", "gram_generic.hip", "gram_fast.hip", "gram_quad.hip", "svgd_phi.hip",
-           "vec_kernels.hip", "vec_fused.hip", "cost_kernels.hip"]
+           "vec_kernels.hip", "vec_fused.hip", "cost_kernels.hip", "sig_backward.hip"]
 HEADERS = [os.path.join(_CSRC, "sig_common.h"), os.path.join(_PKG, "..", "include", "sigsvgd_hip.h")]
 
 # mirror of include/sigsvgd_hip.h
@@ -41,6 +41,7 @@ EXPORTS = [
     "sigsvgd_vec_kernel",
     "sigsvgd_vec_kernel_fused",
     "sigsvgd_signature",
+    "sigsvgd_signature_backward",
     "sigsvgd_obstacle_cost",
 ]
 
@@ -145,6 +146,8 @@ def load():
     L.sigsvgd_obstacle_cost.argtypes = [vp, ci, ci, ci, vp, vp, vp, ci, vp, vp, vp, ci, cf, cf, vp, vp, vp, vp]
     L.sigsvgd_signature.restype = ci
     L.sigsvgd_signature.argtypes = [vp, ci, ci, ci, ci, ci, ci, vp, ctypes.POINTER(ctypes.c_longlong), vp]
+    L.sigsvgd_signature_backward.restype = ci
+    L.sigsvgd_signature_backward.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, vp, vp]
     if L.sigsvgd_abi_version() != ABI_VERSION:
         raise RuntimeError("sigsvgd_amd: libsigsvgd_hip.so ABI version mismatch; rebuild it")
     _lib = L

@@ -42,6 +42,8 @@ int obstacle_cost_launch(const float *x, int N, int Kx, int d, const float *star
                          float *cost, float *traj, float *grad_x, hipStream_t stream);
 int signature_launch(const void *X, int N, int L, int C, int depth, int basepoint, int dtype, void *out,
                      hipStream_t stream);
+int signature_bwd_launch(const void *X, const void *gsig, int N, int L, int C, int depth, int basepoint, int dtype, void *gX,
+                         long long sigdim, hipStream_t stream);
 
 static int check_common(const void *X, const void *Y, int A, int B, int T, int d, int dtype, double inv_h,
                         int n, int kind, const void *K_out)
@@ -338,6 +340,26 @@ int sigsvgd_signature(const void *X, int N, int L, int C, int depth, int basepoi
         return SIGSVGD_E_BADARG;
     }
     return signature_launch(X, N, L, C, depth, basepoint, dtype, out, static_cast<hipStream_t>(stream));
+}
+
+int sigsvgd_signature_backward(const void *X, const void *grad_sig, int N, int L, int C, int depth, int basepoint, int dtype,
+                               void *grad_X, void *stream)
+{
+    if (N < 1 || L < 1 || C < 1 || depth < 1 || (dtype != SIGSVGD_F32 && dtype != SIGSVGD_F64)) {
+        set_error("signature_backward: bad arguments N=%d L=%d C=%d depth=%d dtype=%d", N, L, C, depth, dtype);
+        return SIGSVGD_E_BADARG;
+    }
+    if (!X || !grad_sig || !grad_X) {
+        set_error("signature_backward: null pointer argument");
+        return SIGSVGD_E_BADARG;
+    }
+    const long long ch = signature_channels(C, depth);
+    if (ch < 0) {
+        set_error("signature_backward: C=%d depth=%d overflows", C, depth);
+        return SIGSVGD_E_UNSUPPORTED;
+    }
+    Range range("sigsvgd_signature_backward");
+    return signature_bwd_launch(X, grad_sig, N, L, C, depth, basepoint, dtype, grad_X, ch, static_cast<hipStream_t>(stream));
 }
 
 } // extern "C"

@@ -571,7 +571,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
             if (GRAD) {
                 // ---- phase 3: reverse sweep (U recurrence; S replaces K_fwd slot by slot) -----------------
                 float cur = 1.f, downA = 1.f, downB = 1.f, V = 0.f; // `down` persists (lane 63 keeps U[P][.] = 1), alternating as above
-                float Sb = 0.f, Sc = 0.f, Nb = 0.f, s0 = 0.f;
+                float Sb = 0.f, eprev = 0.f;
                 f32x2 acc[DPAD / 2]; // packed pairs: the contraction runs on v_pk_fma_f32
 #pragma unroll
                 for (int c = 0; c < DPAD / 2; ++c) acc[c] = f32x2{0.f, 0.f};
@@ -590,7 +590,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
                 // sum_m R*G[m,n] * x~_m rides a wave rotation (v_add_f32 with a wave_rol:1 DPP source) and
                 // never needs a transposed pass: finished columns wrap past lane 0 through lanes that
                 // are already idle, and after the last step column n sits in lane (64 - n) & 63.
-                float t0 = 0.f, tacc[DPAD];
+                float tacc[DPAD];
 #pragma unroll
                 for (int c = 0; c < DPAD; ++c) tacc[c] = 0.f;
 
@@ -599,34 +599,41 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
                 // one iteration of the phase-4 pass (below); `gcu`, `ycu`: G[l][n] and the y~_n row, fetched one
                 // iteration ahead so that the LDS latency is off the chain and one s_waitcnt serves the iteration
                 auto grad_part = [&](float Snew, bool accumulate, float gcu, const f32x2 *ycu) {
-                    const float Na = dpp_shr1_zero(Snew); // S[l-1, q+1]
-                    float dN = Na - Nb;
-                    asm volatile("" : "+v"(dN)); // keeps hipcc from SLP-packing the two differences (costs 2 moves)
-                    const float R = (Sc - Sb) + dN;
-                    Sc = Sb;
+                    // R[l][q+2] = (S[l][q+2] - S[l][q+1]) - (S[l-1][q+2] - S[l-1][q+1]): the column difference
+                    // e = S[l][q+1] - S[l][q] of this iteration serves this lane on the NEXT iteration and, through the wave
+                    // shift, lane l+1 on this one (its column is one behind) -- each difference is formed once (rounds 1-2
+                    // shifted S and formed the neighbour's difference a second time: one instruction more per iteration,
+                    // 5.38 -> 5.25 ms per C4 launch in a same-box A/B; the result is the same bit for bit)
+                    const float e = Sb - Snew;
+                    const float up = dpp_shr1_zero(e); // lane l-1: S[l-1][q+2] - S[l-1][q+1]; lane 0: no row above
+                    const float R = eprev - up;
+                    eprev = e;
                     Sb = Snew;
-                    Nb = Na;
                     if (!accumulate) return; // warm-up iteration: only the two-deep history is filled
                     const float rg = R * gcu;
                     const f32x2 rg2 = {rg, rg};
-                    s0 += rg;
+                    // Both contractions take the DIFFERENCE x~_m - y~_n (one packed subtraction per channel pair, shared
+                    // by the two sides).  Rounds 1-2 accumulated sum R G y~_n and sum R G separately and closed with
+                    // x~_m * sum - sum: when consecutive points lie more than a bandwidth apart, G is concentrated where
+                    // x~_m - y~_n is smallest and that closing cancels catastrophically (gradient error 1e-3 relative to
+                    // its maximum at |step|^2 / h ~ 30, profiles/r03_precision_sweep.md; 3e-6 in this form).
+                    f32x2 df[DPAD / 2];
 #pragma unroll
-                    for (int c = 0; c < DPAD / 2; ++c) acc[c] = __builtin_elementwise_fma(rg2, ycu[c], acc[c]);
+                    for (int c = 0; c < DPAD / 2; ++c) df[c] = xc2[c] - ycu[c];
+#pragma unroll
+                    for (int c = 0; c < DPAD / 2; ++c) acc[c] = __builtin_elementwise_fma(rg2, df[c], acc[c]);
                     // pin the running sums here: the contraction must stay inside its step
 #pragma unroll
                     for (int c = 0; c < DPAD / 2; ++c) asm volatile("" : "+v"(acc[c]));
-                    asm volatile("" : "+v"(s0));
                     if (SYM) {
-                        t0 = add_rol1(t0, rg);
 #pragma unroll
                         for (int c = 0; c < DPAD / 2; ++c) {
-                            const f32x2 pr = rg2 * xc2[c];
+                            const f32x2 pr = rg2 * df[c];
                             tacc[2 * c] = add_rol1(tacc[2 * c], pr[0]);
                             if (2 * c + 1 < DC) tacc[2 * c + 1] = add_rol1(tacc[2 * c + 1], pr[1]);
                         }
 #pragma unroll
                         for (int c = 0; c < DPAD; ++c) asm volatile("" : "+v"(tacc[c]));
-                        asm volatile("" : "+v"(t0));
                     }
                 };
 
@@ -678,7 +685,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
                 }
 
                 SIG_STAMP(4)
-                // row-side gradient of this pair: -(2/h) * sum_n R G (x~_m - y~_n)
+                // row-side gradient of this pair: -(2/h) * sum_n R G (x~_m - y~_n); column side: the same sum over m, negated
                 float w_ij = 1.f, w_ji = 1.f;
                 if (a.go) {
                     w_ij = (float)load_any(a.go, (size_t)i * a.B + j, io64);
@@ -689,16 +696,14 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
                 }
 #pragma unroll
                 for (int c = 0; c < DPAD; ++c) {
-                    gacc[c] += (double)(w_ij * m2h * (xc2[c / 2][c % 2] * s0 - acc[c / 2][c % 2]));
+                    gacc[c] += (double)(w_ij * m2h * acc[c / 2][c % 2]);
                 }
 
                 if (SYM && j != i && lane < RING) { // (RING = 32: the mirror lanes hold the same sums in another order)
                     // park the column-side result in this wave's own G region ([lane][c]) for the block sum
                     const int ncol = (RING - lrow) & RM; // the column whose finished sums this lane ended up with
-                    const float *yr = yf + ncol * YFS;
 #pragma unroll
-                    for (int c = 0; c < DPAD; ++c)
-                        Gs[ncol * DPAD + c] = (ncol <= P) ? w_ji * m2h * (yr[c] * t0 - tacc[c]) : 0.f;
+                    for (int c = 0; c < DPAD; ++c) Gs[ncol * DPAD + c] = (ncol <= P) ? -(w_ji * m2h) * tacc[c] : 0.f;
                 } else if (SYM) {
 #pragma unroll
                     for (int c = 0; c < DPAD; ++c) Gs[lane * DPAD + c] = 0.f; // diagonal pair: no column side
@@ -828,7 +833,7 @@ int device_cu_count()
 TileMap make_tilemap(int ntile, int off, int stride, bool fold)
 {
     TileMap t;
-    t.off = off; t.stride = stride; t.ntile = ntile;
+    t.off = off; t.stride = stride; t.ntile = ntile; t.fold = fold ? 1 : 0;
     auto count_upto = [&](int hi) { return hi >= off ? (hi - off) / stride + 1 : 0; }; // tiles off + k*stride <= hi
     if (!fold) {
         t.m0 = t.owned = count_upto(ntile - 1);
@@ -875,7 +880,7 @@ inline int grad_wg_per_cu(int T, int d) { return (d <= 8 && T <= 32) ? 3 : 1; }
 using FastGeom = GradGeom;
 FastGeom fast_geometry(int A, int B, int T, int d, bool sym, const TileMap &tm)
 {
-    return grad_geometry(A, B, T * d, sym, tm.off, tm.stride, tm.owned > tm.m0, grad_nw(T, d),
+    return grad_geometry(A, B, T * d, sym, tm.off, tm.stride, tm.fold != 0, grad_nw(T, d),
                          (long long)cu_count() * grad_wg_per_cu(T, d));
 }
 FastGeom fast_geometry(int A, int B, int T, int d, bool sym)
@@ -907,7 +912,7 @@ template <int DPAD, int NW, int RING = 64>
 int launch_variant(const GramProblem &p, FastArgs &a, bool grad, bool sym)
 {
     // items of this launch: (owned row tile, column); symmetric launches only the columns from the tile's first row on
-    const TileMap tm = make_tilemap((p.A + NW - 1) / NW, a.tm.off, a.tm.stride, a.tm.owned > a.tm.m0);
+    const TileMap tm = make_tilemap((p.A + NW - 1) / NW, a.tm.off, a.tm.stride, a.tm.fold != 0);
     if (tm.owned <= 0) return SIGSVGD_OK;
     const long long total = tm.start(tm.owned, p.B, NW, sym ? 1 : 0);
     if (total <= 0) return SIGSVGD_OK;

@@ -139,15 +139,18 @@ __device__ __forceinline__ float q_wave_sum63(float v)
 }
 // G[m][n] = 2^(-log2(e)/h * |x~_m - y~_n|^2) in fp32, from the DIFFERENCES (the expanded form loses 6e-8 of its largest
 // term, 1e-5 of G for rough paths).  ONE expression for the gradient pass and both seam passes: the row-side sums
-// telescope exactly (constant column paths give an exactly zero gradient) only if every point sees the same bits.
+// telescope (constant column paths: zero gradient up to one fp32 rounding) only if every point sees the same bits.
+// The differences are handed back: both gradient contractions take them (sum R G (x~_m - y~_n); the split form
+// x~_m * sum R G - sum R G y~_n cancels catastrophically once consecutive points lie more than a bandwidth apart).
 template <int DPAD>
-__device__ __forceinline__ float q_gval(const float (&xf)[DPAD], const qf32x2 (&y2)[DPAD / 2], float ns32)
+__device__ __forceinline__ float q_gval(const float (&xf)[DPAD], const qf32x2 (&y2)[DPAD / 2], float ns32,
+                                        qf32x2 (&df)[DPAD / 2])
 {
     qf32x2 e2 = qf32x2{0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < DPAD / 2; ++c) {
-        const qf32x2 df = qf32x2{xf[2 * c], xf[2 * c + 1]} - y2[c];
-        e2 = __builtin_elementwise_fma(df, df, e2);
+        df[c] = qf32x2{xf[2 * c], xf[2 * c + 1]} - y2[c];
+        e2 = __builtin_elementwise_fma(df[c], df[c], e2);
     }
     return __builtin_amdgcn_exp2f((e2[0] + e2[1]) * ns32);
 }
@@ -549,7 +552,6 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
             float cap0h0 = 0.f, cap63h0 = 0.f, cap0h1 = 0.f; // S[l][0], S[l][63] of half 0, S[l][64] (first of half 1)
             float xf[DPAD];
             // row-side contraction sums of the band in work: carried over its two reverse visits, sent when the band is done
-            float s0 = 0.f;
             qf32x2 acc[DPAD / 2];
 #pragma unroll
             for (int c = 0; c < DPAD / 2; ++c) acc[c] = qf32x2{0.f, 0.f};
@@ -740,7 +742,6 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                     const float *botb = (below ? hU : ones) + 64 * h; // U[64 b + 64][64 h + q] for lane 63 on step sigma = q + 63
                     if (rev_band != b) { // first reverse quadrant of the band: right boundary column of ones
                         rev_band = b;
-                        s0 = 0.f;
 #pragma unroll
                         for (int c = 0; c < DPAD / 2; ++c) acc[c] = qf32x2{0.f, 0.f};
                         rc = 1.f;
@@ -785,7 +786,7 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                 const float rowmask = (b == 1 && lanep == 0) ? 0.f : 1.f; // point row 64 is contracted in the seam pass
                 const float ns32 = (float)nscale;
                 {
-                    float t0 = 0.f, tacc[DPAD]; // column-side travelling sums (SYM)
+                    float tacc[DPAD]; // column-side travelling sums (SYM)
 #pragma unroll
                     for (int c = 0; c < DPAD; ++c) tacc[c] = 0.f;
                     float capA = 0.f, capB = 0.f;
@@ -817,24 +818,21 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                         Nc = Nb;
                         Nb = Na;
                         Sprev = Scur;
-                        const float gv = q_gval<DPAD>(xf, yr2, ns32);
+                        qf32x2 df[DPAD / 2];
+                        const float gv = q_gval<DPAD>(xf, yr2, ns32, df);
                         const float rg = R * gv;
                         const qf32x2 rg2 = {rg, rg};
-                        s0 += rg;
 #pragma unroll
-                        for (int c = 0; c < DPAD / 2; ++c) acc[c] = __builtin_elementwise_fma(rg2, yr2[c], acc[c]);
+                        for (int c = 0; c < DPAD / 2; ++c) acc[c] = __builtin_elementwise_fma(rg2, df[c], acc[c]);
                         // pin the running sums here: the contraction must stay inside its iteration
 #pragma unroll
                         for (int c = 0; c < DPAD / 2; ++c) asm volatile("" : "+v"(acc[c]));
-                        asm volatile("" : "+v"(s0));
                         if (SYM) {
                             const float rgw = rg * w_ji;
-                            t0 = q_add_ror1(t0, rgw);
 #pragma unroll
-                            for (int c = 0; c < DPAD; ++c) tacc[c] = q_add_ror1(tacc[c], rgw * xf[c]);
+                            for (int c = 0; c < DPAD; ++c) tacc[c] = q_add_ror1(tacc[c], rgw * df[c / 2][c % 2]);
 #pragma unroll
                             for (int c = 0; c < DPAD; ++c) asm volatile("" : "+v"(tacc[c]));
-                            asm volatile("" : "+v"(t0));
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
@@ -849,7 +847,6 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                         float *dst = SIGQ_CRW + (2 * b + h) * (CS * 64) + lv;
 #pragma unroll
                         for (int c = 0; c < DPAD; ++c) dst[c * 64] = tacc[c];
-                        dst[DPAD * 64] = t0;
                     }
                 }
 
@@ -864,17 +861,17 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                         qf32x2 ys2[DPAD / 2];
 #pragma unroll
                         for (int c = 0; c < DPAD / 2; ++c) ys2[c] = reinterpret_cast<const qf32x2 *>(yf + (128 * sc) * YFS)[c];
-                        const float rg = R * q_gval<DPAD>(xf, ys2, ns32);
+                        qf32x2 dfs[DPAD / 2];
+                        const float rg = R * q_gval<DPAD>(xf, ys2, ns32, dfs);
                         const qf32x2 rg2 = {rg, rg};
-                        s0 += rg;
 #pragma unroll
-                        for (int c = 0; c < DPAD / 2; ++c) acc[c] = __builtin_elementwise_fma(rg2, ys2[c], acc[c]);
+                        for (int c = 0; c < DPAD / 2; ++c) acc[c] = __builtin_elementwise_fma(rg2, dfs[c], acc[c]);
                         if (SYM) { // one column, 64 rows: wave sums, lane c adds channel c (all lanes on one address would
                                    // serialise 64-fold in LDS)
                             const float rgw = rg * w_ji;
 #pragma unroll
-                            for (int c = 0; c <= DPAD; ++c) {
-                                const float vsum = q_wave_sum63((c < DPAD) ? rgw * xf[c] : rgw);
+                            for (int c = 0; c < DPAD; ++c) {
+                                const float vsum = q_wave_sum63(rgw * dfs[c / 2][c % 2]);
                                 if (lv == 63) SIGQ_CRW[6 * CS * 64 + (2 * b + sc) * CS + c] = vsum; // seam record [band][column 0 / 64]
                             }
                         }
@@ -889,12 +886,12 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                             float *dst = rowacc + m * RS;
 #pragma unroll
                             for (int c = 0; c < RS; ++c)
-                                if (c < d) atomicAdd(dst + c, w_ij * m2h * (xf[c] * s0 - acc[c / 2][c % 2]));
+                                if (c < d) atomicAdd(dst + c, w_ij * m2h * acc[c / 2][c % 2]);
                         } else {
                             float *dst = SIGQ_RGW + m * 16;
 #pragma unroll
                             for (int c = 0; c < DPAD; ++c)
-                                if (c < d) unsafeAtomicAdd(dst + c, w_ij * m2h * (xf[c] * s0 - acc[c / 2][c % 2]));
+                                if (c < d) unsafeAtomicAdd(dst + c, w_ij * m2h * acc[c / 2][c % 2]);
                         }
                     }
                 }
@@ -907,7 +904,7 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                 // bands' rows before the contraction; lanes take columns n = lane and lane + 64.
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_s_waitcnt(0xc07f);
-                float ps0 = 0.f, part[DPAD], xm[DPAD];
+                float part[DPAD], xm[DPAD];
 #pragma unroll
                 for (int c = 0; c < DPAD; ++c) {
                     part[c] = 0.f;
@@ -924,20 +921,18 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
                     for (int c = 0; c < DPAD; ++c) e2 = __builtin_fmaf(xm[c] - yr[c], xm[c] - yr[c], e2);
                     const float rgn = (n <= P) ? ((Sa - Sz) - (Ta - Tz)) * __builtin_amdgcn_exp2f(e2 * ns32) : 0.f;
-                    ps0 += rgn;
 #pragma unroll
-                    for (int c = 0; c < DPAD; ++c) part[c] = __builtin_fmaf(rgn, yr[c], part[c]);
+                    for (int c = 0; c < DPAD; ++c) part[c] = __builtin_fmaf(rgn, xm[c] - yr[c], part[c]);
                     if (SYM) { // record of point row 64: [half][value][lane], lane = local column
                         float *dst = SIGQ_CRW + (4 + hh) * (CS * 64) + lanep;
 #pragma unroll
-                        for (int c = 0; c < DPAD; ++c) dst[c * 64] = rgn * w_ji * xm[c];
-                        dst[DPAD * 64] = rgn * w_ji;
+                        for (int c = 0; c < DPAD; ++c) dst[c * 64] = rgn * w_ji * (xm[c] - yr[c]);
                     }
                 }
                 // row 64 belongs to band 1's lane 0 accumulators
 #pragma unroll
                 for (int c = 0; c < DPAD; ++c) {
-                    const float v = q_wave_sum63(w_ij * m2h * (xm[c] * ps0 - part[c])); // total in lane 63
+                    const float v = q_wave_sum63(w_ij * m2h * part[c]); // total in lane 63
                     if (lanep == 63 && c < d) { // (row 64 receives nothing else: band 1's lane 0 is masked out of the band flush)
                         if (rowlds) atomicAdd(rowacc + 64 * RS + min(c, RS - 1) + (lanep - 63), v);
                         else unsafeAtomicAdd(SIGQ_RGW + 64 * 16 + c + (lanep - 63), v);
@@ -949,7 +944,7 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
 
         if (GRAD && SYM) {
             // close the column-side sums of y_j over the rows of the tile:
-            // d/dy_n = -(2/h) * (y~_n * sum_m w R G - sum_m w R G x~_m)
+            // d/dy_n = -(2/h) * sum_m w R G (y~_n - x~_m) = +(2/h) * (the recorded sums of w R G (x~_m - y~_n))
             // The eight wavefronts' records are added in wave order (rounds 1-2 joined them with LDS atomics, whose order
             // -- and with it the last bits of the gradient -- changed from run to run), and the item's sums go to their
             // own row of the column slab.
@@ -958,33 +953,21 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
             for (int e = tidp; e < T * DPAD; e += NT) {
                 const int n = e / DPAD, c = e % DPAD;
                 const int hq = n >> 6, q = n & 63, ln = (63 - q) & 63;
-                float sw = 0.f, sx = 0.f;
+                float sx = 0.f;
 #pragma unroll 1
                 for (int w = 0; w < QNW; ++w) {
                     if (i0 + w >= a.A || j < i0 + w) continue; // that wavefront had no pair
                     const float *rb = a.crec + ((size_t)blockIdx.x * QNW + w) * QREC;
                     auto ldr = [&](int k) { return __hip_atomic_load(rb + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-                    if (nrows1 > 0) { // pass over quadrant (1, hq)
-                        sx += ldr(((2 + hq) * CS + c) * 64 + ln);
-                        sw += ldr(((2 + hq) * CS + DPAD) * 64 + ln);
-                    }
-                    if (hq == 0 || nrows1 > 0) { // pass over quadrant (0, hq)
-                        sx += ldr((hq * CS + c) * 64 + ln);
-                        sw += ldr((hq * CS + DPAD) * 64 + ln);
-                    }
-                    sx += ldr(((4 + hq) * CS + c) * 64 + q); // point row 64
-                    sw += ldr(((4 + hq) * CS + DPAD) * 64 + q);
-                    if (q == 0) { // seam columns 0 and 64, per band
+                    if (nrows1 > 0) sx += ldr(((2 + hq) * CS + c) * 64 + ln);            // pass over quadrant (1, hq)
+                    if (hq == 0 || nrows1 > 0) sx += ldr((hq * CS + c) * 64 + ln);       // pass over quadrant (0, hq)
+                    sx += ldr(((4 + hq) * CS + c) * 64 + q);                             // point row 64
+                    if (q == 0) {                                                        // seam columns 0 and 64, per band
                         sx += ldr(6 * CS * 64 + hq * CS + c);
-                        sw += ldr(6 * CS * 64 + hq * CS + DPAD);
-                        if (nrows1 > 0) {
-                            sx += ldr(6 * CS * 64 + (2 + hq) * CS + c);
-                            sw += ldr(6 * CS * 64 + (2 + hq) * CS + DPAD);
-                        }
+                        if (nrows1 > 0) sx += ldr(6 * CS * 64 + (2 + hq) * CS + c);
                     }
                 }
-                const float v = m2h * (yf[(128 * hq + q) * YFS + c] * sw - sx);
-                if (c < d) dstc[n * d + c] = v;
+                if (c < d) dstc[n * d + c] = -m2h * sx;
             }
             SIG_QSTAMP(9)
         }
@@ -1036,7 +1019,7 @@ inline GradGeom quad_geometry(int A, int B, int T, int d, bool sym, int off = 0,
 }
 inline GradGeom quad_geometry(int A, int B, int T, int d, bool sym, const TileMap &tm)
 {
-    return quad_geometry(A, B, T, d, sym, tm.off, tm.stride, tm.owned > tm.m0);
+    return quad_geometry(A, B, T, d, sym, tm.off, tm.stride, tm.fold != 0);
 }
 // workspace of a gradient launch: [row segments][column slab][column records][row accumulators (d >= 15)][increment scratch]
 struct QuadCut {

@@ -1,0 +1,222 @@
+// Backward of the truncated path signature (adjoint of sigsvgd_signature): given dL/dS for the signature of every path,
+// dL/dX.  This is what makes `PathSigKernel` differentiable with respect to the PATH, which is how the reference uses it:
+// `analytic_grad=False` (src/kernels/_traj_kernels.py:92) routes it to `autograd.grad(k_xx.sum(), x)`
+// (src/inference/score.py:50-55, src/inference/svgd.py:41-43), i.e. through `signatory.signature` (:124-125).
+//
+// One workgroup per path, everything in fp64 in LDS.  The signature of the whole path is recomputed forwards (Chen's
+// identity, as signature_kernel does), then the points are taken in REVERSE: with E = exp(D_t) the tensor exponential of
+// the increment and S' = S (x) E the update of point t,
+//   * the signature before the point comes back from the one after it, S = S' (x) exp(-D_t) (the group inverse: nothing
+//     is stored per point);
+//   * adjoint of the left factor:   G_j[w]  = sum_{m >= 0} (1/m!) sum_{v in C^m} G'_{j+m}[w v] D^v
+//     -- m rounds of "contract the last letter with D";
+//   * adjoint of the right factor:  dE_m[v] = sum_{j >= 0} sum_{w in C^j} S_j[w] G'_{j+m}[w v]          (S_0 = 1)
+//   * adjoint of the exponential:   dD[a]   = sum_m (1/m!) sum_{r=1..m} sum_{v: v_r = a} dE_m[v] prod_{s != r} D[v_s]
+//   * D_t = x_t - x_{t-1}:          dX[t]   = dD_t - dD_{t+1}.
+// Every sum has one owner thread and a fixed order: no atomics, reproducible bits.
+#include "sig_common.h"
+
+namespace sigsvgd {
+
+namespace {
+constexpr int SB_MAX_DEPTH = 8;
+
+struct SigLevels {
+    int pw[SB_MAX_DEPTH + 1];  // C^k
+    int off[SB_MAX_DEPTH + 2]; // offset of level k (1-based) in the concatenated signature; off[depth + 1] = total
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void signature_bwd_kernel(const T *__restrict__ X, const T *__restrict__ gsig, int L, int C,
+                                                            int depth, int basepoint, int sigdim, T *__restrict__ gX)
+{
+    extern __shared__ double sb_lds[];
+    double *S = sb_lds, *Sn = S + sigdim, *G = Sn + sigdim, *Gn = G + sigdim, *A0 = Gn + sigdim, *A1 = A0 + sigdim;
+    double *inc = A1 + sigdim, *gnext = inc + C, *parts = gnext + C; // parts: [C][depth (depth + 1) / 2]
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const T *x = X + (size_t)blockIdx.x * L * C;
+    T *gx = gX + (size_t)blockIdx.x * L * C;
+    const int U = depth * (depth + 1) / 2;
+
+    SigLevels lv;
+    lv.pw[0] = 1;
+    lv.off[1] = 0;
+    for (int k = 1; k <= depth; ++k) {
+        lv.pw[k] = lv.pw[k - 1] * C;
+        lv.off[k + 1] = lv.off[k] + lv.pw[k];
+    }
+    auto load_inc = [&](int t, double sign) { // D_t = x_t - x_{t-1} (x_{-1} = 0: the base point)
+        if (tid < C)
+            inc[tid] = sign * ((double)x[(size_t)t * C + tid] - (t > 0 ? (double)x[(size_t)(t - 1) * C + tid] : 0.0));
+    };
+    // dst = src (x) exp(inc): element (a_1 .. a_k) in Horner form, h_r = src_r[a_1..a_r] + h_{r-1} inc[a_r] / (k - r + 1)
+    auto chen = [&](const double *src, double *dst) {
+        for (int k = 1; k <= depth; ++k)
+            for (int e = tid; e < lv.pw[k]; e += nt) {
+                double h = 1.0;
+                for (int r = 1; r <= k; ++r) {
+                    const int pr = e / lv.pw[k - r];
+                    h = src[lv.off[r] + pr] + h * inc[pr % C] / (double)(k - r + 1);
+                }
+                dst[lv.off[k] + e] = h;
+            }
+    };
+
+    // ---- forward: the signature of the whole path ----------------------------------------------------------------
+    for (int e = tid; e < sigdim; e += nt) {
+        S[e] = 0.0;
+        G[e] = (double)gsig[(size_t)blockIdx.x * sigdim + e];
+    }
+    if (tid < C) gnext[tid] = 0.0;
+    const int t0 = basepoint ? 0 : 1;
+    for (int t = t0; t < L; ++t) {
+        __syncthreads();
+        load_inc(t, 1.0);
+        __syncthreads();
+        chen(S, Sn);
+        double *tmp = S;
+        S = Sn;
+        Sn = tmp;
+    }
+
+    // ---- reverse sweep over the points -------------------------------------------------------------------------------
+    for (int t = L - 1; t >= t0; --t) {
+        __syncthreads();
+        load_inc(t, -1.0);
+        __syncthreads();
+        chen(S, Sn); // Sn = the signature before point t
+        __syncthreads();
+        if (tid < C) inc[tid] = -inc[tid]; // back to +D_t
+        for (int e = tid; e < sigdim; e += nt) {
+            Gn[e] = G[e];
+            A0[e] = G[e];
+        }
+        __syncthreads();
+        // adjoint of the left factor: m rounds of contracting the last letter with D
+        double fact = 1.0;
+        double *a0 = A0, *a1 = A1;
+        for (int m = 1; m < depth; ++m) {
+            fact *= (double)m;
+            for (int j = 1; j <= depth - m; ++j)
+                for (int w = tid; w < lv.pw[j]; w += nt) {
+                    const double *src = a0 + lv.off[j + 1] + (size_t)w * C;
+                    double s = 0.0;
+                    for (int a = 0; a < C; ++a) s = __builtin_fma(src[a], inc[a], s);
+                    a1[lv.off[j] + w] = s;
+                    Gn[lv.off[j] + w] += s / fact;
+                }
+            __syncthreads();
+            double *tmp = a0;
+            a0 = a1;
+            a1 = tmp;
+        }
+        // adjoint of the right factor, dE_m[v] (into a0), and the monomials P_k[w] = prod of D over the letters of w (into
+        // a1: levels 0 .. depth-1 at offsets 0, 1, 1 + C, ...)
+        for (int m = 1; m <= depth; ++m)
+            for (int v = tid; v < lv.pw[m]; v += nt) {
+                double s = G[lv.off[m] + v];
+                for (int j = 1; j <= depth - m; ++j) {
+                    const double *sp = Sn + lv.off[j];
+                    const double *gp = G + lv.off[j + m] + v;
+                    for (int w = 0; w < lv.pw[j]; ++w) s = __builtin_fma(sp[w], gp[(size_t)w * lv.pw[m]], s);
+                }
+                a0[lv.off[m] + v] = s;
+            }
+        if (tid == 0) a1[0] = 1.0;
+        __syncthreads();
+        {
+            int poff = 0; // offset of P_{k-1}
+            for (int k = 1; k < depth; ++k) {
+                const int noff = poff + lv.pw[k - 1];
+                for (int e = tid; e < lv.pw[k]; e += nt) a1[noff + e] = a1[poff + e / C] * inc[e % C];
+                __syncthreads();
+                poff = noff;
+            }
+        }
+        // adjoint of the exponential: work unit (a, m, r) sums over the words with letter a at position r
+        for (int u = tid; u < C * U; u += nt) {
+            const int a = u / U;
+            int q = u % U, m = 1;
+            while (q >= m) { // unit q of the triangle -> (m, r)
+                q -= m;
+                ++m;
+            }
+            const int r = q + 1;
+            int phi = 0, plo = 0; // offsets of P_{r-1} and P_{m-r}
+            for (int k = 0; k < r - 1; ++k) phi += lv.pw[k];
+            for (int k = 0; k < m - r; ++k) plo += lv.pw[k];
+            double fm = 1.0;
+            for (int k = 2; k <= m; ++k) fm *= (double)k;
+            const double *de = a0 + lv.off[m];
+            double s = 0.0;
+            for (int hi = 0; hi < lv.pw[r - 1]; ++hi) {
+                const double ph = a1[phi + hi];
+                const double *row = de + (size_t)hi * lv.pw[m - r + 1] + (size_t)a * lv.pw[m - r];
+                double sl = 0.0;
+                for (int lo = 0; lo < lv.pw[m - r]; ++lo) sl = __builtin_fma(row[lo], a1[plo + lo], sl);
+                s = __builtin_fma(ph, sl, s);
+            }
+            parts[u] = s / fm;
+        }
+        __syncthreads();
+        if (tid < C) {
+            double gd = 0.0;
+            for (int u = 0; u < U; ++u) gd += parts[tid * U + u];
+            gx[(size_t)t * C + tid] = (T)(gd - gnext[tid]);
+            gnext[tid] = gd;
+        }
+        // the adjoint and the signature move one point back
+        double *tmp = S;
+        S = Sn;
+        Sn = tmp;
+        tmp = G;
+        G = Gn;
+        Gn = tmp;
+    }
+    __syncthreads();
+    if (!basepoint && tid < C) gx[tid] = (T)(-gnext[tid]); // x_0 enters D_1 only
+}
+} // namespace
+
+int signature_bwd_launch(const void *X, const void *gsig, int N, int L, int C, int depth, int basepoint, int dtype, void *gX,
+                         long long sigdim, hipStream_t stream)
+{
+    if (depth > SB_MAX_DEPTH || C > 255) {
+        set_error("signature_backward: depth %d > %d or C=%d > 255", depth, SB_MAX_DEPTH, C);
+        return SIGSVGD_E_UNSUPPORTED;
+    }
+    const size_t lds = ((size_t)6 * sigdim + 2 * (size_t)C + (size_t)C * depth * (depth + 1) / 2) * sizeof(double);
+    if (sigdim < 0 || lds > 150 * 1024) {
+        set_error("signature_backward: %lld channels (C=%d, depth=%d) need %zu B of LDS, more than the 150 KB this kernel uses",
+                  sigdim, C, depth, lds);
+        return SIGSVGD_E_UNSUPPORTED;
+    }
+    if (!basepoint && L < 2) { // no increment at all: the signature is constant
+        hipError_t e0 = hipMemsetAsync(gX, 0, (size_t)N * L * C * (dtype == SIGSVGD_F64 ? 8 : 4), stream);
+        return e0 == hipSuccess ? SIGSVGD_OK : hip_fail(e0, "hipMemsetAsync(signature_backward)");
+    }
+    const int threads = sigdim <= 64 ? 64 : (sigdim <= 128 ? 128 : 256);
+    hipError_t e;
+    if (dtype == SIGSVGD_F64) {
+        if (lds > 64 * 1024) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&signature_bwd_kernel<double>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(signature_bwd_kernel)");
+        }
+        hipLaunchKernelGGL((signature_bwd_kernel<double>), dim3(N), dim3(threads), lds, stream, static_cast<const double *>(X),
+                           static_cast<const double *>(gsig), L, C, depth, basepoint, (int)sigdim, static_cast<double *>(gX));
+    } else {
+        if (lds > 64 * 1024) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&signature_bwd_kernel<float>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(signature_bwd_kernel)");
+        }
+        hipLaunchKernelGGL((signature_bwd_kernel<float>), dim3(N), dim3(threads), lds, stream, static_cast<const float *>(X),
+                           static_cast<const float *>(gsig), L, C, depth, basepoint, (int)sigdim, static_cast<float *>(gX));
+    }
+    e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "launch signature_bwd_kernel");
+    return SIGSVGD_OK;
+}
+
+} // namespace sigsvgd

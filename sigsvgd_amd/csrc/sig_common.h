@@ -178,7 +178,7 @@ int generic_launch(const GramProblem &p);
 // has B - t*NW columns, so a tile and its mirror image together always cost the same and every rank gets the same
 // number of items (cyclic ownership alone gives rank 0 5.4 % more than the mean at N=1024 on 8 ranks).
 struct TileMap {
-    int off, stride, ntile, owned, m0; // m0 tiles of the first kind (off + k*stride), then owned - m0 mirror images
+    int off, stride, ntile, owned, m0, fold; // m0 tiles of the first kind (off + k*stride), then owned - m0 mirror images
     __host__ __device__ int tile_of(int kq) const
     {
         return kq < m0 ? off + kq * stride : ntile - 1 - (off + (kq - m0) * stride);

@@ -6,10 +6,15 @@ natural sharding: N^2/2 independent pair solves followed by one reduction over p
 
     rank r owns particle rows [r*N/G, (r+1)*N/G)
     1. all-gather   X and score shards, packed into ONE collective   (2*N*T*d*4 B; 3.7 MB at N=1024,T=64,d=7)
-    2. compute      the unordered pairs whose 8-row tile index is r mod G (cyclic over the upper
-                    triangle => balanced), on the gathered X:  K_partial [N,N], grad_partial [N,T,d]
+    2. compute      the unordered pairs {i <= j} whose row tile (ops.sym_tile_rows(T, d) rows: 4 for T <= 32 or
+                    d > 8, else 8) has index r, r + G, ... or is the mirror image ntile-1-t of such a tile
+                    (FOLDED ownership: in the upper triangle tile t holds N - t*rows columns, so a tile and
+                    its mirror image always hold the same number of pairs and every rank gets the same
+                    share; cyclic ownership alone gives the first rank 5.4 % more than the mean at N=1024,
+                    G=8), on the gathered X:  K_partial [N,N], grad_partial [N,T,d]
                     v_partial = -((K_partial @ score - grad_partial)/N)   (linear in the partials)
-    3. reduce-scatter(sum) v_partial -> this rank's rows of v;  X_shard <- X_shard - lr * v
+    3. reduce-scatter(sum) v_partial -> this rank's rows of v;  X_shard <- X_shard - lr * v  (one launch)
+All per-step buffers (gathered operands, partials, velocity) are allocated once and reused.
 K itself stays distributed (each rank keeps its partial; `gather_gram` sums it on demand).
 
 Both collectives are latency-bound at these sizes (a 229 KB shard per peer over a dedicated xGMI
@@ -36,18 +41,20 @@ def shard_rows(N: int, rank: int, world: int) -> Tuple[int, int]:
     return rank * per, (rank + 1) * per
 
 
-def all_gather_rows(shard: torch.Tensor, group=None) -> torch.Tensor:
+def all_gather_rows(shard: torch.Tensor, group=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """[N/G, ...] -> [N, ...] (rank order)."""
     world = dist.get_world_size(group)
-    out = torch.empty((shard.shape[0] * world,) + tuple(shard.shape[1:]), dtype=shard.dtype, device=shard.device)
+    if out is None:
+        out = torch.empty((shard.shape[0] * world,) + tuple(shard.shape[1:]), dtype=shard.dtype, device=shard.device)
     dist.all_gather_into_tensor(out, shard.contiguous(), group=group)
     return out
 
 
-def reduce_scatter_rows(full: torch.Tensor, group=None) -> torch.Tensor:
+def reduce_scatter_rows(full: torch.Tensor, group=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """sum over ranks of [N, ...] -> this rank's [N/G, ...] rows."""
     world = dist.get_world_size(group)
-    out = torch.empty((full.shape[0] // world,) + tuple(full.shape[1:]), dtype=full.dtype, device=full.device)
+    if out is None:
+        out = torch.empty((full.shape[0] // world,) + tuple(full.shape[1:]), dtype=full.dtype, device=full.device)
     if dist.get_backend(group) == "gloo":  # gloo has no reduce_scatter: all-reduce then slice (tests only)
         tmp = full.contiguous().clone()
         dist.all_reduce(tmp, group=group)
@@ -90,33 +97,53 @@ class _PhaseClock:
 class ShardedSigSVGD:
     """One SVGD iteration with particles sharded across ranks.
 
-    partial_fn(X_full, inv_h, tile_offset, tile_stride) -> (K_partial, grad_partial) defaults to the
-    HIP library's symmetric partial solve; phi_fn(K, score, grad_k) -> v to the MFMA velocity kernel.
-    (The CPU tests substitute oracle-backed callables to exercise the sharding algebra under gloo.)"""
+    partial_fn(X_full, inv_h, tile_offset, tile_stride[, out=, fold=]) -> (K_partial, grad_partial) defaults to the
+    HIP library's symmetric partial solve with folded tile ownership; phi_fn(K, score, grad_k) -> v to the MFMA velocity
+    kernel.  (The CPU tests substitute oracle-backed callables to exercise the sharding algebra under gloo.)"""
 
     def __init__(self, inv_h: float, lr: float, group=None, partial_fn: Optional[Callable] = None,
-                 phi_fn: Optional[Callable] = None, rows_fn: Optional[Callable] = None, rowwise: bool = False):
+                 phi_fn: Optional[Callable] = None, rows_fn: Optional[Callable] = None, rowwise: bool = False,
+                 fold: bool = True):
         self.inv_h = float(inv_h)
         self.lr = float(lr)
         self.group = group
-        self.partial_fn = partial_fn or (lambda X, inv_h, off, stride: ops.gram_sym_partial(X, inv_h, off, stride))
+        self.fold = bool(fold)
+        self.partial_fn = partial_fn or ops.gram_sym_partial
         self.phi_fn = phi_fn or (lambda K, s, gk: ops.svgd_phi(K, s, gk))
         self.rows_fn = rows_fn or (lambda Xs, Xf, inv_h: ops.gram_fwd_bwd(Xs, Xf, inv_h))
         self.rowwise = bool(rowwise)
         self.last_K_partial = None
         self.last_K_rows = None
         self.phase_ms = None  # filled by step(profile=True): milliseconds per phase on this rank
+        self._buf = {}        # per-step buffers, allocated once per (shape, dtype, device)
+
+    def _buffers(self, X_shard: torch.Tensor, world: int):
+        key = (tuple(X_shard.shape), X_shard.dtype, X_shard.device, world)
+        b = self._buf.get(key)
+        if b is None:
+            n, T, d = X_shard.shape
+            N, dev, dt = n * world, X_shard.device, X_shard.dtype
+            b = {
+                "X_full": torch.empty((N, T, d), dtype=dt, device=dev),
+                "s_full": torch.empty((N, T, d), dtype=dt, device=dev),
+                "K_partial": torch.empty((N, N), dtype=dt, device=dev),
+                "grad_partial": torch.empty((N, T, d), dtype=torch.float64, device=dev),
+                "v_rows": torch.empty((n, T, d), dtype=dt, device=dev),
+            }
+            self._buf = {key: b}  # one shape at a time: a new shape releases the old buffers
+        return b
 
     def step(self, X_shard: torch.Tensor, score_shard: torch.Tensor, profile: bool = False) -> torch.Tensor:
-        """Returns the updated shard X_shard - lr * v_rows.  profile=True brackets the four phases with
-        events on the current stream (device tensors) or host clocks (CPU rehearsal) and leaves the
-        per-phase milliseconds in `self.phase_ms`; it synchronises, so never use it in a timed loop."""
+        """Returns the updated shard X_shard - lr * v_rows (a new tensor; the step's internal buffers are reused by the
+        next call).  profile=True brackets the phases with events on the current stream (device tensors) or host clocks
+        (CPU rehearsal) and leaves the per-phase milliseconds in `self.phase_ms`; it synchronises, so never use it in a
+        timed loop."""
         rank, world = _world(self.group)
         mark = _PhaseClock(X_shard.device) if profile else None
-        # one collective for both operands: [n, 2, T, d] shards -> [N, 2, T, d]
-        both = all_gather_rows(torch.stack((X_shard, score_shard.to(X_shard.dtype)), dim=1), self.group)
-        X_full = both[:, 0].contiguous()
-        s_full = both[:, 1].contiguous()
+        buf = self._buffers(X_shard, world)
+        # two collectives into preallocated, contiguous operands (no stack / split copies)
+        X_full = all_gather_rows(X_shard, self.group, out=buf["X_full"])
+        s_full = all_gather_rows(score_shard.to(X_shard.dtype), self.group, out=buf["s_full"])
         if mark:
             mark("all_gather")
         if self.rowwise or not self._partial_supported(X_full):
@@ -125,17 +152,18 @@ class ShardedSigSVGD:
                 mark("rowwise_solve_and_update")
                 self.phase_ms = mark.result()
             return out
-        Kp, gp = self.partial_fn(X_full, self.inv_h, rank, world)
+        Kp, gp = self.partial_fn(X_full, self.inv_h, rank, world, out=(buf["K_partial"], buf["grad_partial"]),
+                                 fold=self.fold)
         if mark:
             mark("partial_solve")
         self.last_K_partial = Kp
         v_part = self.phi_fn(Kp, s_full, gp.to(s_full.dtype))  # -((Kp @ s - gp)/N), linear in (Kp, gp)
         if mark:
             mark("velocity")
-        v_rows = reduce_scatter_rows(v_part.reshape(X_full.shape), self.group)
+        v_rows = reduce_scatter_rows(v_part.reshape(X_full.shape), self.group, out=buf["v_rows"])
         if mark:
             mark("reduce_scatter")
-        out = X_shard - self.lr * v_rows
+        out = torch.add(X_shard, v_rows, alpha=-self.lr)  # one launch
         if mark:
             mark("update")
             self.phase_ms = mark.result()

@@ -254,10 +254,12 @@ def svgd_adam(K, score, grad_k, X, lr: float, state: AdamState, mask=None, inpla
 
 
 def gram_sym_partial(X, inv_h: float, tile_offset: int, tile_stride: int, static_kind: int = _lib.STATIC_RBF,
-                     grad_out: Optional[torch.Tensor] = None, sym: bool = False, out=None):
+                     grad_out: Optional[torch.Tensor] = None, sym: bool = False, out=None, fold: bool = False):
     """This rank's share of the symmetric Gram + gradient on the gathered particles X [N,T,d]:
     returns (K_partial [N,N] X.dtype, grad_partial [N,T,d] fp64), zero outside the owned pairs.
     Summed over tile_offset = 0..tile_stride-1 they equal gram_fwd_bwd(X, X, y_is_x=True).
+    The launch owns the row tiles (`sym_tile_rows(T, d)` rows each) tile_offset + k*tile_stride; with fold=True also
+    their mirror images, which gives every rank the same number of pairs (SIGSVGD_FLAG_FOLD_TILES).
     `out=(K_partial, grad_partial)` reuses the caller's buffers (K_partial is re-zeroed, grad_partial overwritten)."""
     L = _lib.load()
     dev = _require_gpu(X, grad_out)
@@ -275,7 +277,7 @@ def gram_sym_partial(X, inv_h: float, tile_offset: int, tile_stride: int, static
     else:
         Kp = torch.zeros((N, N), dtype=Xc.dtype, device=dev)
         gp = torch.empty((N, T, d), dtype=torch.float64, device=dev)  # fully overwritten by the library
-    flags = _flags(False, sym, True, False)
+    flags = _flags(False, sym, True, False) | (_lib.FLAG_FOLD_TILES if fold else 0)
     nbytes = ctypes.c_size_t(0)
     _lib.check(L.sigsvgd_gram_workspace_bytes(N, N, T, d, 0, 1, flags, ctypes.byref(nbytes)), "gram_workspace_bytes")
     ws, wsn = _workspace(dev, nbytes.value)
@@ -286,6 +288,20 @@ def gram_sym_partial(X, inv_h: float, tile_offset: int, tile_stride: int, static
                                         ws.data_ptr() if ws is not None else None, wsn, _stream_ptr(dev))
     _lib.check(rc, "gram_sym_partial")
     return Kp, gp
+
+
+def sym_tile_rows(T: int, d: int) -> int:
+    """Rows per tile of the symmetric / partial solve (the ownership unit of the sharded step); 0 for shapes the partial
+    solve does not take.  Host-only query of the library."""
+    return int(_lib.load().sigsvgd_gram_sym_tile_rows(int(T), int(d)))
+
+
+def owned_tiles(ntile: int, tile_offset: int, tile_stride: int, fold: bool = False):
+    """The row tiles `gram_sym_partial(..., tile_offset, tile_stride, fold=)` owns, in the library's order (mirror of
+    csrc/sig_common.h TileMap; used by the sharding tests and the CPU test doubles)."""
+    first = [t for t in range(tile_offset, ntile, tile_stride) if not fold or t <= (ntile - 1) // 2]
+    second = [ntile - 1 - t for t in range(tile_offset, ntile, tile_stride) if 2 * t < ntile - 1] if fold else []
+    return first + second
 
 
 # ---- vector kernels / truncated signature (SURVEY.md §8 f-3, f-1) ---------------------------------------
@@ -405,17 +421,11 @@ def signature_channels(channels: int, depth: int) -> int:
     return int(n.value)
 
 
-def signature(X, depth: int, basepoint: bool = False) -> torch.Tensor:
-    """Truncated signature of paths X [N, L, C] -> [N, C + ... + C^depth] (signatory's layout)."""
+def _signature_fwd(Xc: torch.Tensor, depth: int, basepoint: bool) -> torch.Tensor:
     L = _lib.load()
-    dev = _require_gpu(X)
-    if X.dim() != 3:
-        raise ValueError(f"paths must be [batch, length, channels]; got {tuple(X.shape)}")
-    Xc = X.detach().contiguous()
+    dev = Xc.device
     dt = _io_dtype(Xc)
     N, Ln, C = Xc.shape
-    if N == 0:
-        raise ValueError("empty batch")
     n = ctypes.c_longlong(0)
     _lib.check(L.sigsvgd_signature(None, N, Ln, C, int(depth), int(bool(basepoint)), dt, None, ctypes.byref(n), None),
                "signature (channel query)")
@@ -425,6 +435,56 @@ def signature(X, depth: int, basepoint: bool = False) -> torch.Tensor:
                                  _stream_ptr(dev))
     _lib.check(rc, "signature")
     return out
+
+
+def signature_backward(X, grad_sig, depth: int, basepoint: bool = False) -> torch.Tensor:
+    """d sum(grad_sig * signature(X, depth, basepoint)) / dX  -> [N, L, C] (`sigsvgd_signature_backward`)."""
+    L = _lib.load()
+    dev = _require_gpu(X, grad_sig)
+    Xc = X.detach().contiguous()
+    dt = _io_dtype(Xc)
+    N, Ln, C = Xc.shape
+    g = grad_sig.detach().to(Xc.dtype).contiguous()
+    if g.dim() != 2 or g.shape[0] != N or g.shape[1] != signature_channels(C, depth):
+        raise ValueError(f"grad_sig must be [{N}, {signature_channels(C, depth)}], got {tuple(g.shape)}")
+    gX = torch.empty_like(Xc)
+    with torch.cuda.device(dev):
+        rc = L.sigsvgd_signature_backward(Xc.data_ptr(), g.data_ptr(), N, Ln, C, int(depth), int(bool(basepoint)), dt,
+                                          gX.data_ptr(), _stream_ptr(dev))
+    _lib.check(rc, "signature_backward")
+    return gX
+
+
+class _Signature(torch.autograd.Function):
+    """signature(X) as an autograd node: HIP forward, HIP adjoint (the path is the only differentiable input)."""
+
+    @staticmethod
+    def forward(ctx, X, depth, basepoint):
+        Xc = X.detach().contiguous()
+        ctx.save_for_backward(Xc)
+        ctx.depth, ctx.basepoint = int(depth), bool(basepoint)
+        return _signature_fwd(Xc, depth, basepoint)
+
+    @staticmethod
+    def backward(ctx, grad_sig):
+        (Xc,) = ctx.saved_tensors
+        return signature_backward(Xc, grad_sig, ctx.depth, ctx.basepoint), None, None
+
+
+def signature(X, depth: int, basepoint: bool = False) -> torch.Tensor:
+    """Truncated signature of paths X [N, L, C] -> [N, C + ... + C^depth] (signatory's layout).  Differentiable with
+    respect to X (reference: `signatory.signature` inside PathSigKernel, src/kernels/_traj_kernels.py:124-125, reached by
+    autograd from src/inference/score.py:50-55)."""
+    _lib.load()
+    _require_gpu(X)
+    if X.dim() != 3:
+        raise ValueError(f"paths must be [batch, length, channels]; got {tuple(X.shape)}")
+    if X.shape[0] == 0:
+        raise ValueError("empty batch")
+    _io_dtype(X)
+    if X.requires_grad and torch.is_grad_enabled():
+        return _Signature.apply(X, int(depth), bool(basepoint))
+    return _signature_fwd(X.detach().contiguous(), depth, basepoint)
 
 
 def obstacle_cost(x, start, target, basis, log_weights, mean, std, w_obstacle: float = 1.0, w_length: float = 1.0,

@@ -44,17 +44,19 @@ def svgd_phi(K, score, grad_k, mask=None, X=None, lr=None, adagrad_state=None):
     return v
 
 
-def gram_sym_partial(X, inv_h, tile_offset, tile_stride, static_kind=0, grad_out=None, sym=False):
-    """Same ownership rule as the HIP kernels: unordered pairs {i<=j} whose 8-row (T<=64 and d<=8) / 4-row
-    tile of i has index tile_offset mod tile_stride."""
+def gram_sym_partial(X, inv_h, tile_offset, tile_stride, static_kind=0, grad_out=None, sym=False, out=None, fold=False):
+    """Same ownership rule as the HIP kernels, taken from the library itself (host-only queries): unordered pairs
+    {i <= j} whose row tile of i -- `ops.sym_tile_rows(T, d)` rows -- is one of `ops.owned_tiles(...)`."""
+    from sigsvgd_amd import ops
+
     Xn = _np(X)
     N, T, d = Xn.shape
-    nw = 8 if (d <= 8 and T <= 64) else 4
-    K_full, g, G = O.gram_forward_full(Xn, Xn, static_kind, 1.0 / inv_h, 0)
+    nw = ops.sym_tile_rows(T, d)
+    owned = set(ops.owned_tiles((N + nw - 1) // nw, tile_offset, tile_stride, fold))
     Kp = np.zeros((N, N))
     gp = np.zeros((N, T, d))
     for i in range(N):
-        if (i // nw) % tile_stride != tile_offset:
+        if (i // nw) not in owned:
             continue
         for j in range(i, N):
             Kij, gi = O.gram_backward(Xn[i:i + 1], Xn[j:j + 1], None, static_kind, 1.0 / inv_h, 0)
@@ -63,7 +65,12 @@ def gram_sym_partial(X, inv_h, tile_offset, tile_stride, static_kind=0, grad_out
             if j != i:
                 _, gj = O.gram_backward(Xn[j:j + 1], Xn[i:i + 1], None, static_kind, 1.0 / inv_h, 0)
                 gp[j] += gj[0]
-    return torch.as_tensor(Kp, dtype=X.dtype), torch.as_tensor(gp, dtype=torch.float64)
+    Kt, gt = torch.as_tensor(Kp, dtype=X.dtype), torch.as_tensor(gp, dtype=torch.float64)
+    if out is not None:
+        out[0].copy_(Kt)
+        out[1].copy_(gt)
+        return out
+    return Kt, gt
 
 
 def patch_ops(monkeypatch):

@@ -98,12 +98,14 @@ def test_c5_full(gpu):
         assert _relK(Kn[rows[0]:rows[1]], Kref) < TOL
         gmax = np.abs(gref).max()
         assert np.abs(gn[rows[0]:rows[1]] - gref).max() / gmax < TOL
-    # the 8 tile-cyclic shares of the sharded step sum to the full launch (K exactly disjoint, gradient to rounding)
+    # the 8 shares of the sharded step (folded tile ownership) sum to the full launch (K exactly disjoint, gradient to
+    # rounding) and hold the same number of pairs each
     Ksum = torch.zeros((N, N), dtype=torch.float32, device=gpu)
     gsum = torch.zeros((N, T, d), dtype=torch.float64, device=gpu)
     for off in range(8):
-        Kp, gp = ops.gram_sym_partial(Xg, 1.0, off, 8)
+        Kp, gp = ops.gram_sym_partial(Xg, 1.0, off, 8, fold=True)
         assert bool(torch.isfinite(Kp).all()) and bool(torch.isfinite(gp).all())
+        assert int(torch.triu(Kp != 0).sum()) == (N * (N + 1) // 2) // 8  # every rank: one eighth of the pairs
         Ksum += Kp
         gsum += gp
         del Kp, gp

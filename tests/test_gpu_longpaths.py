@@ -91,8 +91,9 @@ def test_long_symmetric_solve_equals_ordered_pairs(gpu, N, T, d, dtype):
     assert _rel(g2.cpu().numpy(), gref2) < TOL
 
 
-@pytest.mark.parametrize("N,T,d,world", [(22, 128, 14, 3), (10, 70, 5, 2), (9, 96, 3, 4)])
-def test_long_partials_sum_to_full(gpu, N, T, d, world):
+@pytest.mark.parametrize("fold", [False, True])
+@pytest.mark.parametrize("N,T,d,world", [(22, 128, 14, 3), (10, 70, 5, 2), (9, 96, 3, 4), (40, 80, 16, 2)])
+def test_long_partials_sum_to_full(gpu, N, T, d, world, fold):
     """sigsvgd_gram_sym_partial on the long-path shapes: the per-rank partials (4-row tiles, cyclic) add up
     to the full symmetric solve, and each owned pair appears in exactly one partial."""
     from sigsvgd_amd import ops
@@ -105,7 +106,7 @@ def test_long_partials_sum_to_full(gpu, N, T, d, world):
     gs = torch.zeros(N, T, d, dtype=torch.float64, device=gpu)
     cover = torch.zeros(N, N, device=gpu)
     for r in range(world):
-        Kp, gp = ops.gram_sym_partial(Xg, 1.0, r, world, grad_out=go)
+        Kp, gp = ops.gram_sym_partial(Xg, 1.0, r, world, grad_out=go, fold=fold)
         Ks += Kp
         gs += gp
         cover += (Kp != 0).float()

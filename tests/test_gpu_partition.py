@@ -66,22 +66,31 @@ def test_symmetric_launch_shapes(gpu, N):
     assert torch.equal(K, K.T)
 
 
-@pytest.mark.parametrize("N,stride", [(20, 3), (70, 8), (9, 2), (5, 4)])
-def test_partial_shares_sum_to_full(gpu, N, stride):
-    """Strided row tiles (more ranks than tiles included): the shares add up to the symmetric solve."""
+@pytest.mark.parametrize("fold", [False, True])
+@pytest.mark.parametrize("N,stride,T", [(20, 3, 20), (70, 8, 20), (9, 2, 20), (5, 4, 20), (100, 3, 40), (131, 4, 64)])
+def test_partial_shares_sum_to_full(gpu, N, stride, T, fold):
+    """Strided row tiles (more ranks than tiles included), cyclic and folded ownership: the shares add up to the symmetric
+    solve, every pair belongs to exactly one share, and a share holds exactly the tiles `ops.owned_tiles` lists."""
     from sigsvgd_amd import ops
 
-    T, d, h = 20, 7, 1.0
+    d, h = 7, 1.0
     X = _paths(N, T, d, 31)
     Xg = torch.as_tensor(X, device=gpu)
     K, g = ops.gram_fwd_bwd(Xg, Xg, 1.0 / h, y_is_x=True)
     Ks = torch.zeros_like(K)
     gs = torch.zeros(N, T, d, device=gpu, dtype=torch.float64)
+    nw = ops.sym_tile_rows(T, d)
+    ntile = (N + nw - 1) // nw
     for r in range(stride):
-        Kp, gp = ops.gram_sym_partial(Xg, 1.0 / h, r, stride)
+        Kp, gp = ops.gram_sym_partial(Xg, 1.0 / h, r, stride, fold=fold)
         Ks += Kp
         gs += gp
+        # upper-triangle rows with an entry right of the diagonal are the rows of the owned tiles
+        up = torch.triu(Kp != 0)
+        rows = set(int(i) // nw for i in torch.nonzero(up.any(dim=1)).flatten().tolist())
+        assert rows == set(ops.owned_tiles(ntile, r, stride, fold)), (r, rows)
     torch.cuda.synchronize()
+    assert torch.equal(Ks, K)
     assert _relK(Ks.cpu().numpy(), K.double().cpu().numpy()) < SELF
     assert _rel(gs.cpu().numpy(), g.double().cpu().numpy()) < 1e-5
 

@@ -60,7 +60,7 @@ def test_regimes_coverage_kernel(gpu, T, d, n, scale, h):
 
 @pytest.mark.parametrize("T,d", [(64, 7), (128, 14), (40, 2)])
 def test_degenerate_paths(gpu, T, d):
-    """constant paths (all increments zero): K = 1 exactly and zero gradient; a path against itself
+    """constant paths (all increments zero): K = 1 exactly and a vanishing gradient; a path against itself
     repeated: K symmetric with equal rows; duplicated consecutive points change nothing (g = 0 cells)."""
     from sigsvgd_amd import ops
 
@@ -69,7 +69,9 @@ def test_degenerate_paths(gpu, T, d):
     K, g = ops.gram_fwd_bwd(torch.as_tensor(const, device=gpu), torch.as_tensor(mov, device=gpu), 1.0)
     assert torch.equal(K, torch.ones_like(K))
     K2, g2 = ops.gram_fwd_bwd(torch.as_tensor(mov, device=gpu), torch.as_tensor(const, device=gpu), 1.0)
-    assert torch.equal(K2, torch.ones_like(K2)) and float(g2.abs().max()) == 0.0
+    # (constant column paths: the true gradient is 0; the fp32 contraction of R G (x - y) leaves one rounding of a
+    #  product of order |x - y|, i.e. 1e-8 where gradients of moving pairs are of order 1)
+    assert torch.equal(K2, torch.ones_like(K2)) and float(g2.abs().max()) < 2e-7
     same = np.repeat(mov[:1], 5, axis=0)
     K3, g3 = ops.gram_fwd_bwd(torch.as_tensor(same, device=gpu), torch.as_tensor(same, device=gpu), 1.0, y_is_x=True)
     assert float((K3 - K3[0, 0]).abs().max()) <= 1e-6 * float(K3[0, 0])

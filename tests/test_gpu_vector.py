@@ -203,6 +203,81 @@ def test_path_sig_kernel_fixture_and_oracle(gpu):
     assert rel(K, wK) < 1e-5 and rel(dK, wdK) < 1e-5
 
 
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("N,L,C,depth,bp", [(5, 9, 2, 3, True), (4, 7, 3, 2, False), (3, 12, 2, 4, True), (6, 5, 4, 3, False),
+                                            (3, 20, 7, 3, True), (2, 1, 3, 2, True), (3, 6, 1, 5, False)])
+def test_signature_backward_vs_oracle(gpu, N, L, C, depth, bp, dtype):
+    """the HIP adjoint of the signature (`sigsvgd_signature_backward`, reached by autograd through `ops.signature`) against
+    the oracle's reverse-mode gradient, which tests/test_oracle_vector.py pins with finite differences of the signature"""
+    from sigsvgd_amd import ops
+
+    rng = np.random.default_rng(100 * C + 10 * depth + L)
+    X = np.cumsum(0.3 * rng.standard_normal((N, L, C)), axis=1)
+    W = rng.standard_normal((N, VO.signature_channels(C, depth)))
+    if dtype == torch.float32:
+        X, W = X.astype(np.float32).astype(np.float64), W.astype(np.float32).astype(np.float64)
+    sig_ref, g_ref = VO.signature_vjp(X, W, depth, bp)
+    x = torch.as_tensor(X, dtype=dtype, device=gpu).requires_grad_(True)
+    S = ops.signature(x, depth, basepoint=bp)
+    (g,) = torch.autograd.grad((S * torch.as_tensor(W, dtype=dtype, device=gpu)).sum(), x)
+    tol = 1e-11 if dtype == torch.float64 else 1e-5
+    assert g.dtype == dtype and g.shape == x.shape
+    assert rel(S.detach(), sig_ref) < tol and rel(g, g_ref) < tol
+    # the explicit entry point gives the same bits, twice
+    g2 = ops.signature_backward(x.detach(), torch.as_tensor(W, dtype=dtype, device=gpu), depth, bp)
+    assert torch.equal(g, g2) and torch.equal(g2, ops.signature_backward(x.detach(), torch.as_tensor(W, dtype=dtype, device=gpu), depth, bp))
+    # no graph, no node
+    assert not ops.signature(x.detach(), depth, basepoint=bp).requires_grad
+
+
+def test_path_sig_kernel_is_differentiable_through_the_signature(gpu):
+    """PathSigKernel has analytic_grad=False (reference _traj_kernels.py:92): ScoreEstimator routes it to
+    `k_xx = kernel(x, x.detach(), compute_grad=False); grad_k = autograd.grad(k_xx.sum(), x)` (score.py:50-55) and
+    SVGD._compute_kernel does the same (svgd.py:41-43) -- both differentiate THROUGH signatory.signature.  Here: through
+    the HIP signature and its HIP adjoint; checked against the oracle's chain (Gaussian on signatures, fixed bandwidth,
+    then the signature's vjp) and against central finite differences of the oracle's K.sum() at depth 2 and 3."""
+    from sigsvgd_amd.inference import SVGD, ScoreEstimator
+    from sigsvgd_amd.kernels import GaussianKernel, PathSigKernel
+
+    rng = np.random.default_rng(21)
+    h = 1.7
+    for depth in (2, 3):
+        X = np.cumsum(0.4 * rng.standard_normal((7, 8, 2)), axis=1)
+        psk = PathSigKernel(static_kernel=GaussianKernel(bandwidth_fn=lambda _: h))
+        x = torch.as_tensor(X, dtype=torch.float64, device=gpu).requires_grad_(True)
+        K = psk(x, x.detach(), depth=depth, compute_grad=False)
+        (gk,) = torch.autograd.grad(K.sum(), x)
+
+        def Ksum(Xa):  # oracle: first slot varies, second fixed (x.detach())
+            Kc, _, _ = VO.gaussian(VO.signature(Xa, depth, True), VO.signature(X, depth, True), h)
+            return Kc
+
+        Kref = Ksum(X)
+        assert rel(K.detach(), Kref) < 1e-10
+        # oracle chain rule: dK_ij/dS_i = -(S_i - S_j)/h^2 K_ij, then the signature's vjp
+        Sx = VO.signature(X, depth, True)
+        dS = -((Sx[:, None, :] - Sx[None, :, :]) / h**2 * Kref[..., None]).sum(1)
+        _, g_chain = VO.signature_vjp(X, dS, depth, True)
+        assert rel(gk, g_chain) < 1e-9
+        eps, fd = 1e-6, np.zeros_like(X)
+        for idx in [(0, 0, 0), (3, 4, 1), (6, 7, 0), (2, 2, 1), (5, 0, 1)]:
+            Xp, Xm = X.copy(), X.copy()
+            Xp[idx] += eps
+            Xm[idx] -= eps
+            fd[idx] = (Ksum(Xp).sum() - Ksum(Xm).sum()) / (2 * eps)
+            assert abs(float(gk[idx]) - fd[idx]) < 1e-6 * np.abs(g_chain).max()
+    # the estimator and SVGD routes of the reference run end to end
+    xs = torch.as_tensor(X, dtype=torch.float32, device=gpu).requires_grad_(True)
+    psk32 = PathSigKernel(static_kernel=GaussianKernel(bandwidth_fn=lambda _: h))
+    est = ScoreEstimator(psk32, lambda x: ((x**2).sum((1, 2)), {}), {})
+    assert est.score.__func__ is ScoreEstimator._svgd_ag_score
+    glp, aux = est.score(xs)
+    assert aux["grad_k"].shape == xs.shape and bool(torch.isfinite(aux["grad_k"]).all())
+    assert rel(aux["grad_k"], g_chain) < 1e-4 and rel(aux["k_xx"], Kref) < 1e-5
+    k2, g2 = SVGD(psk32, optimizer_class=None)._compute_kernel(xs.detach().requires_grad_(True))
+    assert rel(g2.reshape(xs.shape), g_chain) < 1e-4
+
+
 def test_svgd_with_default_gaussian_kernel_matches_closed_form(gpu):
     """SVGD(kernel=None) uses GaussianKernel (reference svgd.py:24-25): one manual step == oracle."""
     from sigsvgd_amd.inference import SVGD

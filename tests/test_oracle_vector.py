@@ -120,3 +120,22 @@ def test_path_sig_kernel_wiring_matches_reference_on_standin_signatory():
     np.testing.assert_allclose(K, G["psk_d2_med_K"], rtol=1e-6)
     K, _, _ = VO.path_sig_kernel(P1, P1, depth=3)
     np.testing.assert_allclose(K, G["psk_d3_Konly"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("C,depth,bp", [(2, 3, True), (3, 2, False), (2, 4, True), (4, 3, False)])
+def test_signature_vjp_is_the_gradient_of_signature(C, depth, bp):
+    """the oracle's reverse-mode gradient of the signature: its forward value equals `signature`, and its gradient equals
+    central finite differences of `signature` (what the HIP adjoint is compared with on the GPU)"""
+    rng = np.random.default_rng(C * 10 + depth)
+    X = np.cumsum(0.3 * rng.standard_normal((3, 6, C)), axis=1)
+    W = rng.standard_normal((3, VO.signature_channels(C, depth)))
+    sig, g = VO.signature_vjp(X, W, depth, bp)
+    assert np.abs(sig - VO.signature(X, depth, bp)).max() < 1e-12
+    eps = 1e-6
+    fd = np.zeros_like(X)
+    for idx in np.ndindex(*X.shape):
+        Xp, Xm = X.copy(), X.copy()
+        Xp[idx] += eps
+        Xm[idx] -= eps
+        fd[idx] = ((VO.signature(Xp, depth, bp) - VO.signature(Xm, depth, bp)) * W).sum() / (2 * eps)
+    assert np.abs(g - fd).max() / np.abs(fd).max() < 1e-7
