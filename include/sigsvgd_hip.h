@@ -132,8 +132,8 @@ int sigsvgd_gram_sym_partial(const void *X, int N, int T, int d, int dtype, doub
                              const void *grad_out, void *K_partial, double *grad_partial,
                              void *workspace, size_t workspace_bytes, void *stream);
 
-/* Rows per tile of the symmetric / partial solve for paths of T points in d channels: 4 for T <= 32 or d > 8 (T <= 64),
- * else 8; 0 for shapes sigsvgd_gram_sym_partial does not take.  The unit of ownership of the sharded solve. */
+/* Rows per tile of the symmetric / partial solve for paths of T points in d channels: 4 for T <= 64 with d > 8, else 8
+ * (0 for shapes sigsvgd_gram_sym_partial does not take).  The unit of ownership of the sharded solve. */
 int sigsvgd_gram_sym_tile_rows(int T, int d);
 
 /* v_out[N,D] = -((K[N,N] @ score[N,D] - grad_k[N,D]) / N) * (mask ? mask[N,D] : 1)   (fp32)

@@ -315,11 +315,15 @@ __device__ __forceinline__ void store_any(void *base, size_t idx, double v, int 
 
 // LP: the last of the DPAD channels is padding (d == DPAD - 1, e.g. the 7-DoF arm at DPAD = 8): its FMA in the
 // static kernel and its travelling column sum are dropped.
-// RING: slots per lane = length of the column ring.  64 in general; 32 for paths of <= 32 points (T <= 32, gradient
-// launches), where the skewed phases 1 and 4 then take 34 iterations instead of 66: lanes 32..63 MIRROR lanes 0..31
-// (row = lane & 31, same work, same values), which is what keeps the wave-wide machinery intact -- the boundary
-// lane of the DPP shifts at the seam is row 31, which has no cells for T <= 32 and so holds the boundary value 1,
-// and a travelling column sum meets every row exactly once in 32 consecutive lanes of the 64-lane rotation.
+// RING: slots per lane = length of the column ring.  64 in general; 32 for paths of <= 32 points (T <= 32), where the
+// skewed phases 1 and 4 take 34 iterations instead of 66 and a wavefront solves TWO pairs at once: lanes 0..31 own the
+// points of trajectory i, lanes 32..63 those of trajectory i + 1, against the SAME column trajectory j (time index =
+// lane & 31).  The wave-wide machinery stays intact: the lane next to the seam, row 31, has no cells for T <= 32 and
+// therefore holds the boundary value 1 that row 0 of the second pair needs from its DPP shift (and S = 0 for the
+// scatter); each of the 64 travelling column sums collects one of the two rows at every time index on its way through 32
+// consecutive lanes, and the two sums of a column (they end 32 lanes apart) are added when the workgroup's waves are --
+// exactly the sum over the tile's rows the column side wants.  (Round 2 let lanes 32..63 mirror lanes 0..31: the same
+// work twice.)
 template <int DPAD, int NW, bool GRAD, bool SYM, bool LP, int RING = 64>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
     GRAD ? ((RING == 32 && NW == 4 && DPAD <= 8) ? 3 : 1) : ((DPAD <= 8) ? 3 : 2),
@@ -328,6 +332,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
     constexpr int DC = LP ? DPAD - 1 : DPAD; // channels that can be non-zero
     constexpr int NT = NW * 64;
     constexpr int RM = RING - 1;
+    constexpr int RPW = (RING == 32) ? 2 : 1; // rows (trajectories i) per wavefront
+    constexpr int NWR = NW * RPW;             // rows per tile
     // y rows are stored twice (row r and r + 64) so that the skewed row (t - lane) & 63 becomes
     // (64 - lane) + t: a per-lane base plus a compile-time offset.
     // Row strides are padded (YDS doubles / YFS floats) so that the 16 lanes a ds_read_b128 services per
@@ -360,8 +366,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
 #ifdef SIGSVGD_PHASE_STAMPS
     unsigned long long ph_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast_ = __builtin_amdgcn_s_memtime();
 #endif
-    int i = 0, j0 = 0, j1 = 0;
-    bool row_ok = false;
+    int j0 = 0, j1 = 0;
     float *Gs = Gs_all + (GRAD ? wave * GSW : 0);
     const double inv_h = a.inv_h;
     const float m2h = (float)(-2.0 * inv_h * 3.46410161513775459); // the G image holds G / sqrt(12)
@@ -427,7 +432,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
     {
         long long rem = it0;
         for (;; ++kq) {
-            const int cn = a.B - (SYM ? a.tm.tile_of(kq) * NW : 0);
+            const int cn = a.B - (SYM ? a.tm.tile_of(kq) * NWR : 0);
             if (rem < cn) break;
             rem -= cn;
         }
@@ -436,12 +441,13 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
     bool staged = false;
     while (remaining > 0) {
     const int itile = a.tm.tile_of(kq);
-    const int cfirst = SYM ? itile * NW : 0; // first column that touches or crosses the diagonal
+    const int cfirst = SYM ? itile * NWR : 0; // first column that touches or crosses the diagonal
     const int ncol = min(a.B - cfirst - cstart, remaining);
-    const int jnext_tile = SYM ? a.tm.tile_of(kq + 1) * NW : 0; // where the range goes on, on the next owned tile
+    const int jnext_tile = SYM ? a.tm.tile_of(kq + 1) * NWR : 0; // where the range goes on, on the next owned tile
     const bool more_tiles = remaining > ncol;
-    i = itile * NW + wave;
-    row_ok = i < a.A;
+    const int i0 = itile * NWR + wave * RPW;                // first (or only) row of this wavefront: scalar
+    const int i = (RING == 32) ? i0 + (lane >> 5) : i0;     // the row this LANE works for
+    const bool row_ok = i < a.A;
 #pragma unroll
     for (int c = 0; c < DPAD; ++c) {
         gacc[c] = 0.0;
@@ -457,7 +463,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
     }
 
     for (int j = j0; j < j1; ++j) {
-        const bool pair_ok = row_ok && (!SYM || j >= i);
+        // (two rows per wavefront: the second one is the later row, so the first decides whether there is work at all;
+        //  a half without a pair of its own -- row beyond A, or left of the diagonal -- computes along and is dropped)
+        const bool pair_ok = i0 < a.A && (!SYM || j >= i0);
+        const bool mine = row_ok && (!SYM || j >= i); // this lane's pair exists
         const bool last = j + 1 == j1;
         const bool more = !last || more_tiles;
         if (more) stage_load(last ? jnext_tile : j + 1); // in flight during the pair
@@ -560,7 +569,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
                     for (int k0 = 0; k0 < 64; k0 += 8) // Ksl[k] <- K[l, q]
                         sweep_fwd8<GRAD>(cur, upA, upB, V, &Dsl[k0 & RM], &Ksl[k0 & RM], mk + k0, r3);
                 }
-                if (lane == P - 1) { // this lane's last value is K[P, P]
+                if (lrow == P - 1 && mine) { // this lane's last value is K[P, P]
                     store_any(a.K, (size_t)i * a.B + j, (double)cur, io64);
                     if (SYM && j != i) store_any(a.K, (size_t)j * a.B + i, (double)cur, io64);
                 }
@@ -569,6 +578,19 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
             SIG_STAMP(2)
             SIG_PRIO(1)
             if (GRAD) {
+                // weights of this lane's pair: row side w_ij, column side w_ji (per lane with two rows per wavefront,
+                // uniform otherwise; fetched here so that the loads are long back when the gradient pass needs them)
+                float w_ij = 1.f, w_ji = 1.f; // (per lane with two rows per wavefront; uniform otherwise)
+                if (!mine) {
+                    w_ij = 0.f; w_ji = 0.f;
+                } else if (a.go) {
+                    w_ij = (float)load_any(a.go, (size_t)i * a.B + j, io64);
+                    if (SYM || a.symw) w_ji = (float)load_any(a.go, (size_t)j * a.B + i, io64);
+                    if (a.symw) { w_ij += w_ji; w_ji = w_ij; }
+                } else if (a.symw) {
+                    w_ij = 2.f; w_ji = 2.f;
+                }
+                const float wcol = (mine && j != i) ? w_ji : 0.f; // the diagonal pair has no column side
                 // ---- phase 3: reverse sweep (U recurrence; S replaces K_fwd slot by slot) -----------------
                 float cur = 1.f, downA = 1.f, downB = 1.f, V = 0.f; // `down` persists (lane 63 keeps U[P][.] = 1), alternating as above
                 float Sb = 0.f, eprev = 0.f;
@@ -626,9 +648,13 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
                     for (int c = 0; c < DPAD / 2; ++c) asm volatile("" : "+v"(acc[c]));
                     if (SYM) {
+                        // (two rows per wavefront: a travelling sum collects BOTH rows on its way, so each contribution
+                        //  carries its own pair's weight; with one row the weight is applied once, when the sums are parked)
+                        const float rgc = (RING == 32) ? rg * wcol : rg;
+                        const f32x2 rgc2 = {rgc, rgc};
 #pragma unroll
                         for (int c = 0; c < DPAD / 2; ++c) {
-                            const f32x2 pr = rg2 * df[c];
+                            const f32x2 pr = rgc2 * df[c];
                             tacc[2 * c] = add_rol1(tacc[2 * c], pr[0]);
                             if (2 * c + 1 < DC) tacc[2 * c + 1] = add_rol1(tacc[2 * c + 1], pr[1]);
                         }
@@ -686,27 +712,19 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
 
                 SIG_STAMP(4)
                 // row-side gradient of this pair: -(2/h) * sum_n R G (x~_m - y~_n); column side: the same sum over m, negated
-                float w_ij = 1.f, w_ji = 1.f;
-                if (a.go) {
-                    w_ij = (float)load_any(a.go, (size_t)i * a.B + j, io64);
-                    if (SYM || a.symw) w_ji = (float)load_any(a.go, (size_t)j * a.B + i, io64);
-                    if (a.symw) { w_ij += w_ji; w_ji = w_ij; }
-                } else if (a.symw) {
-                    w_ij = 2.f; w_ji = 2.f;
-                }
 #pragma unroll
                 for (int c = 0; c < DPAD; ++c) {
                     gacc[c] += (double)(w_ij * m2h * acc[c / 2][c % 2]);
                 }
 
-                if (SYM && j != i && lane < RING) { // (RING = 32: the mirror lanes hold the same sums in another order)
-                    // park the column-side result in this wave's own G region ([lane][c]) for the block sum
+                if (SYM) {
+                    // park the column-side result in this wave's own G region ([half][column][c]) for the block sum; the
+                    // diagonal pair has no column side, a half without a pair contributes nothing
                     const int ncol = (RING - lrow) & RM; // the column whose finished sums this lane ended up with
+                    const float wpark = (ncol <= P) ? ((RING == 32) ? -m2h : -(wcol * m2h)) : 0.f;
+                    float *pk = Gs + ((RING == 32 ? (lane >> 5) * RING : 0) + ncol) * DPAD;
 #pragma unroll
-                    for (int c = 0; c < DPAD; ++c) Gs[ncol * DPAD + c] = (ncol <= P) ? -(w_ji * m2h) * tacc[c] : 0.f;
-                } else if (SYM) {
-#pragma unroll
-                    for (int c = 0; c < DPAD; ++c) Gs[lane * DPAD + c] = 0.f; // diagonal pair: no column side
+                    for (int c = 0; c < DPAD; ++c) pk[c] = wpark * tacc[c];
                 }
             }
         } else if (GRAD && SYM) {
@@ -729,7 +747,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
                 const int n = (int)(((float)e + 0.5f) * inv_d), c = e - n * d; // exact for e < 2^20
                 float s = 0.f;
 #pragma unroll
-                for (int w = 0; w < NW; ++w) s += Gs_all[w * GSW + n * DPAD + c];
+                for (int w = 0; w < NW; ++w) {
+                    s += Gs_all[w * GSW + n * DPAD + c];
+                    if (RING == 32) s += Gs_all[w * GSW + (RING + n) * DPAD + c]; // the wavefront's second row
+                }
                 dst[e] = s;
             }
         }
@@ -740,8 +761,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
 #endif
     }
 
-    if (GRAD && row_ok && lane < T) { // this (workgroup, row tile) segment's own slot: segments are numbered kq + workgroup
-        double *dst = a.rseg + (((size_t)(kq + (int)blockIdx.x)) * NW + wave) * (size_t)(T * d) + lane * d;
+    if (GRAD && row_ok && lrow < T) { // this (workgroup, row tile) segment's own slot: segments are numbered kq + workgroup
+        const int rslot = wave * RPW + (RING == 32 ? (lane >> 5) : 0);
+        double *dst = a.rseg + (((size_t)(kq + (int)blockIdx.x)) * NWR + rslot) * (size_t)(T * d) + lrow * d;
 #pragma unroll
         for (int c = 0; c < DPAD; ++c)
             if (c < d) dst[c] = gacc[c];
@@ -770,12 +792,22 @@ struct GradReduceArgs {
     TileMap tm;
     long long nitems;
 };
-__global__ __launch_bounds__(256) void grad_reduce_kernel(GradReduceArgs r)
+// One workgroup per row i (grid.y) and per 512 elements of it (grid.x), so everything that depends on the row only -- its
+// tile, the tile's item range, the workgroups that met it, the item index of column i in every owned tile -- is
+// wave-uniform scalar arithmetic (64-bit divisions: with one thread per output element and per-thread index arithmetic
+// this kernel took 27.5 us at N=128, T=32, d=7, a third of the iteration).  An element is a sum over up to N / NW slab
+// rows (column side) and one segment per workgroup that met the row's tile (row side: a handful in large launches, up
+// to ~100 in small ones, where a workgroup owns one or two columns).  The workgroup's threads cover a whole slab row
+// (T*d contiguous floats) with each load, sixteen rows in flight: whole-row reads keep the DRAM pages busy (64-element
+// slices of a row read by different workgroups at different times ran at 1 TB/s: 118 us per C4 launch).
+constexpr int RED_T = 512;
+__global__ __launch_bounds__(RED_T) void grad_reduce_kernel(GradReduceArgs r)
 {
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (size_t)r.A * r.TD) return;
-    const int i = (int)(idx / r.TD), e = (int)(idx % r.TD);
+    const int e = blockIdx.x * RED_T + threadIdx.x;
+    const int i = blockIdx.y;
+    if (e >= r.TD) return;
     double s = 0.0;
+    // row side: the segments of the row's tile, one per workgroup whose item range met it
     const int ti = i / r.NW, wv = i % r.NW;
     const int kqr = r.tm.kq_of_tile(ti);
     if (kqr >= 0) {
@@ -783,22 +815,35 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(GradReduceArgs r)
         const long long cn = r.sym ? r.B - ti * r.NW : r.B;
         // workgroup w works on the items [nitems*w/grid, nitems*(w+1)/grid): the one holding item x is
         const int wlo = (int)(((S0 + 1) * r.grid - 1) / r.nitems), whi = (int)(((S0 + cn) * r.grid - 1) / r.nitems);
-        for (int w = wlo; w <= whi; ++w) s += r.rseg[((size_t)(kqr + w) * r.NW + wv) * r.TD + e];
-    }
-    if (r.sym) { // the items (owned tile, column i) of the tiles whose first row is <= i, in the order of the enumeration
-        for (int kq = 0; kq < r.tm.owned; kq += 4) { // four independent loads in flight
-            float v[4];
+        const double *base = r.rseg + ((size_t)kqr * r.NW + wv) * r.TD + e;
+        for (int w = wlo; w <= whi; w += 8) {
+            double v[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 8; ++u) v[u] = (w + u <= whi) ? base[(size_t)(w + u) * r.NW * r.TD] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+    }
+    // column side: the items (owned tile, column i) of the tiles whose first row is <= i, in the order of the enumeration
+    if (r.sym) {
+        for (int kq = 0; kq < r.tm.owned; kq += 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
                 const int tu = kq + u < r.tm.owned ? r.tm.tile_of(kq + u) : r.tm.ntile;
                 const bool in = tu * r.NW <= i && tu < r.tm.ntile;
+#ifdef SIG_EXP_SEQ_SLAB // timing experiment only: consecutive slab rows per output row (wrong results)
+                const long long it = in ? ((long long)i * 64 + kq + u) % r.nitems : 0;
+#else
                 const long long it = in ? r.tm.start(kq + u, r.B, r.NW, 1) + (i - tu * r.NW) : 0;
+#endif
                 v[u] = in ? r.cslab[(size_t)it * r.TD + e] : 0.f;
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) s += (double)v[u];
+            for (int u = 0; u < 16; ++u) s += (double)v[u];
         }
     }
+    const size_t idx = (size_t)i * r.TD + e;
     if (r.out64)
         static_cast<double *>(r.out)[idx] = s;
     else
@@ -865,8 +910,12 @@ int grad_reduce_launch(const GradGeom &g, const double *rseg, const float *cslab
     r.rseg = rseg; r.cslab = cslab; r.out = out; r.out64 = out64;
     r.A = A; r.B = B; r.TD = TD; r.NW = g.NW; r.tm = g.tm;
     r.sym = sym ? 1 : 0; r.grid = g.grid > 0 ? g.grid : 1; r.nitems = g.nitems > 0 ? g.nitems : 1;
-    const size_t nacc = (size_t)A * TD;
-    hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)((nacc + 255) / 256)), dim3(256), 0, stream, r);
+    if (A > 65535) {
+        set_error("gradient reduction: %d rows exceed the grid limit", A);
+        return SIGSVGD_E_UNSUPPORTED;
+    }
+    const int rt = TD >= RED_T ? RED_T : ((TD + 63) / 64) * 64; // (short rows: no idle wavefronts)
+    hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)((TD + RED_T - 1) / RED_T), (unsigned)A), dim3(rt), 0, stream, r);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "launch grad_reduce_kernel");
     return SIGSVGD_OK;
@@ -875,7 +924,7 @@ int grad_reduce_launch(const GradGeom &g, const double *rseg, const float *cslab
 namespace {
 inline int cu_count() { return device_cu_count(); }
 // geometry of a GRADIENT launch (the forward-only launches keep no partial sums): rows per tile, workgroups a CU holds
-inline int grad_nw(int T, int d) { return (d <= 8) ? (T <= 32 ? 4 : 8) : 4; }
+inline int grad_nw(int T, int d) { return (d <= 8) ? 8 : 4; } // (T <= 32: 4 wavefronts of two rows each)
 inline int grad_wg_per_cu(int T, int d) { return (d <= 8 && T <= 32) ? 3 : 1; }
 using FastGeom = GradGeom;
 FastGeom fast_geometry(int A, int B, int T, int d, bool sym, const TileMap &tm)
@@ -912,9 +961,10 @@ template <int DPAD, int NW, int RING = 64>
 int launch_variant(const GramProblem &p, FastArgs &a, bool grad, bool sym)
 {
     // items of this launch: (owned row tile, column); symmetric launches only the columns from the tile's first row on
-    const TileMap tm = make_tilemap((p.A + NW - 1) / NW, a.tm.off, a.tm.stride, a.tm.fold != 0);
+    constexpr int NWR = NW * (RING == 32 ? 2 : 1); // rows per tile: the 32-slot ring solves two rows per wavefront
+    const TileMap tm = make_tilemap((p.A + NWR - 1) / NWR, a.tm.off, a.tm.stride, a.tm.fold != 0);
     if (tm.owned <= 0) return SIGSVGD_OK;
-    const long long total = tm.start(tm.owned, p.B, NW, sym ? 1 : 0);
+    const long long total = tm.start(tm.owned, p.B, NWR, sym ? 1 : 0);
     if (total <= 0) return SIGSVGD_OK;
     const int ncu = cu_count();
     a.tm = tm;
@@ -932,8 +982,8 @@ int launch_variant(const GramProblem &p, FastArgs &a, bool grad, bool sym)
     dim3 block(NW * 64);
     if (grad) { // the reduction kernel re-derives the segments from this geometry: it must be the one the workspace was cut for
         const FastGeom g = fast_geometry(p.A, p.B, p.T, p.d, sym, a.tm);
-        if (g.NW != NW || g.grid != (int)grid.x || g.nitems != total) {
-            set_error("fast: launch geometry mismatch (NW %d/%d grid %d/%u items %lld/%lld)", g.NW, NW, g.grid, grid.x,
+        if (g.NW != NWR || g.grid != (int)grid.x || g.nitems != total) {
+            set_error("fast: launch geometry mismatch (rows per tile %d/%d grid %d/%u items %lld/%lld)", g.NW, NWR, g.grid, grid.x,
                       g.nitems, total);
             return SIGSVGD_E_BADARG;
         }

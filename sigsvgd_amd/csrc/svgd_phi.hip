@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void svgd_phi_kernel(const float *__restrict__
 {
     __shared__ __align__(16) float kt[PM * KS];     // K tile      [row][k]
     __shared__ __align__(16) float st[PK * SS];     // score tile  [k][col]
-    __shared__ __align__(16) float red[3 * PM * PN]; // partial tiles of wavefronts 1..3
+    __shared__ __align__(16) float red[4 * PM * PN]; // partial tiles of the four wavefronts (k quarters)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row0 = blockIdx.y * PM, col0 = blockIdx.x * PN;
     const bool vecK = (N % 4) == 0 && (reinterpret_cast<uintptr_t>(K) & 15) == 0;
@@ -123,59 +123,67 @@ __global__ __launch_bounds__(256) void svgd_phi_kernel(const float *__restrict__
             }
         }
     }
-    // combine the four k-quarters: C/D map (16x16): col = lane&15, row = (lane>>4)*4 + reg
+    // combine the four k-quarters: C/D map (16x16): col = lane&15, row = (lane>>4)*4 + reg.  Every wavefront parks its
+    // partial tile, then ALL 256 threads run the epilogue, 8 outputs each with consecutive threads on consecutive columns
+    // (round 2 left it to wavefront 0: 32 outputs per lane, one load-compute-store chain after the other -- 46 of the
+    // kernel's 47 us at C4 were this tail)
     __syncthreads();
-    if (wave > 0) {
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int b = 0; b < 4; ++b)
+        for (int b = 0; b < 4; ++b)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    red[(wave - 1) * PM * PN + (a * 16 + (lane >> 4) * 4 + r) * PN + b * 16 + (lane & 15)] = acc[a][b][r];
+            for (int r = 0; r < 4; ++r)
+                red[wave * PM * PN + (a * 16 + (lane >> 4) * 4 + r) * PN + b * 16 + (lane & 15)] = acc[a][b][r];
+    __syncthreads();
+    const float invN = 1.0f / (float)N;
+    float step_size = lr, inv_sqrt_bc2 = 1.f, omb1 = 0.f, omb2 = 0.f, b2 = 0.f;
+    if (adam.exp_avg) { // torch.optim.Adam (amsgrad=False, weight_decay=0, maximize=False): scalars in fp64 as torch
+        const double t = (double)(*adam.step + 1);
+        step_size = (float)(adam.lr / (1.0 - pow(adam.beta1, t)));
+        inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow(adam.beta2, t)));
+        omb1 = (float)(1.0 - adam.beta1);
+        omb2 = (float)(1.0 - adam.beta2);
+        b2 = (float)adam.beta2;
     }
-    __syncthreads();
-    if (wave == 0) {
-        const float invN = 1.0f / (float)N;
-        float step_size = lr, inv_sqrt_bc2 = 1.f, omb1 = 0.f, omb2 = 0.f, b2 = 0.f;
-        if (adam.exp_avg) { // torch.optim.Adam (amsgrad=False, weight_decay=0, maximize=False): scalars in fp64 as torch
-            const double t = (double)(*adam.step + 1);
-            step_size = (float)(adam.lr / (1.0 - pow(adam.beta1, t)));
-            inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow(adam.beta2, t)));
-            omb1 = (float)(1.0 - adam.beta1);
-            omb2 = (float)(1.0 - adam.beta2);
-            b2 = (float)adam.beta2;
+    constexpr int EPT = PM * PN / 256; // outputs per thread
+    float sv[EPT], gv[EPT], xv[EPT], mv[EPT], av[EPT], e1[EPT], e2[EPT];
+    bool ok[EPT];
+#pragma unroll
+    for (int u = 0; u < EPT; ++u) { // all loads first: one round trip for the lot
+        const int el = tid + u * 256, lr_ = el / PN, lc = el % PN;
+        const int gr = row0 + lr_, gc = col0 + lc;
+        ok[u] = gr < N && gc < D;
+        const size_t idx = ok[u] ? (size_t)gr * D + gc : 0;
+        sv[u] = ((red[lr_ * PN + lc] + red[PM * PN + lr_ * PN + lc]) + red[2 * PM * PN + lr_ * PN + lc]) +
+                red[3 * PM * PN + lr_ * PN + lc];
+        gv[u] = gk[idx];
+        mv[u] = mask ? mask[idx] : 1.f;
+        av[u] = adagrad ? adagrad[idx] : 0.f;
+        xv[u] = X_in ? X_in[idx] : 0.f;
+        e1[u] = adam.exp_avg ? adam.exp_avg[idx] : 0.f;
+        e2[u] = adam.exp_avg ? adam.exp_avg_sq[idx] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < EPT; ++u) {
+        if (!ok[u]) continue;
+        const int el = tid + u * 256;
+        const size_t idx = (size_t)(row0 + el / PN) * D + col0 + el % PN;
+        float v = -((sv[u] - gv[u]) * invN) * mv[u];
+        if (adagrad) { // reference svgd.py:110-113: running sum of squared gradients, g / sqrt(sum + 1e-12)
+            const float acc2 = av[u] + v * v;
+            adagrad[idx] = acc2;
+            v = v / sqrtf(acc2 + 1e-12f);
         }
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int lr_ = a * 16 + (lane >> 4) * 4 + r, lc = b * 16 + (lane & 15);
-                    const int gr = row0 + lr_, gc = col0 + lc;
-                    if (gr < N && gc < D) {
-                        const float s = ((acc[a][b][r] + red[lr_ * PN + lc]) + red[PM * PN + lr_ * PN + lc]) +
-                                        red[2 * PM * PN + lr_ * PN + lc];
-                        const size_t idx = (size_t)gr * D + gc;
-                        float v = -((s - gk[idx]) * invN);
-                        if (mask) v *= mask[idx];
-                        if (adagrad) { // reference svgd.py:110-113: running sum of squared gradients, g / sqrt(sum + 1e-12)
-                            const float acc2 = adagrad[idx] + v * v;
-                            adagrad[idx] = acc2;
-                            v = v / sqrtf(acc2 + 1e-12f);
-                        }
-                        v_out[idx] = v;
-                        if (adam.exp_avg) {
-                            const float m = adam.exp_avg[idx] + omb1 * (v - adam.exp_avg[idx]); // lerp
-                            const float q = b2 * adam.exp_avg_sq[idx] + omb2 * (v * v);
-                            adam.exp_avg[idx] = m;
-                            adam.exp_avg_sq[idx] = q;
-                            X_out[idx] = X_in[idx] - step_size * (m / (sqrtf(q) * inv_sqrt_bc2 + adam.eps));
-                        } else if (X_out)
-                            X_out[idx] = X_in[idx] - lr * v;
-                    }
-                }
+        v_out[idx] = v;
+        if (adam.exp_avg) {
+            const float m = e1[u] + omb1 * (v - e1[u]); // lerp
+            const float q = b2 * e2[u] + omb2 * (v * v);
+            adam.exp_avg[idx] = m;
+            adam.exp_avg_sq[idx] = q;
+            X_out[idx] = xv[u] - step_size * (m / (sqrtf(q) * inv_sqrt_bc2 + adam.eps));
+        } else if (X_out)
+            X_out[idx] = xv[u] - lr * v;
     }
 }
 

@@ -6,7 +6,7 @@ natural sharding: N^2/2 independent pair solves followed by one reduction over p
 
     rank r owns particle rows [r*N/G, (r+1)*N/G)
     1. all-gather   X and score shards, packed into ONE collective   (2*N*T*d*4 B; 3.7 MB at N=1024,T=64,d=7)
-    2. compute      the unordered pairs {i <= j} whose row tile (ops.sym_tile_rows(T, d) rows: 4 for T <= 32 or
+    2. compute      the unordered pairs {i <= j} whose row tile (ops.sym_tile_rows(T, d) rows: 4 for T <= 64 with
                     d > 8, else 8) has index r, r + G, ... or is the mirror image ntile-1-t of such a tile
                     (FOLDED ownership: in the upper triangle tile t holds N - t*rows columns, so a tile and
                     its mirror image always hold the same number of pairs and every rank gets the same
