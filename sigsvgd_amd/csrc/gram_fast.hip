@@ -792,57 +792,71 @@ struct GradReduceArgs {
     TileMap tm;
     long long nitems;
 };
-// One workgroup per row i (grid.y) and per 512 elements of it (grid.x), so everything that depends on the row only -- its
-// tile, the tile's item range, the workgroups that met it, the item index of column i in every owned tile -- is
-// wave-uniform scalar arithmetic (64-bit divisions: with one thread per output element and per-thread index arithmetic
-// this kernel took 27.5 us at N=128, T=32, d=7, a third of the iteration).  An element is a sum over up to N / NW slab
-// rows (column side) and one segment per workgroup that met the row's tile (row side: a handful in large launches, up
-// to ~100 in small ones, where a workgroup owns one or two columns).  The workgroup's threads cover a whole slab row
-// (T*d contiguous floats) with each load, sixteen rows in flight: whole-row reads keep the DRAM pages busy (64-element
-// slices of a row read by different workgroups at different times ran at 1 TB/s: 118 us per C4 launch).
-constexpr int RED_T = 512;
-__global__ __launch_bounds__(RED_T) void grad_reduce_kernel(GradReduceArgs r)
+// grid (ceil(T*d / 64), A), 4 wavefronts: a workgroup serves 64 elements of one row i, so everything that depends on the
+// row only -- its tile, the tile's item range, the workgroups that met it, the slab row of column i in every owned
+// tile -- is wave-uniform SCALAR arithmetic, and the slab rows are walked incrementally (a tile's items follow the
+// previous tile's: one 64-bit add per tile; evaluating the closed forms per load made the kernel scalar-bound: 27.5 us
+// at N=128, T=32, d=7 -- a third of the iteration -- and 100-137 us per C4 launch whatever the thread layout).  An
+// element is a sum over up to N / NW slab rows (column side) and one segment per workgroup that met the row's tile (row
+// side: a handful in large launches, up to ~100 in small ones, where a workgroup owns one or two columns): wavefront w
+// adds the w-th quarter of each list, sixteen loads in flight, and the four partial sums are joined in wavefront order.
+constexpr int RED_W = 4; // (8 wavefronts of half the share each: 78 us instead of 66 at C4)
+__global__ __launch_bounds__(RED_W * 64) void grad_reduce_kernel(GradReduceArgs r)
 {
-    const int e = blockIdx.x * RED_T + threadIdx.x;
-    const int i = blockIdx.y;
-    if (e >= r.TD) return;
+    __shared__ double part[RED_W][64];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int e = blockIdx.x * 64 + lane;
+    const int i = r.A - 1 - (int)blockIdx.y; // rows with the longest column sums first (66 -> 60 us at C4)
+    const bool live = e < r.TD;
     double s = 0.0;
-    // row side: the segments of the row's tile, one per workgroup whose item range met it
-    const int ti = i / r.NW, wv = i % r.NW;
-    const int kqr = r.tm.kq_of_tile(ti);
-    if (kqr >= 0) {
-        const long long S0 = r.tm.start(kqr, r.B, r.NW, r.sym);
-        const long long cn = r.sym ? r.B - ti * r.NW : r.B;
-        // workgroup w works on the items [nitems*w/grid, nitems*(w+1)/grid): the one holding item x is
-        const int wlo = (int)(((S0 + 1) * r.grid - 1) / r.nitems), whi = (int)(((S0 + cn) * r.grid - 1) / r.nitems);
-        const double *base = r.rseg + ((size_t)kqr * r.NW + wv) * r.TD + e;
-        for (int w = wlo; w <= whi; w += 8) {
-            double v[8];
+    if (live) {
+        // row side: the segments of the row's tile, one per workgroup whose item range met it
+        const int ti = i / r.NW, wv = i % r.NW;
+        const int kqr = r.tm.kq_of_tile(ti);
+        if (kqr >= 0) {
+            const long long S0 = r.tm.start(kqr, r.B, r.NW, r.sym);
+            const long long cn = r.sym ? r.B - ti * r.NW : r.B;
+            // workgroup w works on the items [nitems*w/grid, nitems*(w+1)/grid): the one holding item x is
+            const int wlo = (int)(((S0 + 1) * r.grid - 1) / r.nitems), whi = (int)(((S0 + cn) * r.grid - 1) / r.nitems);
+            const int nseg = whi - wlo + 1, per = (nseg + RED_W - 1) / RED_W;
+            const int w0 = wlo + wave * per, w1 = min(whi + 1, w0 + per);
+            const size_t sstride = (size_t)r.NW * r.TD;
+            const double *base = r.rseg + ((size_t)kqr * r.NW + wv) * r.TD + e + (size_t)w0 * sstride;
+            for (int w = w0; w < w1; w += 8, base += 8 * sstride) {
+                double v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = (w + u <= whi) ? base[(size_t)(w + u) * r.NW * r.TD] : 0.0;
+                for (int u = 0; u < 8; ++u) v[u] = (w + u < w1) ? base[u * sstride] : 0.0;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) s += v[u];
-        }
-    }
-    // column side: the items (owned tile, column i) of the tiles whose first row is <= i, in the order of the enumeration
-    if (r.sym) {
-        for (int kq = 0; kq < r.tm.owned; kq += 16) {
-            float v[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int tu = kq + u < r.tm.owned ? r.tm.tile_of(kq + u) : r.tm.ntile;
-                const bool in = tu * r.NW <= i && tu < r.tm.ntile;
-#ifdef SIG_EXP_SEQ_SLAB // timing experiment only: consecutive slab rows per output row (wrong results)
-                const long long it = in ? ((long long)i * 64 + kq + u) % r.nitems : 0;
-#else
-                const long long it = in ? r.tm.start(kq + u, r.B, r.NW, 1) + (i - tu * r.NW) : 0;
-#endif
-                v[u] = in ? r.cslab[(size_t)it * r.TD + e] : 0.f;
+                for (int u = 0; u < 8; ++u) s += v[u];
             }
+        }
+        // column side: the items (owned tile, column i) of the tiles whose first row is <= i, in the order of the enumeration
+        if (r.sym) {
+            const int per = (r.tm.owned + RED_W - 1) / RED_W;
+            const int k0 = wave * per, k1 = min(r.tm.owned, k0 + per);
+            // slab row of item (tile kq, column i) = start(kq) + i - tile * NW; start(kq + 1) = start(kq) + B - tile * NW
+            const float *row = r.cslab + (size_t)(k0 < k1 ? r.tm.start(k0, r.B, r.NW, 1) : 0) * r.TD + e;
+            for (int kq = k0; kq < k1; kq += 16) {
+                float v[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) s += (double)v[u];
+                for (int u = 0; u < 16; ++u) {
+                    const bool have = kq + u < k1;
+                    const int first = have ? r.tm.tile_of(kq + u) * r.NW : r.B; // first row of the tile
+                    const bool in = first <= i;
+                    v[u] = in ? row[(size_t)(in ? i - first : 0) * r.TD] : 0.f;
+                    row += have ? (size_t)(r.B - first) * r.TD : 0;
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) s += (double)v[u];
+            }
         }
     }
+    part[wave][lane] = s;
+    __syncthreads();
+    if (wave != 0 || !live) return;
+    s = part[0][lane];
+#pragma unroll
+    for (int w = 1; w < RED_W; ++w) s += part[w][lane];
     const size_t idx = (size_t)i * r.TD + e;
     if (r.out64)
         static_cast<double *>(r.out)[idx] = s;
@@ -914,8 +928,7 @@ int grad_reduce_launch(const GradGeom &g, const double *rseg, const float *cslab
         set_error("gradient reduction: %d rows exceed the grid limit", A);
         return SIGSVGD_E_UNSUPPORTED;
     }
-    const int rt = TD >= RED_T ? RED_T : ((TD + 63) / 64) * 64; // (short rows: no idle wavefronts)
-    hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)((TD + RED_T - 1) / RED_T), (unsigned)A), dim3(rt), 0, stream, r);
+    hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)((TD + 63) / 64), (unsigned)A), dim3(RED_W * 64), 0, stream, r);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "launch grad_reduce_kernel");
     return SIGSVGD_OK;

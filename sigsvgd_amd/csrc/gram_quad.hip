@@ -393,7 +393,13 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
 #ifdef SIGSVGD_PHASE_STAMPS
     unsigned long long ph_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast_ = __builtin_amdgcn_s_memtime();
 #endif
-    float *dcw = a.dcache ? a.dcache + ((size_t)blockIdx.x * QNW + wave) * (3 * 64 * 64) : nullptr;
+    float *dcw = a.dcache ? a.dcache + ((size_t)blockIdx.x * QNW + wave) * (6 * 64 * 64) : nullptr;
+    // KSTORE (8-channel layout): the forward solution of the three quadrants whose reverse sweep comes later waits in the
+    // scratch next to the increments, and each quadrant is swept forwards once (4 / 4 / 4 sweeps and passes, the minimum)
+    // instead of being re-swept before its reverse sweep (7 forward sweeps): T=100, d=7 symmetric 2.80 -> 2.70 ms, ordered
+    // 4.19 -> 3.93 at N=256.  The 16-channel layout keeps the re-sweep: there the 64 extra loads in front of the reverse sweep
+    // and 35 more spilled registers cost more than the sweep (4.42 -> 4.54 ms symmetric at T=128, d=14).
+    constexpr bool KSTORE = DPAD == 8;
 
     // Work distribution as in gram_fast.hip: the items of a launch -- (owned row tile, column), tile-major; symmetric
     // launches only the columns from the tile's first row on -- all cost the same (the 8 waves meet at a barrier per
@@ -628,6 +634,11 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                     const float *dp = dcw + dslot * 4096 + lv;
 #pragma unroll
                     for (int k = 0; k < 64; ++k) Dsl[k] = dp[k * 64];
+                    if (KSTORE) { // ... and the forward solution with them: no forward sweep on this visit
+                        const float *kp = dcw + (3 + dslot) * 4096 + lv;
+#pragma unroll
+                        for (int k = 0; k < 64; ++k) Ssl[k] = kp[k * 64];
+                    }
                 } else {
                     const double *ybase = yd + (128 * h + 64 - lv) * YDS; // local column (t - lane) & 63 == ybase + t * YDS
                     // the point column that closes the last cell column of half 0 (column 64) is outside the ring
@@ -691,7 +702,7 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
 
                 SIG_QSTAMP(1)
                 // ---- phase 2: forward sweep of the quadrant -----------------------------------------------------
-                {
+                if (!KSTORE || dmode != 2) {
                     const float *topb = (b ? hK : ones) + 64 * h; // K[64 b][64 h + q + 1] for lane 0 on step sigma = q
                     if (h == 0) { // a new band: left boundary column of ones
                         fc = 1.f;
@@ -719,6 +730,11 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                     asm volatile("" ::: "memory");
                     quad_fwd_all<0>(fc, fuA, fuB, fV, Dsl, Ssl, wr, rows, hbf, haddr, hinc, r3);
                     asm volatile("" ::: "memory");
+                    if (KSTORE && dmode == 1) { // reverse sweep and gradient pass follow on a later visit
+                        float *kp = dcw + (3 + dslot) * 4096 + lv;
+#pragma unroll
+                        for (int k = 0; k < 64; ++k) kp[k * 64] = Ssl[k];
+                    }
                 }
                 if (b == 0 && h == 0) {
                     svc = fc;
@@ -1009,7 +1025,7 @@ bool quad_supported(int A, int B, int T, int d, int n, int kind, unsigned flags)
 
 namespace {
 inline int quad_cu_count() { return device_cu_count(); } // the grid is at most one workgroup per CU
-constexpr size_t QUAD_DCACHE_PER_WG = (size_t)QNW * 3 * 64 * 64 * sizeof(float); // 384 KB
+constexpr size_t QUAD_DCACHE_PER_WG = (size_t)QNW * 6 * 64 * 64 * sizeof(float); // 768 KB: increments (+ forward solution, 8-channel layout) of 3 quadrants
 constexpr size_t QUAD_CREC_PER_WG = (size_t)QNW * QREC * sizeof(float);          // 208 KB
 constexpr size_t QUAD_ROWG_PER_WG = (size_t)QNW * 128 * 16 * sizeof(float);      // 64 KB (d = 15, 16 only)
 
