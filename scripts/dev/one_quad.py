@@ -1,5 +1,5 @@
 import sys, torch
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from sigsvgd_amd.utils.synthetic import synthetic_inputs
 from sigsvgd_amd import ops
 dev = torch.device('cuda:0')

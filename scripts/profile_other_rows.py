@@ -37,5 +37,6 @@ for _ in range(10):
     ops.vec_kernel(sq, V, V, _lib.VEC_GAUSSIAN, 1 / 448.0, -1 / 448.0)
     ops.vec_kernel_fused(V, V, _lib.VEC_GAUSSIAN, 1 / 448.0, -1 / 448.0)
     S = ops.signature(P, 3, basepoint=True)
+    ops.signature_backward(P, S, 3, basepoint=True)
 torch.cuda.synchronize()
 print("ok", float(K.sum()), tuple(S.shape))
