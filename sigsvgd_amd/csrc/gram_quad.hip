@@ -142,13 +142,16 @@ __device__ __forceinline__ float q_wave_sum63(float v)
 // telescope (constant column paths: zero gradient up to one fp32 rounding) only if every point sees the same bits.
 // The differences are handed back: both gradient contractions take them (sum R G (x~_m - y~_n); the split form
 // x~_m * sum R G - sum R G y~_n cancels catastrophically once consecutive points lie more than a bandwidth apart).
-template <int DPAD>
+// (DC: channels that can be non-zero, even; the pairs beyond it are left out of the sum and their differences set to 0)
+template <int DPAD, int DC = DPAD>
 __device__ __forceinline__ float q_gval(const float (&xf)[DPAD], const qf32x2 (&y2)[DPAD / 2], float ns32,
                                         qf32x2 (&df)[DPAD / 2])
 {
     qf32x2 e2 = qf32x2{0.f, 0.f};
 #pragma unroll
-    for (int c = 0; c < DPAD / 2; ++c) {
+    for (int c = DC / 2; c < DPAD / 2; ++c) df[c] = qf32x2{0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < DC / 2; ++c) {
         df[c] = qf32x2{xf[2 * c], xf[2 * c + 1]} - y2[c];
         e2 = __builtin_elementwise_fma(df[c], df[c], e2);
     }
@@ -351,6 +354,10 @@ template <int DPAD, bool GRAD, bool SYM, bool ROWG = false>
 __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void gram_quad_kernel(QuadArgs a)
 {
     constexpr int NT = QNW * 64;
+    // Channels the hot loops touch: the 16-channel gradient instantiation without ROWG serves d <= 14 only (d = 15, 16 take
+    // the ROWG one), so the last channel pair is all zeros there -- the bimanual arm of BASELINE.json's stress config has
+    // d = 14 -- and drops out of the static kernel's dot product, the fp32 kernel value and both contractions.
+    constexpr int DC = (DPAD == 16 && GRAD && !ROWG) ? 14 : DPAD;
     constexpr int CS = DPAD + 1;  // values per point column of the column-side sums: DPAD channels and the weight sum
     constexpr int YDS = DPAD + 2; // fp64 row: coordinates, [DPAD] = -log2(e)/h * |y~|^2
     constexpr int YFS = (DPAD == 16) ? 18 : 12; // fp32 row (8-byte aligned; 18 l mod 64 visits 32 distinct even banks)
@@ -397,9 +404,9 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
     // KSTORE (8-channel layout): the forward solution of the three quadrants whose reverse sweep comes later waits in the
     // scratch next to the increments, and each quadrant is swept forwards once (4 / 4 / 4 sweeps and passes, the minimum)
     // instead of being re-swept before its reverse sweep (7 forward sweeps): T=100, d=7 symmetric 2.80 -> 2.70 ms, ordered
-    // 4.19 -> 3.93 at N=256.  The 16-channel layout keeps the re-sweep: there the 64 extra loads in front of the reverse sweep
-    // and 35 more spilled registers cost more than the sweep (4.42 -> 4.54 ms symmetric at T=128, d=14).
-    constexpr bool KSTORE = DPAD == 8;
+    // 4.19 -> 3.93 at N=256; T=128, d=14 ordered 5.52 -> 5.37.  The symmetric 16-channel instantiation keeps the re-sweep:
+    // there the 64 extra loads in front of the reverse sweep and the registers they cost outweigh the sweep (3.83 -> 4.01 ms).
+    constexpr bool KSTORE = DPAD == 8 || !SYM;
 
     // Work distribution as in gram_fast.hip: the items of a launch -- (owned row tile, column), tile-major; symmetric
     // launches only the columns from the tile's first row on -- all cost the same (the 8 waves meet at a barrier per
@@ -656,19 +663,20 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                     // the exponential that follows covers the LDS latency, and there is no second row buffer to keep
                     double yrow[DPAD + 1];
 #pragma unroll
-                    for (int c = 0; c <= DPAD; ++c) yrow[c] = ybase[c];
+                    for (int c = 0; c <= DPAD; ++c) yrow[c] = (c < DC || c == DPAD) ? ybase[c] : 0.0;
 #pragma unroll
                     for (int t = 0; t < 66; ++t) {
                         double g;
                         if (t < 64) {
                             double e2 = xn + yrow[DPAD];
 #pragma unroll
-                            for (int c = 0; c < DPAD; ++c) e2 = __builtin_fma(xs[c], yrow[c], e2);
+                            for (int c = 0; c < DC; ++c) e2 = __builtin_fma(xs[c], yrow[c], e2);
                             asm volatile("" : "+v"(e2));
                             if (t < 63) {
                                 const double *yr = ybase + (t + 1) * YDS;
 #pragma unroll
-                                for (int c = 0; c <= DPAD; ++c) yrow[c] = yr[c];
+                                for (int c = 0; c <= DPAD; ++c)
+                                    if (c < DC || c == DPAD) yrow[c] = yr[c];
                             }
                             qexp7_pin(ek);
                             g = qexp2_p7(e2, ek);
@@ -812,7 +820,7 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                     const float *yfb = yf + (128 * h + 64 - lv) * YFS;
                     qf32x2 ynx[DPAD / 2]; // the y~ row of the next iteration (fetched one iteration ahead)
 #pragma unroll
-                    for (int c = 0; c < DPAD / 2; ++c) ynx[c] = reinterpret_cast<const qf32x2 *>(yfb)[c];
+                    for (int c = 0; c < DPAD / 2; ++c) ynx[c] = c < DC / 2 ? reinterpret_cast<const qf32x2 *>(yfb)[c] : qf32x2{0.f, 0.f};
                     SIG_QSTAMP(6)
 #pragma unroll
                     for (int it = 0; it < 64; ++it) {
@@ -822,7 +830,7 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                         if (it < 63) {
                             const qf32x2 *yn = reinterpret_cast<const qf32x2 *>(yfb + (it + 1) * YFS);
 #pragma unroll
-                            for (int c = 0; c < DPAD / 2; ++c) ynx[c] = yn[c];
+                            for (int c = 0; c < DC / 2; ++c) ynx[c] = yn[c];
                         }
                         const float Scur = Ssl[it];
                         const float Na = q_shr_zero(Scur); // S[l-1][n+1]
@@ -835,20 +843,25 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                         Nb = Na;
                         Sprev = Scur;
                         qf32x2 df[DPAD / 2];
-                        const float gv = q_gval<DPAD>(xf, yr2, ns32, df);
+                        const float gv = q_gval<DPAD, DC>(xf, yr2, ns32, df);
                         const float rg = R * gv;
                         const qf32x2 rg2 = {rg, rg};
 #pragma unroll
-                        for (int c = 0; c < DPAD / 2; ++c) acc[c] = __builtin_elementwise_fma(rg2, df[c], acc[c]);
+                        for (int c = 0; c < DC / 2; ++c) acc[c] = __builtin_elementwise_fma(rg2, df[c], acc[c]);
                         // pin the running sums here: the contraction must stay inside its iteration
 #pragma unroll
-                        for (int c = 0; c < DPAD / 2; ++c) asm volatile("" : "+v"(acc[c]));
+                        for (int c = 0; c < DC / 2; ++c) asm volatile("" : "+v"(acc[c]));
                         if (SYM) {
                             const float rgw = rg * w_ji;
+                            const qf32x2 rgw2 = {rgw, rgw};
 #pragma unroll
-                            for (int c = 0; c < DPAD; ++c) tacc[c] = q_add_ror1(tacc[c], rgw * df[c / 2][c % 2]);
+                            for (int c = 0; c < DC / 2; ++c) { // (packed products: half the multiplies)
+                                const qf32x2 pr = rgw2 * df[c];
+                                tacc[2 * c] = q_add_ror1(tacc[2 * c], pr[0]);
+                                tacc[2 * c + 1] = q_add_ror1(tacc[2 * c + 1], pr[1]);
+                            }
 #pragma unroll
-                            for (int c = 0; c < DPAD; ++c) asm volatile("" : "+v"(tacc[c]));
+                            for (int c = 0; c < DC; ++c) asm volatile("" : "+v"(tacc[c]));
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
@@ -966,24 +979,40 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
             // own row of the column slab.
             __syncthreads(); // (also makes the other wavefronts' records visible: workgroup-scope release / acquire)
             float *dstc = a.cslab + (size_t)item * (T * d);
-            for (int e = tidp; e < T * DPAD; e += NT) {
-                const int n = e / DPAD, c = e % DPAD;
+            // thread -> (channel c, point n) with n fastest: a wavefront reads 64 consecutive floats of a record per load
+            // (with the channel fastest every lane touched its own 256-B line), all 24 loads of an element in flight;
+            // plain loads: the records were written on this CU, whose L1 is coherent with its own stores
+            for (int e = tidp; e < 128 * DPAD; e += NT) {
+                const int c = e >> 7, n = e & 127;
                 const int hq = n >> 6, q = n & 63, ln = (63 - q) & 63;
-                float sx = 0.f;
-#pragma unroll 1
+                float v1[QNW], v0[QNW], v64[QNW];
+#pragma unroll
                 for (int w = 0; w < QNW; ++w) {
-                    if (i0 + w >= a.A || j < i0 + w) continue; // that wavefront had no pair
                     const float *rb = a.crec + ((size_t)blockIdx.x * QNW + w) * QREC;
-                    auto ldr = [&](int k) { return __hip_atomic_load(rb + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-                    if (nrows1 > 0) sx += ldr(((2 + hq) * CS + c) * 64 + ln);            // pass over quadrant (1, hq)
-                    if (hq == 0 || nrows1 > 0) sx += ldr((hq * CS + c) * 64 + ln);       // pass over quadrant (0, hq)
-                    sx += ldr(((4 + hq) * CS + c) * 64 + q);                             // point row 64
-                    if (q == 0) {                                                        // seam columns 0 and 64, per band
-                        sx += ldr(6 * CS * 64 + hq * CS + c);
-                        if (nrows1 > 0) sx += ldr(6 * CS * 64 + (2 + hq) * CS + c);
+                    v1[w] = rb[((2 + hq) * CS + c) * 64 + ln]; // pass over quadrant (1, hq)
+                    v0[w] = rb[(hq * CS + c) * 64 + ln];       // pass over quadrant (0, hq)
+                    v64[w] = rb[((4 + hq) * CS + c) * 64 + q]; // point row 64
+                }
+                float sx = 0.f;
+#pragma unroll
+                for (int w = 0; w < QNW; ++w) {
+                    const bool has = i0 + w < a.A && j >= i0 + w; // that wavefront had a pair
+                    float t = 0.f;
+                    if (nrows1 > 0) t += v1[w];
+                    if (hq == 0 || nrows1 > 0) t += v0[w];
+                    t += v64[w];
+                    sx += has ? t : 0.f;
+                }
+                if (q == 0) { // seam columns 0 and 64, per band
+#pragma unroll 1
+                    for (int w = 0; w < QNW; ++w) {
+                        if (i0 + w >= a.A || j < i0 + w) continue;
+                        const float *rb = a.crec + ((size_t)blockIdx.x * QNW + w) * QREC + 6 * CS * 64;
+                        sx += rb[hq * CS + c];
+                        if (nrows1 > 0) sx += rb[(2 + hq) * CS + c];
                     }
                 }
-                if (c < d) dstc[n * d + c] = -m2h * sx;
+                if (n < T && c < d) dstc[n * d + c] = -m2h * sx;
             }
             SIG_QSTAMP(9)
         }
