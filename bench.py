@@ -129,14 +129,25 @@ def committed_counters():
     instantiation and the git revision they were taken on).  None when a file is absent."""
     out = {"traffic": None, "valu_issue": None}
     try:
+        # the dominant "kernel" of an iteration is two launches since round 3: the pair kernel writes the gradient's partial
+        # sums, grad_reduce_kernel reads them back and adds them in a fixed order -- both are counted
         with open(PMC_TRAFFIC_CSV) as f:
-            rows = [r for r in csv.DictReader(f) if "gram_fast_kernel" in r["kernel"]]
-        fetch = [float(r["bytes_per_dispatch"]) for r in rows if r["counter"] == "FETCH_SIZE"]
-        write = [float(r["bytes_per_dispatch"]) for r in rows if r["counter"] == "WRITE_SIZE"]
-        if fetch and write:
-            out["traffic"] = sum(fetch) / len(fetch) + sum(write) / len(write)
-            out["traffic_detail"] = {"fetch_bytes": sum(fetch) / len(fetch), "write_bytes": sum(write) / len(write),
-                                     "kernel": rows[0]["kernel"], "revision": rows[0].get("revision"),
+            rows = [r for r in csv.DictReader(f) if "gram_fast_kernel" in r["kernel"] or "grad_reduce_kernel" in r["kernel"]]
+        per = {}
+        for r in rows:
+            name = "gram_fast_kernel" if "gram_fast_kernel" in r["kernel"] else "grad_reduce_kernel"
+            per.setdefault((name, r["counter"]), []).append(float(r["bytes_per_dispatch"]))
+        mean = {k: sum(v) / len(v) for k, v in per.items()}
+        if all((k, c) in mean for k in ("gram_fast_kernel", "grad_reduce_kernel") for c in ("FETCH_SIZE", "WRITE_SIZE")):
+            fetch = mean[("gram_fast_kernel", "FETCH_SIZE")] + mean[("grad_reduce_kernel", "FETCH_SIZE")]
+            write = mean[("gram_fast_kernel", "WRITE_SIZE")] + mean[("grad_reduce_kernel", "WRITE_SIZE")]
+            # gfx950: FETCH_SIZE tallies 128-B read requests at 64 B (MI355X_MICROARCH.md, HBM); calibrated on this path's
+            # own access pattern: the reduction kernel reads a known 129.4 MB at C4 and the counter says 64.7 MB, while
+            # WRITE_SIZE matches the known 133.6 MB of the pair kernel exactly (DESIGN.md section 6) -> reads are doubled
+            out["traffic"] = 2.0 * fetch + write
+            out["traffic_detail"] = {"fetch_bytes_raw": fetch, "write_bytes_raw": write, "fetch_correction": 2.0,
+                                     "per_kernel_raw": {f"{k}:{c}": v for (k, c), v in sorted(mean.items())},
+                                     "revision": rows[0].get("revision"),
                                      "source": os.path.relpath(PMC_TRAFFIC_CSV, ROOT)}
     except (OSError, KeyError, ValueError):
         pass
@@ -308,8 +319,8 @@ def main(argv=None, backend_cls=HipBackend, script=None) -> int:
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            # HBM-side bytes per launch: FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes, read from the
-            # committed summary (null if it is missing); raw counters, 4-8 B/lane accesses (no x2 correction applies)
+            # HBM-side bytes per launch (pair kernel + reduction kernel): 2 x FETCH_SIZE + WRITE_SIZE of separate
+            # rocprofv3 --pmc passes, read from the committed summary (null if it is missing); see committed_counters()
             "traffic": pmc["traffic"],
             "traffic_detail": pmc.get("traffic_detail"),
             "algorithmic_bytes_per_launch": by,

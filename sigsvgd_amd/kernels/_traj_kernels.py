@@ -96,8 +96,9 @@ class SignatureKernel:
         self.kernel = SigKernel(static_kernel, dyadic_order=depth)
 
     def __call__(self, X, Y, **kwargs):
-        # The reference upcasts to fp64 around compute_Gram and casts K back; the HIP kernels read
-        # fp32/fp64 paths directly and always run the PDE in fp64, so no copies are needed.
+        # The reference upcasts to fp64 around compute_Gram and casts K back; the HIP kernels read fp32/fp64 paths
+        # directly (static kernel and increments in fp64, sweeps in fp32 difference form or fp64 depending on the
+        # kernel: DESIGN.md §3), so no copies are needed.
         return self.kernel.compute_Gram(X, Y)
 
     def gram_and_grad(self, X, grad_out=None):

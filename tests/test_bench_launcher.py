@@ -67,7 +67,7 @@ def test_committed_counters_parse():
 
     c = bench.committed_counters()
     if os.path.exists(bench.PMC_TRAFFIC_CSV):
-        assert c["traffic"] and c["traffic"] > 0 and "gram_fast_kernel" in c["traffic_detail"]["kernel"]
+        assert c["traffic"] and c["traffic"] > 0 and "gram_fast_kernel:WRITE_SIZE" in c["traffic_detail"]["per_kernel_raw"]
     else:
         assert c["traffic"] is None
     if os.path.exists(bench.PMC_SQ_CSV):
