@@ -1,7 +1,9 @@
 """Per-entry accuracy of the fp32 difference-form sweeps against the fp64 oracle over roughness, bandwidth and offset
 (VERDICT round 2, item 2).  For every regime: N paths = cumsum(scale * randn) + offset, RBF bandwidth h; the HIP Gram +
-gradient (symmetric and ordered launches) against oracle/sigkernel_c.c; reported: worst per-entry |K - K_ref| / |K_ref|,
-worst gradient error relative to max |grad_ref|, and the range of K.  Writes a markdown table (argv[1])."""
+gradient (symmetric and ordered launches) against oracle/sigkernel_c.c; reported: worst per-entry |K - K_ref| / |K_ref|
+over the entries >= 0.1, worst absolute error over the entries < 0.1 (pairs whose solution has cancelled 90 % of the
+boundary value 1: the fp32 sweeps resolve K like values near 1), worst gradient error relative to max |grad_ref|, and the
+range of K.  Shapes: the register-resident, quadrant and refined-grid kernels.  Writes a markdown table (argv[1])."""
 import sys
 
 import numpy as np
@@ -15,7 +17,8 @@ dev = torch.device("cuda:0")
 SCALES = [0.01, 0.02, 0.05, 0.1, 0.2, 0.5]
 HS = [0.02, 0.1, 0.5, 1.0, 3.0, 10.0]
 OFFSETS = [0.0, 100.0]
-SHAPES = [(12, 64, 7), (12, 32, 7), (10, 128, 14), (10, 100, 5)]
+SHAPES = [(12, 64, 7, 0), (12, 32, 7, 0), (10, 128, 14, 0), (10, 100, 5, 0), (12, 64, 2, 0), (12, 20, 2, 2), (12, 5, 2, 5), (12, 30, 4, 2)]
+KFLOOR = 0.1  # entries below it are held to an absolute error (fp32 sweeps resolve K like values near 1)
 
 
 def paths(N, T, d, scale, offset, seed=0):
@@ -25,37 +28,45 @@ def paths(N, T, d, scale, offset, seed=0):
 
 def main(out_path):
     C.build()
-    lines = ["| N,T,d | scale | h | offset | K range | worst per-entry K error (sym / ordered) | gradient error / max (sym / ordered) |",
-             "|---|---|---|---|---|---|---|"]
+    lines = ["| N,T,d | scale | h | offset | K range | worst per-entry relative K error, entries >= 0.1 (sym / ordered) | "
+             "worst absolute K error, entries < 0.1 | gradient error / max (sym / ordered) |",
+             "|---|---|---|---|---|---|---|---|"]
     worst = (0.0, None)
     worst_g = (0.0, None)
     skipped = 0
-    for (N, T, d) in SHAPES:
+    worst_small = (0.0, None)
+    for (N, T, d, n) in SHAPES:
         for scale in SCALES:
             for h in HS:
                 for off in OFFSETS:
                     X = paths(N, T, d, scale, off)
-                    Kref, gref = C.gram_fwd_bwd(X, X, h, 0)
+                    Kref, gref = C.gram_fwd_bwd(X, X, h, n)
                     if not np.isfinite(Kref).all() or Kref.max() > 1e30:  # beyond fp32 range: no fp32 answer exists
                         skipped += 1
                         continue
                     Xg = torch.as_tensor(X, device=dev)
-                    errs, gerrs = [], []
+                    errs, gerrs, small = [], [], 0.0
+                    big = Kref >= KFLOOR
                     for sym in (True, False):
-                        K, g = ops.gram_fwd_bwd(Xg, Xg if sym else Xg.clone(), 1.0 / h, 0, y_is_x=sym)
+                        K, g = ops.gram_fwd_bwd(Xg, Xg if sym else Xg.clone(), 1.0 / h, n, y_is_x=sym)
                         Kn, gn = K.double().cpu().numpy(), g.double().cpu().numpy()
-                        errs.append(float((np.abs(Kn - Kref) / np.abs(Kref)).max()))
+                        errs.append(float((np.abs(Kn - Kref)[big] / np.abs(Kref)[big]).max()))
+                        if (~big).any():
+                            small = max(small, float(np.abs(Kn - Kref)[~big].max()))
                         gm = np.abs(gref).max()
                         gerrs.append(float(np.abs(gn - gref).max() / gm) if gm > 0 else 0.0)
-                    tag = (N, T, d, scale, h, off)
+                    tag = (N, T, d, n, scale, h, off)
+                    if small > worst_small[0]:
+                        worst_small = (small, tag)
                     if max(errs) > worst[0]:
                         worst = (max(errs), tag)
                     if max(gerrs) > worst_g[0]:
                         worst_g = (max(gerrs), tag)
-                    lines.append(f"| {N},{T},{d} | {scale} | {h} | {off:g} | {Kref.min():.3g} .. {Kref.max():.3g} | "
-                                 f"{errs[0]:.1e} / {errs[1]:.1e} | {gerrs[0]:.1e} / {gerrs[1]:.1e} |")
+                    lines.append(f"| {N},{T},{d} order {n} | {scale} | {h} | {off:g} | {Kref.min():.3g} .. {Kref.max():.3g} | "
+                                 f"{errs[0]:.1e} / {errs[1]:.1e} | {small:.1e} | {gerrs[0]:.1e} / {gerrs[1]:.1e} |")
     head = [f"# fp32 difference-form sweeps vs the fp64 oracle, per entry ({len(lines) - 2} regimes, {skipped} skipped: K beyond fp32 range)",
-            "", f"worst per-entry K error: {worst[0]:.2e} at (N,T,d,scale,h,offset) = {worst[1]}",
+            "", f"worst per-entry relative K error over the entries >= {KFLOOR}: {worst[0]:.2e} at (N,T,d,order,scale,h,offset) = {worst[1]}",
+            f"worst absolute K error over the entries < {KFLOOR}: {worst_small[0]:.2e} at {worst_small[1]}",
             f"worst gradient error / max|grad|: {worst_g[0]:.2e} at {worst_g[1]}", ""]
     with open(out_path, "w") as f:
         f.write("\n".join(head + lines) + "\n")

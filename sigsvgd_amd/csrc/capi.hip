@@ -122,6 +122,9 @@ static int dispatch(const GramProblem &p)
     // long paths (65 <= T <= 128): the quadrant kernel (stored forward solution, any roughness)
     if (!(p.flags & SIGSVGD_FLAG_FORCE_GENERIC) && quad_supported(p.A, p.B, p.T, p.d, p.n, p.kind, p.flags))
         return quad_launch(p);
+    // short paths with dyadic refinement whose refined grid has 64 .. 128 cells per side (the reference's own call shapes)
+    if (!(p.flags & SIGSVGD_FLAG_FORCE_GENERIC) && dyad_supported(p.A, p.B, p.T, p.d, p.n, p.kind, p.flags))
+        return dyad_launch(p);
     return generic_launch(p);
 }
 
@@ -147,6 +150,8 @@ int sigsvgd_gram_workspace_bytes(int A, int B, int T, int d, int dyadic_order, i
         return fast_workspace_bytes(A, B, T, d, want_grad, flags, bytes);
     if (!(flags & SIGSVGD_FLAG_FORCE_GENERIC) && quad_supported(A, B, T, d, dyadic_order, SIGSVGD_STATIC_RBF, flags))
         return quad_workspace_bytes(A, B, T, d, want_grad, bytes);
+    if (!(flags & SIGSVGD_FLAG_FORCE_GENERIC) && dyad_supported(A, B, T, d, dyadic_order, SIGSVGD_STATIC_RBF, flags))
+        return dyad_workspace_bytes(A, B, T, d, want_grad, bytes);
     return generic_workspace_bytes(A, B, T, d, dyadic_order, want_grad, bytes);
 }
 

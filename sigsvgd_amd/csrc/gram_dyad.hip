@@ -1,0 +1,497 @@
+// Signature-kernel Gram forward/backward for SHORT paths with DYADIC REFINEMENT -- the shapes the reference's own
+// scripts use (T = 3 .. 33 points, dyadic order 2 .. 6: examples/script_planning_obstacle_field.py:156-158,325,
+// script_planning_robot.py:391, BASELINE.json config C1) -- on the register-resident sweep engine of the quadrant kernel.
+//
+// The refined PDE grid has P = (T - 1) * 2^n cells per side, 64 <= P <= 128 here: 2 x 2 quadrants of <= 64 x 64 cells,
+// swept with the hand-written statements of quad_sweeps.h (one wavefront per trajectory pair, lane = cell row, slot =
+// (column + lane) & 63, fp32 difference form, EXEC windows, quadrant hand-over through LDS rows).  What differs from
+// gram_quad.hip is everything around the sweeps, and all of it is small because it lives on the COARSE grid:
+//   * static kernel: T x T values per pair in fp64 (lane = point row), 4-corner increments D_coarse[(T-1)^2] -> LDS (fp32,
+//     scaled by 1 / (r^2 sqrt(12)): the refined increment of every fine cell of a coarse cell, as the stencil wants it);
+//   * a quadrant's increments are GATHERED from that table into the slot registers (64 LDS reads per visit): nothing to
+//     keep between visits, no scratch in global memory;
+//   * after a quadrant's reverse sweep its S = K_fwd * U values are block-summed into S_coarse[(T-1)^2] (fp64, LDS adds
+//     by one wavefront in program order), which is dL/dD_coarse up to 1 / r^2;
+//   * the 4-corner scatter R, the RBF derivative and both contractions run once per pair on the coarse grid, fp32 on the
+//     differences x_m - y_n as in the other kernels.
+// Gradient partial sums leave through the segment / item slabs of grad_reduce_kernel (gram_fast.hip): no atomics between
+// wavefronts, bit-reproducible results.  Until round 3 these shapes ran on the coverage kernel (one wavefront per pair,
+// 53 instructions per PDE step on one dependent chain: 86 us for C1's 136 pairs).
+//
+// Reference semantics: sigkernel _SigKernelGram.forward/backward [RECALLED, SURVEY.md App. A]; static kernel
+// src/kernels/_traj_kernels.py:176-195; callers src/inference/score.py:68-69.
+#include "sig_common.h"
+
+namespace sigsvgd {
+
+struct DyadArgs {
+    const void *X, *Y, *go;
+    void *K;
+    double *rseg; // [owned tiles + workgroups][8][T*d]
+    float *cslab; // [items][T*d] (symmetric launches)
+    int io64, A, B, T, d, n, symw;
+    TileMap tm;
+    long long nitems;
+    double inv_h;
+};
+
+namespace {
+constexpr int DNW = 8;   // wavefronts (rows i) per workgroup
+constexpr int DTMAX = 33; // coarse points per path
+constexpr int DHN = 136;  // hand-over rows: entries 0 .. 129 are read
+
+#include "quad_sweeps.h"
+
+__device__ __forceinline__ double d_ldany(const void *b, size_t i, int io64)
+{
+    return io64 ? static_cast<const double *>(b)[i] : (double)static_cast<const float *>(b)[i];
+}
+__device__ __forceinline__ void d_stany(void *b, size_t i, double v, int io64)
+{
+    if (io64)
+        static_cast<double *>(b)[i] = v;
+    else
+        static_cast<float *>(b)[i] = (float)v;
+}
+} // namespace
+
+template <int DPAD, bool GRAD, bool SYM>
+__global__ __launch_bounds__(DNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void gram_dyad_kernel(DyadArgs a)
+{
+    constexpr int NT = DNW * 64;
+    constexpr int TM = DTMAX - 1; // coarse cells per side at most
+    __shared__ __align__(16) double yd[DTMAX * (DPAD + 1)]; // y~_n in fp64 (centred on y[0]), [DPAD] = -|y~_n|^2 / h
+    __shared__ __align__(16) float yf[DTMAX * DPAD];        // the same in fp32 for the coarse contraction
+    __shared__ double yref[DPAD];
+    __shared__ float ones[DHN];
+    struct WaveLds {
+        double Sc[TM * TM];    // block sums of S = K_fwd * U over the fine cells of every coarse cell
+        float Dc[TM * TM];     // coarse increments / (r^2 sqrt(12)); after the last gather: the parked column-side sums
+        float hK[DHN], hU[DHN], hdummy[64];
+        float rowacc[DTMAX * DPAD]; // row-side gradient of the wavefront's particle over the columns of a segment
+    };
+    __shared__ WaveLds wl_all[DNW];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int T = a.T, d = a.d, n = a.n, io64 = a.io64, Tm = T - 1;
+    const int P = Tm << n, nrows1 = P - 64; // cell rows of band 1 = cell columns of half 1 (0 .. 64)
+    const double inv_h = a.inv_h;
+    const float m2h = (float)(-2.0 * inv_h);
+    const double dscale = 1.0 / ((double)(1 << n) * (double)(1 << n) * 3.46410161513775459); // 1 / (r^2 sqrt(12))
+    const double inv_r2 = 1.0 / ((double)(1 << n) * (double)(1 << n));
+    WaveLds &wl = wl_all[wave];
+    float *hK = wl.hK, *hU = wl.hU, *hdummy = wl.hdummy;
+    for (int e = tid; e < DHN; e += NT) ones[e] = 1.f;
+    for (int e = lane; e < DHN; e += 64) hK[e] = 1.f, hU[e] = 1.f;
+
+    // static item ranges: (owned row tile, column), tile-major; symmetric launches only the columns from the tile's first row
+    const long long it0 = a.nitems * blockIdx.x / gridDim.x, it1 = a.nitems * (blockIdx.x + 1) / gridDim.x;
+    int remaining = (int)(it1 - it0);
+    long long item = it0;
+    int kq = 0, cstart = 0;
+    {
+        long long rem = it0;
+        for (;; ++kq) {
+            const int cn = a.B - (SYM ? a.tm.tile_of(kq) * DNW : 0);
+            if (rem < cn) break;
+            rem -= cn;
+        }
+        cstart = (int)rem;
+    }
+#pragma unroll 1
+    while (remaining > 0) {
+    const int itile = a.tm.tile_of(kq);
+    const int cfirst = SYM ? itile * DNW : 0;
+    const int ncolr = min(a.B - cfirst - cstart, remaining);
+    const int i0 = itile * DNW, i = i0 + wave;
+    const int j0 = cfirst + cstart, j1 = j0 + ncolr;
+    const bool row_ok = i < a.A;
+    if (GRAD)
+        for (int e = lane; e < DTMAX * DPAD; e += 64) wl.rowacc[e] = 0.f;
+
+#pragma unroll 1
+    for (int j = j0; j < j1; ++j, ++item) {
+        int lanep = lane;
+        asm volatile("" : "+v"(lanep));
+        // ---- stage y_j (coarse points, centred on its first point) ------------------------------------------------
+        __syncthreads();
+        for (int e = tid; e < T * DPAD; e += NT) {
+            const int t = e / DPAD, c = e % DPAD;
+            const double r0 = c < d ? d_ldany(a.Y, (size_t)j * T * d + c, io64) : 0.0;
+            const double v = c < d ? d_ldany(a.Y, ((size_t)j * T + t) * d + c, io64) - r0 : 0.0;
+            yd[t * (DPAD + 1) + c] = v;
+            yf[t * DPAD + c] = (float)v;
+            if (t == 0) yref[c] = r0;
+            double s = v * v;
+#pragma unroll
+            for (int off = 1; off < DPAD; off <<= 1) s += __shfl_xor(s, off, 64);
+            if (c == 0) yd[t * (DPAD + 1) + DPAD] = -s * inv_h;
+        }
+        __syncthreads();
+
+        if (row_ok && (!SYM || j >= i)) {
+            float w_ij = 1.f, w_ji = 1.f;
+            if (GRAD) {
+                if (a.go) {
+                    w_ij = (float)d_ldany(a.go, (size_t)i * a.B + j, io64);
+                    if (SYM || a.symw) w_ji = (float)d_ldany(a.go, (size_t)j * a.B + i, io64);
+                    if (a.symw) { w_ij += w_ji; w_ji = w_ij; }
+                } else if (a.symw) {
+                    w_ij = 2.f; w_ji = 2.f;
+                }
+                if (SYM && j == i) w_ji = 0.f; // diagonal pair: first-slot derivative only
+            }
+            // ---- coarse static kernel: lane m = point row m; G[m][b] in fp64, row differences, 4-corner increments --------
+            float xf[DPAD]; // x~_m in fp32 for the coarse contraction
+            {
+                const int m = min(lanep, T - 1);
+                double xs[DPAD], xn = 0.0;
+#pragma unroll
+                for (int c = 0; c < DPAD; ++c) {
+                    const double xc = c < d ? d_ldany(a.X, ((size_t)i * T + m) * d + c, io64) - yref[c] : 0.0;
+                    xn = __builtin_fma(xc, xc, xn);
+                    xs[c] = xc * (2.0 * inv_h);
+                    xf[c] = (float)xc;
+                }
+                xn = -xn * inv_h;
+                double gprev = 0.0;
+                for (int b = 0; b < T; ++b) {
+                    const double *yr = yd + b * (DPAD + 1);
+                    double e2 = xn + yr[DPAD];
+#pragma unroll
+                    for (int c = 0; c < DPAD; ++c) e2 = __builtin_fma(xs[c], yr[c], e2);
+                    const double g = exp64(e2);
+                    const double rd = g - gprev; // G[m][b] - G[m][b-1]
+                    gprev = g;
+                    const double nb = shfl_down_f64(rd); // row m + 1
+                    if (b >= 1 && lanep < Tm) wl.Dc[lanep * Tm + (b - 1)] = (float)((nb - rd) * dscale);
+                }
+                if (GRAD)
+                    for (int e = lanep; e < Tm * Tm; e += 64) wl.Sc[e] = 0.0;
+            }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+
+            float Dsl[64], Ssl[64];
+            float fc = 1.f, fuA = 1.f, fuB = 1.f, fV = 0.f;
+            float svc = 1.f, svA = 1.f, svB = 1.f, svV = 0.f;
+            int fwd_prev = -1;
+            float rc = 1.f, rdA = 1.f, rdB = 1.f, rV = 0.f;
+            int rev_band = -1;
+            bool kdone = false;
+            // visit list, 8 bits per visit: band | half << 1 | reverse << 2 | leave K[64][.] << 3
+            unsigned long long vis = 0;
+            int nv = 0;
+            auto add = [&](int b, int h, int r, int hk) {
+                if ((b ? nrows1 : 64) > 0 && (h ? nrows1 : 64) > 0) {
+                    vis |= (unsigned long long)(b | (h << 1) | (r << 2) | (hk << 3)) << (8 * nv);
+                    ++nv;
+                }
+            };
+            if (GRAD) {
+                if (nrows1 > 0) { // band 0 forward (leaves K[64][.]), band 1, then band 0 again (re-swept: see gram_quad.hip)
+                    add(0, 0, 0, 1); add(0, 1, 0, 1); add(1, 0, 0, 0); add(1, 1, 1, 0);
+                    add(1, 0, 1, 0); add(0, 1, 1, 0); add(0, 0, 1, 0);
+                } else {
+                    add(0, 0, 1, 0);
+                }
+            } else {
+                add(0, 0, 0, 1); add(0, 1, 0, 1); add(1, 0, 0, 0); add(1, 1, 0, 0);
+            }
+            const int b_last = nrows1 > 0 ? 1 : 0, h_last = nrows1 > 0 ? 1 : 0;
+
+#pragma unroll 1
+            for (int v = 0; v < nv; ++v) {
+                const int code = (int)((vis >> (8 * v)) & 255);
+                const int b = code & 1, h = (code >> 1) & 1;
+                const bool rev = (code & 4) != 0, leave_k = (code & 8) != 0;
+                const int nrows = b ? nrows1 : 64, ncols = h ? nrows1 : 64;
+                int lv = lanep;
+                asm volatile("" : "+v"(lv));
+                const unsigned long long rows = nrows >= 64 ? ~0ull : ((1ull << nrows) - 1ull);
+                const unsigned long long wr = ncols >= 64 ? ~0ull : (ncols > 0 ? ~0ull << (64 - ncols) : 0ull);
+
+                // ---- increments of the quadrant: slot k of lane l is local column (k - l) & 63 -----------------------
+                const int arow = min((64 * b + lv) >> n, Tm - 1);
+                const float *dcrow = wl.Dc + arow * Tm;
+                {
+                    int cl = (64 - lv) & 63; // local column of slot 0
+#pragma unroll
+                    for (int k = 0; k < 64; ++k) {
+                        Dsl[k] = dcrow[min((64 * h + cl) >> n, Tm - 1)];
+                        cl = (cl + 1) & 63;
+                    }
+                }
+                // ---- forward sweep ---------------------------------------------------------------------------------
+                {
+                    const float *topb = (b ? hK : ones) + 64 * h;
+                    if (h == 0) {
+                        fc = 1.f;
+                        fV = 0.f;
+                        fuA = (lanep == 0) ? topb[1] : 1.f;
+                        fuB = (lanep == 0) ? topb[0] : 1.f;
+                    } else if (fwd_prev != b) {
+                        fc = svc;
+                        fV = svV;
+                        fuA = svA;
+                        fuB = svB;
+                    }
+                    fwd_prev = b + 2 * h;
+                    const unsigned ho = (unsigned)(size_t)(leave_k ? hK + 64 * h + 1 : hdummy + 63);
+                    int haddr = (int)((lv == 63) ? ho : (unsigned)(size_t)(hdummy + lv));
+                    const int hinc = (lanep == 63 && leave_k) ? 4 : 0;
+                    float r3 = 1.7320508075688772f;
+                    asm volatile("" : "+s"(r3));
+#pragma unroll
+                    for (int k = 0; k < 64; ++k) Ssl[k] = 0.f;
+                    const float hbf = topb[lv + 2];
+                    asm volatile("" ::: "memory");
+                    quad_fwd_all<0, true>(fc, fuA, fuB, fV, Dsl, Ssl, wr, rows, hbf, haddr, hinc, r3, nrows + ncols);
+                    asm volatile("" ::: "memory");
+                }
+                if (b == 0 && h == 0) {
+                    svc = fc;
+                    svV = fV;
+                    svA = fuA;
+                    svB = fuB;
+                }
+                if (!kdone && b == b_last && h == h_last) {
+                    kdone = true;
+                    if (lanep == nrows - 1) {
+                        d_stany(a.K, (size_t)i * a.B + j, (double)fc, io64);
+                        if (SYM && j != i) d_stany(a.K, (size_t)j * a.B + i, (double)fc, io64);
+                    }
+                }
+                if (!GRAD || !rev) continue;
+
+                // ---- reverse sweep (S = K_fwd * U replaces K_fwd slot by slot) ---------------------------------------
+                {
+                    const bool below = (b == 0) && nrows1 > 0;
+                    const float *botb = (below ? hU : ones) + 64 * h;
+                    if (rev_band != b) {
+                        rev_band = b;
+                        rc = 1.f;
+                        rV = 0.f;
+                        const float c1 = botb[ncols], c0 = botb[ncols - 1];
+                        const bool odd = ((62 + ncols) & 1) != 0;
+                        rdA = (lanep == 63) ? (odd ? c0 : c1) : 1.f;
+                        rdB = (lanep == 63) ? (odd ? c1 : c0) : 1.f;
+                    }
+                    const bool leave_u = (b == 1);
+                    const unsigned ho = (unsigned)(size_t)(leave_u ? hU + 64 * h + ncols - 1 : hdummy);
+                    int haddr = (int)((lv == 0) ? ho : (unsigned)(size_t)(hdummy + lv));
+                    const int hinc = (lanep == 0 && leave_u) ? -4 : 0;
+                    float r3 = 1.7320508075688772f;
+                    asm volatile("" : "+s"(r3));
+                    const float hbr = botb[lv], bmr = botb[-h];
+                    asm volatile("" ::: "memory");
+                    quad_rev_all<124, true>(rc, rdA, rdB, rV, Dsl, Ssl, wr, rows, hbr, bmr, haddr, hinc, r3, nrows + ncols);
+                    asm volatile("" ::: "memory");
+                }
+                // ---- block sums of S into the coarse grid (cells outside the grid hold S = 0) -------------------------
+                // A lane's slots walk its row's local columns in order, so the cells of one coarse column form a run: the run
+                // is summed in the lane and added when the coarse column changes (or the slots end).  Lanes of one row block
+                // reach their run ends on different slots, so the adds of one instruction never meet on an address (one add
+                // per cell instead -- r lanes times r slots on the same address -- took 2/3 of the kernel at order 5).
+                {
+                    double *scrow = wl.Sc + arow * Tm;
+                    int cl = (64 - lv) & 63;
+                    int bcur = min((64 * h + cl) >> n, Tm - 1);
+                    float run = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 64; ++k) {
+                        run += Ssl[k];
+                        cl = (cl + 1) & 63;
+                        const int bnext = min((64 * h + cl) >> n, Tm - 1);
+                        if (bnext != bcur || k == 63) {
+                            unsafeAtomicAdd(scrow + bcur, (double)run); // ds_add_f64
+                            run = 0.f;
+                        }
+                        bcur = bnext;
+                    }
+                }
+            } // quadrant visits
+
+            if (GRAD) {
+                // ---- coarse gradient: R = 4-corner scatter of S_coarse / r^2, RBF derivative, both contractions ----------
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                const float ns32 = (float)(-inv_h * 1.4426950408889634074);
+                auto Sat = [&](int aa, int bb) -> float {
+                    return (aa >= 0 && aa < Tm && bb >= 0 && bb < Tm) ? (float)(wl.Sc[aa * Tm + bb] * inv_r2) : 0.f;
+                };
+                // row side: lane m sums over the columns n
+                if (lanep < T) {
+                    const int m = lanep;
+                    float acc[DPAD];
+#pragma unroll
+                    for (int c = 0; c < DPAD; ++c) acc[c] = 0.f;
+                    for (int nn = 0; nn < T; ++nn) {
+                        const float R = (Sat(m - 1, nn - 1) + Sat(m, nn)) - (Sat(m - 1, nn) + Sat(m, nn - 1));
+                        const float *yr = yf + nn * DPAD;
+                        float df[DPAD], e2 = 0.f;
+#pragma unroll
+                        for (int c = 0; c < DPAD; ++c) {
+                            df[c] = xf[c] - yr[c];
+                            e2 = __builtin_fmaf(df[c], df[c], e2);
+                        }
+                        const float rg = R * __builtin_amdgcn_exp2f(e2 * ns32);
+#pragma unroll
+                        for (int c = 0; c < DPAD; ++c) acc[c] = __builtin_fmaf(rg, df[c], acc[c]);
+                    }
+#pragma unroll
+                    for (int c = 0; c < DPAD; ++c)
+                        if (c < d) wl.rowacc[m * DPAD + c] += w_ij * m2h * acc[c];
+                }
+                // column side (Y is X): lane n sums over the rows m; x~_m comes from the lanes through LDS (the parked area)
+                if (SYM) {
+                    float *xl = wl.Dc; // (the increments are not needed any more) x~ rows [T][DPAD], then the parked sums
+                    if (lanep < T) {
+#pragma unroll
+                        for (int c = 0; c < DPAD; ++c) xl[lanep * DPAD + c] = xf[c];
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
+                    float acc[DPAD];
+#pragma unroll
+                    for (int c = 0; c < DPAD; ++c) acc[c] = 0.f;
+                    const int nn = min(lanep, T - 1);
+                    const float *yr = yf + nn * DPAD;
+                    for (int m = 0; m < T; ++m) {
+                        const float R = (Sat(m - 1, nn - 1) + Sat(m, nn)) - (Sat(m - 1, nn) + Sat(m, nn - 1));
+                        const float *xr = xl + m * DPAD;
+                        float df[DPAD], e2 = 0.f;
+#pragma unroll
+                        for (int c = 0; c < DPAD; ++c) {
+                            df[c] = xr[c] - yr[c];
+                            e2 = __builtin_fmaf(df[c], df[c], e2);
+                        }
+                        const float rg = R * __builtin_amdgcn_exp2f(e2 * ns32);
+#pragma unroll
+                        for (int c = 0; c < DPAD; ++c) acc[c] = __builtin_fmaf(rg, df[c], acc[c]);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
+                    if (lanep < T) { // d k(x_j, x_i) / d y_n = -(2/h) sum_m R G (y~_n - x~_m)
+#pragma unroll
+                        for (int c = 0; c < DPAD; ++c) xl[lanep * DPAD + c] = -(w_ji * m2h) * acc[c];
+                    }
+                }
+            }
+        } else if (GRAD && SYM) {
+            for (int e = lane; e < T * DPAD; e += 64) wl.Dc[e] = 0.f; // idle wavefront: nothing to add to the column
+        }
+
+        if (GRAD && SYM) {
+            __syncthreads(); // every wavefront has parked its column-side sums
+            float *dstc = a.cslab + (size_t)item * (T * d);
+            for (int e = tid; e < T * d; e += NT) {
+                const int nn = e / d, c = e - nn * d;
+                float s = 0.f;
+#pragma unroll
+                for (int w = 0; w < DNW; ++w) s += wl_all[w].Dc[nn * DPAD + c];
+                dstc[e] = s;
+            }
+        }
+    }
+    if (GRAD && row_ok) { // the segment's row-side sums
+        const int tot = T * d;
+        double *dstr = a.rseg + (((size_t)(kq + (int)blockIdx.x)) * DNW + wave) * (size_t)tot;
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        for (int e = lane; e < tot; e += 64) {
+            const int m = e / d, c = e - m * d;
+            dstr[e] = (double)wl.rowacc[m * DPAD + c];
+        }
+    }
+    remaining -= ncolr;
+    ++kq;
+    cstart = 0;
+    } // row tiles of the range
+}
+
+bool dyad_supported(int A, int B, int T, int d, int n, int kind, unsigned flags)
+{
+    (void)A; (void)B;
+    if (n < 1 || n > 6 || T < 3 || T > DTMAX || d > 16) return false;
+    const int P = (T - 1) << n;
+    if (P < 64 || P > 128) return false;
+    if (kind != SIGSVGD_STATIC_RBF) return false;
+    if (flags & SIGSVGD_FLAG_NAIVE_SOLVER) return false;
+    return true;
+}
+
+namespace {
+inline GradGeom dyad_geometry(int A, int B, int T, int d, bool sym)
+{
+    return grad_geometry(A, B, T * d, sym, 0, 1, false, DNW, (long long)device_cu_count());
+}
+} // namespace
+
+int dyad_workspace_bytes(int A, int B, int T, int d, int want_grad, size_t *bytes)
+{
+    *bytes = 256;
+    if (!want_grad) return SIGSVGD_OK;
+    const GradGeom o = dyad_geometry(A, B, T, d, false);
+    size_t need = o.rseg_bytes;
+    if (A == B) {
+        const GradGeom y = dyad_geometry(A, B, T, d, true);
+        if (y.rseg_bytes + y.cslab_bytes > need) need = y.rseg_bytes + y.cslab_bytes;
+    }
+    *bytes = need + 512;
+    return SIGSVGD_OK;
+}
+
+namespace {
+template <int DPAD>
+int dyad_launch_variant(const GramProblem &p, DyadArgs &a, const GradGeom &g, bool grad, bool sym)
+{
+    if (g.tm.owned <= 0 || g.nitems <= 0) return SIGSVGD_OK;
+    a.tm = g.tm;
+    a.nitems = g.nitems;
+    dim3 grid((unsigned)g.grid), block(DNW * 64);
+    if (grad && sym)
+        hipLaunchKernelGGL((gram_dyad_kernel<DPAD, true, true>), grid, block, 0, p.stream, a);
+    else if (grad)
+        hipLaunchKernelGGL((gram_dyad_kernel<DPAD, true, false>), grid, block, 0, p.stream, a);
+    else if (sym)
+        hipLaunchKernelGGL((gram_dyad_kernel<DPAD, false, true>), grid, block, 0, p.stream, a);
+    else
+        hipLaunchKernelGGL((gram_dyad_kernel<DPAD, false, false>), grid, block, 0, p.stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "launch gram_dyad_kernel");
+    return SIGSVGD_OK;
+}
+} // namespace
+
+int dyad_launch(const GramProblem &p)
+{
+    const bool grad = p.gradX_out != nullptr;
+    const bool sym = (p.flags & SIGSVGD_FLAG_Y_IS_X) && p.A == p.B;
+    DyadArgs a;
+    a.X = p.X; a.Y = p.Y; a.go = p.grad_out; a.K = p.K_out; a.rseg = nullptr; a.cslab = nullptr;
+    a.io64 = p.dtype == SIGSVGD_F64; a.A = p.A; a.B = p.B; a.T = p.T; a.d = p.d; a.n = p.n;
+    a.symw = (p.flags & SIGSVGD_FLAG_SYM) ? 1 : 0; a.inv_h = p.inv_h;
+    a.nitems = 0;
+    if (a.symw && p.A != p.B) {
+        set_error("sym backward needs A == B");
+        return SIGSVGD_E_BADARG;
+    }
+    const GradGeom g = dyad_geometry(p.A, p.B, p.T, p.d, sym);
+    if (grad) {
+        const size_t need = g.rseg_bytes + g.cslab_bytes + 256;
+        if (!p.ws || p.ws_bytes < need) {
+            set_error("dyad: workspace %zu B < required %zu B", p.ws_bytes, need);
+            return SIGSVGD_E_WORKSPACE;
+        }
+        unsigned char *base = reinterpret_cast<unsigned char *>((reinterpret_cast<uintptr_t>(p.ws) + 255) & ~(uintptr_t)255);
+        a.rseg = reinterpret_cast<double *>(base);
+        a.cslab = sym ? reinterpret_cast<float *>(base + g.rseg_bytes) : nullptr;
+    }
+    int rc = p.d <= 8 ? dyad_launch_variant<8>(p, a, g, grad, sym) : dyad_launch_variant<16>(p, a, g, grad, sym);
+    if (rc || !grad) return rc;
+    return grad_reduce_launch(g, a.rseg, a.cslab, p.gradX_out, p.dtype == SIGSVGD_F64, p.A, p.B, p.T * p.d, sym, p.stream);
+}
+
+} // namespace sigsvgd

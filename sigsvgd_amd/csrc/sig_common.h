@@ -227,4 +227,9 @@ int quad_workspace_bytes(int A, int B, int T, int d, int want_grad, size_t *byte
 int quad_launch(const GramProblem &p);
 int quad_sym_partial(const GramProblem &p, int tile_offset, int tile_stride, bool fold, double *grad_partial);
 
+// short paths with dyadic refinement, refined grid of 64 .. 128 cells per side, on the quadrant sweep engine -- gram_dyad.hip
+bool dyad_supported(int A, int B, int T, int d, int n, int kind, unsigned flags);
+int dyad_workspace_bytes(int A, int B, int T, int d, int want_grad, size_t *bytes);
+int dyad_launch(const GramProblem &p);
+
 } // namespace sigsvgd

@@ -24,7 +24,7 @@ def gpu():
 # Collection order of the GPU suite: the files that compare the Gram kernels with the oracle run FIRST, so that a failure in
 # a peripheral feature test (graphs, optimizers, vector kernels, costs) can never again hide the parity evidence under
 # `pytest -x` (round 2: one flaky graph test in test_gpu_api.py stopped the driver's run before 331 parity tests).
-_GPU_ORDER = ["test_gpu_fast", "test_gpu_longpaths", "test_gpu_generic", "test_gpu_fullsize", "test_gpu_determinism",
+_GPU_ORDER = ["test_gpu_fast", "test_gpu_longpaths", "test_gpu_generic", "test_gpu_dyadic", "test_gpu_fullsize", "test_gpu_determinism",
               "test_gpu_precision", "test_gpu_partition", "test_gpu_random_shapes", "test_gpu_robustness", "test_gpu_api",
               "test_gpu_vector"]
 

@@ -1,0 +1,108 @@
+"""GPU parity: the refined-grid kernel (gram_dyad.hip: short paths with dyadic refinement, refined grid of 64 .. 128 cells
+per side -- the reference's own call shapes: examples/script_planning_obstacle_field.py:156-158,325 order 5 on 5 points,
+script_planning_robot.py:391 order 6 on 3 points, BASELINE.json C1 order 2 on 20 points) vs the fp64 oracle, via the C ABI."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle as C
+from oracle import sigkernel_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5  # north_star tolerance (K per entry; gradients relative to max-abs)
+
+
+def _paths(A, T, d, seed, scale=0.3, offset=0.0):
+    rng = np.random.default_rng(seed)
+    return (np.cumsum(scale * rng.standard_normal((A, T, d)), axis=1) + offset).astype(np.float32)
+
+
+def _rel(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - b).max() / np.abs(b).max())
+
+
+def _relK(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    # entries below 0.1 -- pairs whose solution has cancelled 90 % of the boundary value 1 -- are held to the ABSOLUTE error
+    # 1e-6: the fp32 sweeps carry K at the resolution of values near 1 (profiles/r03_precision_sweep.md)
+    return float((np.abs(a - b) / np.maximum(np.abs(b), 0.1)).max())
+
+
+# T, dyadic order, d  (refined cells per side = (T - 1) * 2^n)
+SHAPES = [(20, 2, 2), (5, 5, 2), (3, 6, 7), (9, 3, 3), (17, 2, 14), (33, 2, 5), (10, 3, 16), (30, 2, 4), (5, 4, 8), (3, 5, 1)]
+
+
+def test_shapes_take_the_refined_grid_kernel():
+    """the dispatch is a host-side predicate: cells per side in [64, 128], at most 33 points"""
+    for T, n, d in SHAPES:
+        assert 64 <= (T - 1) << n <= 128 and T <= 33
+
+
+@pytest.mark.parametrize("T,n,d", SHAPES)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_dyadic_general_xy(gpu, T, n, d, dtype):
+    """X != Y, ragged batch sizes: ordered pairs, row-side gradient, arbitrary grad_out; equals the coverage kernel"""
+    from sigsvgd_amd import ops
+
+    A, B = 11, 9
+    X, Y = _paths(A, T, d, 1), _paths(B, T, d, 2)
+    h = 1.7
+    go = np.random.default_rng(3).standard_normal((A, B)).astype(np.float32)
+    Kref, gref = C.gram_fwd_bwd(X, Y, h, n, grad_out=go.astype(np.float64))
+    Xg, Yg, gog = (torch.as_tensor(t, device=gpu).to(dtype) for t in (X, Y, go))
+    K1 = ops.gram_fwd(Xg, Yg, 1.0 / h, n)
+    K2, g2 = ops.gram_fwd_bwd(Xg, Yg, 1.0 / h, n, grad_out=gog)
+    torch.cuda.synchronize()
+    assert K2.dtype == dtype and g2.dtype == dtype
+    assert _relK(K1.cpu().numpy(), Kref) < TOL and _relK(K2.cpu().numpy(), Kref) < TOL
+    assert _rel(g2.cpu().numpy(), gref) < TOL
+    K3, g3 = ops.gram_fwd_bwd(Xg, Yg, 1.0 / h, n, grad_out=gog, force_generic=True)
+    assert _relK(K2.cpu().numpy(), K3.double().cpu().numpy()) < TOL and _rel(g2.cpu().numpy(), g3.double().cpu().numpy()) < TOL
+
+
+@pytest.mark.parametrize("T,n,d", SHAPES)
+@pytest.mark.parametrize("weights", ["ones", "random", "sym"])
+def test_dyadic_symmetric(gpu, T, n, d, weights):
+    """Y is X: each unordered pair once, row- and column-side gradients; N = 19 leaves a last tile with three rows"""
+    from sigsvgd_amd import ops
+
+    N = 19
+    X = _paths(N, T, d, 5)
+    h = 0.9
+    go, sym = None, False
+    if weights != "ones":
+        go = np.random.default_rng(7).standard_normal((N, N)).astype(np.float32)
+    if weights == "sym":
+        sym = True
+    Kref, gref = O.gram_backward(X, X, None if go is None else go.astype(np.float64), O.RBF, h, n, False, sym)
+    Xg = torch.as_tensor(X, device=gpu)
+    gog = None if go is None else torch.as_tensor(go, device=gpu)
+    K, g = ops.gram_fwd_bwd(Xg, Xg, 1.0 / h, n, grad_out=gog, sym=sym, y_is_x=True)
+    torch.cuda.synchronize()
+    Kn = K.cpu().numpy()
+    assert _relK(Kn, Kref) < TOL and np.array_equal(Kn, Kn.T)
+    assert _rel(g.cpu().numpy(), gref) < TOL
+    K2, g2 = ops.gram_fwd_bwd(Xg, Xg, 1.0 / h, n, grad_out=gog, sym=sym, y_is_x=True)
+    assert torch.equal(K, K2) and torch.equal(g, g2)  # reproducible bits
+    Kf = ops.gram_fwd(Xg, Xg, 1.0 / h, n, y_is_x=True)
+    assert _relK(Kf.cpu().numpy(), Kref) < TOL
+
+
+def test_dyadic_reference_shapes_at_their_sizes(gpu):
+    """the reference's planning experiment (30 particles x 5 knots in R^2, order 5) and BASELINE C1 (16 x 20 x 2, order 2)
+    plus a launch with more items than workgroups (N = 300: 5,700 items)"""
+    from sigsvgd_amd import ops
+
+    for N, T, d, n, h in [(30, 5, 2, 5, 0.9), (16, 20, 2, 2, 1.0), (300, 5, 2, 5, 1.0)]:
+        X = _paths(N, T, d, 11, 0.3)
+        Xg = torch.as_tensor(X, device=gpu)
+        K, g = ops.gram_fwd_bwd(Xg, Xg, 1.0 / h, n, y_is_x=True)
+        rows = (0, min(N, 6))
+        Kref, gref = C.gram_fwd_bwd(X, X, h, n, rows=rows)
+        assert _relK(K.cpu().numpy()[rows[0]:rows[1]], Kref) < TOL
+        gfull = np.abs(g.cpu().numpy()).max()
+        assert np.abs(g.cpu().numpy()[rows[0]:rows[1]] - gref).max() / gfull < TOL
+        Ko, go_ = ops.gram_fwd_bwd(Xg, Xg.clone(), 1.0 / h, n)
+        assert _relK(Ko.cpu().numpy(), K.double().cpu().numpy()) < TOL  # (two orientations of a pair: both within TOL of the oracle)
+        assert _rel(go_.cpu().numpy(), g.double().cpu().numpy()) < TOL
