@@ -219,7 +219,7 @@ __constant__ const SweepMasks32 SWEEP_MASK32 = SweepMasks32();
     "v_fmac_f32 %[V], %[" G "], %[y]\n\t"                                                     \
     "v_add_f32 %[cur], %[" UP "], %[V]\n\t" KSL
 #define SIG_FWD_KSL(DIAG, K) "v_mov_b32 %[" K "], %[" DIAG "]\n\t"
-#define SIG_FWD_NOKSL "s_nop 0\n\t"
+#define SIG_FWD_NOKSL "v_max_f32 %[km], |%[cur]|, %[km]\n\t" // (forward-only launches: the largest |K| of the grid, in the hazard slot)
 #define SIG_REV_STEP(DN, DDIAG, G, K, M)                                                      \
     "s_mov_b64 exec, -1\n\t"                                                                  \
     "v_mov_b32_dpp %[" DN "], %[cur] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"               \
@@ -236,7 +236,7 @@ __constant__ const SweepMasks32 SWEEP_MASK32 = SweepMasks32();
 // windows of sigma0 ..
 template <bool STORE>
 __device__ __forceinline__ void sweep_fwd8(float &cur, float &upA, float &upB, float &V, const float *g, float *ksl,
-                                           const unsigned long long *mk, const float r3)
+                                           const unsigned long long *mk, const float r3, float &km)
 {
     float t, y;
     const unsigned long long m0 = mk[0], m1 = mk[1], m2 = mk[2], m3 = mk[3], m4 = mk[4], m5 = mk[5], m6 = mk[6], m7 = mk[7];
@@ -262,7 +262,7 @@ __device__ __forceinline__ void sweep_fwd8(float &cur, float &upA, float &upB, f
                      SIG_FWD_STEP("upA", "upB", "g4", SIG_FWD_NOKSL, "m4") SIG_FWD_STEP("upB", "upA", "g5", SIG_FWD_NOKSL, "m5")
                      SIG_FWD_STEP("upA", "upB", "g6", SIG_FWD_NOKSL, "m6") SIG_FWD_STEP("upB", "upA", "g7", SIG_FWD_NOKSL, "m7")
                      "s_mov_b64 exec, -1\n\t"
-                     : [cur] "+v"(cur), [upA] "+v"(upA), [upB] "+v"(upB), [V] "+v"(V), [t] "=&v"(t), [y] "=&v"(y)
+                     : [cur] "+v"(cur), [upA] "+v"(upA), [upB] "+v"(upB), [V] "+v"(V), [t] "=&v"(t), [y] "=&v"(y), [km] "+v"(km)
                      : [g0] "v"(g[0]), [g1] "v"(g[1]), [g2] "v"(g[2]), [g3] "v"(g[3]), [g4] "v"(g[4]), [g5] "v"(g[5]),
                        [g6] "v"(g[6]), [g7] "v"(g[7]), [r3] "s"(r3), [m0] "s"(m0), [m1] "s"(m1), [m2] "s"(m2),
                        [m3] "s"(m3), [m4] "s"(m4), [m5] "s"(m5), [m6] "s"(m6), [m7] "s"(m7));
@@ -285,6 +285,53 @@ __device__ __forceinline__ void sweep_rev8(float &cur, float &dnA, float &dnB, f
                  : [g0] "v"(g[0]), [g1] "v"(g[1]), [g2] "v"(g[2]), [g3] "v"(g[3]), [g4] "v"(g[4]), [g5] "v"(g[5]),
                    [g6] "v"(g[6]), [g7] "v"(g[7]), [r3] "s"(r3), [m0] "s"(m0), [m1] "s"(m1), [m2] "s"(m2), [m3] "s"(m3),
                    [m4] "s"(m4), [m5] "s"(m5), [m6] "s"(m6), [m7] "s"(m7));
+}
+
+// ---- fp64 forward sweep of a pair whose fp32 solution cancelled ----------------------------------------------------
+// The fp32 sweeps resolve K to ~1e-7 of the LARGEST value on the pair's grid.  Where the discrete solution oscillates
+// (rough paths in few channels against a narrow static kernel: K(x, y) passes through zero, turns negative), the value at
+// the far corner can be a small remainder of much larger intermediate values and its relative error grows by their ratio
+// (measured: up to 1.9e-5 per entry at T = 64, d = 2, against 1e-6 without cancellation).  A wavefront that sees
+// max |K_grid| > 4 * max(|K[P][P]|, 0.1) in one of its pairs therefore repeats the forward sweep in fp64 from the
+// increments it still holds (fp32 storage of fp64 differences: 2e-8) and stores that value over the first; the gradient
+// keeps the fp32 solution (its error is relative to the largest gradient entry: 1.4e-6 in those regimes).  Fully unrolled
+// (the slots are registers), plain selects instead of EXEC windows: it runs on a few pairs of a rough launch and on none of
+// a smooth one.  Same indexing as the fp32 step: lane l computes K[l+1][q+1] on step sigma = l + q from cur = K[l+1][q],
+// up = K[l][q+1] (lane l-1 before its own step) and the up of the step before = K[l][q].
+// What the block costs the pairs that do not take it (same-box A/B against the build without it): C4 4.90 -> 4.88 ms,
+// N=1024 T=32 1.36 -> 1.34 ms, forward-only launches +2 %, and +4 us on the 41 us launch of N=128, T=32 -- there the
+// 168-register kernel now reloads ~20 loop invariants per pair from scratch, whatever shape the block takes (a rolled
+// re-solve from the staged coordinates, a call, parking live values in memory around it: all measured, all worse).
+template <int RING>
+__device__ __forceinline__ double resweep_fwd_fp64(const float (&Dsl)[RING], int P, int lrow)
+{
+    double cur = 1.0, upprev = 1.0;
+    // (opaque copies: the compiler otherwise hoists the 126 lane-window predicates out of the kernel's pair loop -- they
+    //  depend on nothing a pair changes -- and keeps them in spilled SGPRs for the whole kernel)
+    asm volatile("" : "+v"(lrow), "+s"(P));
+    const bool rowv = lrow < P;
+#pragma unroll
+    for (int s0 = 0; s0 < 2 * RING - 3; s0 += 8) {
+        if (s0 <= 2 * P - 2) { // (uniform; steps past 2P-2 have no lane inside the grid)
+#pragma unroll
+            for (int s = s0; s < s0 + 8 && s < 2 * RING - 3; ++s) {
+                const double up = dpp_shr1_one(cur); // lane 0 (and, two rows per wavefront, the lane after the idle row 31): 1.0
+                float gf = Dsl[s & (RING - 1)];
+                asm volatile("" : "+v"(gf)); // (a slot serves steps s and s + RING: converted twice, not kept as a double in between)
+                const double g = (double)gf;
+                const double t = cur + up;
+                const double nw = (t - upprev) + g * __builtin_fma(g, t + upprev, 1.7320508075688772 * t);
+                cur = (rowv && (unsigned)(s - lrow) < (unsigned)P) ? nw : cur;
+                upprev = up;
+            }
+        }
+    }
+    return cur;
+}
+__device__ __forceinline__ float max3_abs(float m, float a, float b)
+{
+    asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(m) : "v"(a), "v"(b));
+    return m;
 }
 
 // [slot][lane] image of G (then R*G) with row stride 65 floats: every in-sweep access is
@@ -554,7 +601,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
                 // the diagonal neighbour K[l][q] of a step is the upper neighbour of the step before, whether or
                 // not this lane was active then (a lane's value is 1.0 until its row starts and frozen after it
                 // ends), so it needs no copy.
-                float cur = 1.f, upA = 1.f, upB = 1.f, V = 0.f;
+                float cur = 1.f, upA = 1.f, upB = 1.f, V = 0.f, km = 1.f;
                 const int smax = 2 * P - 2;
                 if (GRAD) {
 #pragma unroll
@@ -567,11 +614,29 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
                     const unsigned long long *mk = (RING == 64 ? SWEEP_MASK.m[P] : SWEEP_MASK32.m[P]) + rnd * 64; // EXEC windows
 #pragma unroll
                     for (int k0 = 0; k0 < 64; k0 += 8) // Ksl[k] <- K[l, q]
-                        sweep_fwd8<GRAD>(cur, upA, upB, V, &Dsl[k0 & RM], &Ksl[k0 & RM], mk + k0, r3);
+                        sweep_fwd8<GRAD>(cur, upA, upB, V, &Dsl[k0 & RM], &Ksl[k0 & RM], mk + k0, r3, km);
+                }
+                // largest |K| on this lane's row against the pair's result: cancellation -> fp64 (resweep_fwd_fp64 above)
+                if (GRAD) {
+                    km = fabsf(cur); // K[l+1][P]; the slots: K[l][q], q < P
+#pragma unroll
+                    for (int k = 0; k < RING; k += 2) km = max3_abs(km, Ksl[k], Ksl[k + 1]);
+                }
+                float kf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cur), P - 1));
+                if (RING == 32) {
+                    const float kf1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cur), 32 + P - 1));
+                    kf = (lane >> 5) ? kf1 : kf;
                 }
                 if (lrow == P - 1 && mine) { // this lane's last value is K[P, P]
                     store_any(a.K, (size_t)i * a.B + j, (double)cur, io64);
                     if (SYM && j != i) store_any(a.K, (size_t)j * a.B + i, (double)cur, io64);
+                }
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(mine && km > 4.f * fmaxf(fabsf(kf), 0.1f)) != 0, 0)) {
+                    const double k64 = resweep_fwd_fp64<RING>(Dsl, P, lrow);
+                    if (lrow == P - 1 && mine) { // (same lane, same addresses as the first store: the later one stands)
+                        store_any(a.K, (size_t)i * a.B + j, k64, io64);
+                        if (SYM && j != i) store_any(a.K, (size_t)j * a.B + i, k64, io64);
+                    }
                 }
             }
 

@@ -180,3 +180,26 @@ def test_forward_only_symmetric_solve(gpu, N, T, d):
     K0 = ops.gram_fwd(X, X.clone(), 1.0)
     assert torch.equal(K1, K1.T)
     assert _relK(K1.cpu().numpy(), K0.double().cpu().numpy()) < SELF
+
+
+@pytest.mark.parametrize("T,d,scale,h", [(64, 2, 0.1, 0.1), (64, 2, 0.2, 0.1), (64, 2, 0.5, 1.0), (64, 2, 0.05, 0.02),
+                                         (32, 2, 0.2, 0.1), (48, 3, 0.3, 0.3)])
+def test_fast_oscillating_solutions_per_entry(gpu, T, d, scale, h):
+    """Rough paths in few channels against a narrow static kernel: the discrete solution oscillates (negative entries) and
+    K[P][P] can be a small remainder of much larger values on the pair's grid; the fp32 sweeps alone lose up to 1.9e-5 per
+    entry there.  Pairs with max |K_grid| > 4 max(|K|, 0.1) repeat the forward sweep in fp64 (gram_fast.hip,
+    resweep_fwd_fp64): every entry is inside the tolerance, in every launch form."""
+    from sigsvgd_amd import ops
+
+    X = _paths(12, T, d, 0, scale=scale)
+    Kref, gref = C.gram_fwd_bwd(X, X, h, 0)
+    assert Kref.min() < 0.5  # (the regime the test is about: solutions that cancel)
+    Xg = torch.as_tensor(X, device=gpu)
+    outs = [ops.gram_fwd_bwd(Xg, Xg, 1.0 / h, y_is_x=True), ops.gram_fwd_bwd(Xg, Xg.clone(), 1.0 / h)]
+    fwd = [ops.gram_fwd(Xg, Xg, 1.0 / h, y_is_x=True), ops.gram_fwd(Xg, Xg.clone(), 1.0 / h)]
+    torch.cuda.synchronize()
+    for K, g in outs:
+        assert _relK(K.cpu().numpy(), Kref) < 5e-6
+        assert _rel(g.cpu().numpy(), gref) < TOL
+    for K in fwd:
+        assert _relK(K.cpu().numpy(), Kref) < 5e-6
