@@ -47,6 +47,11 @@ struct GenericArgs {
                                    // with yx their cost varies from nothing to JC pairs
     int A, B, T, d, dp, n, r, P, Tm, TmS, nbands, nsteps, JC, nchunks, kind, naive, sym, want_grad;
     int big; // long paths (dyadic order 0 only): S kept in fp32 (one write per entry), no LDS gradient accumulator
+    // fp64 pass over the pairs a fp32-sweep kernel flagged (generic_repair_launch; forward only): the pairs with
+    // flags[i * B + j] != 0 among the rows of the tiles `tm` owns (tile_rows rows each), j >= i with yx
+    const unsigned char *flags;
+    TileMap tm;
+    int tile_rows;
     double inv_h, inv_r2;
     long long total_items;
     size_t wsk_per_block;
@@ -114,6 +119,12 @@ __global__ __launch_bounds__(64) void gram_generic_kernel(GenericArgs a)
         const int j1 = min(a.B, j0 + a.JC);
         const IO *xi = X + (size_t)i * T * d;
         const bool empty = a.yx && j1 <= i; // chunk entirely left of the diagonal: solved from the other side
+        if (a.flags) { // nothing flagged in this chunk (the usual case): next item, before anything is staged
+            bool any = false;
+            if (a.tm.kq_of_tile(i / a.tile_rows) >= 0)
+                for (int j = max(j0, a.yx ? i : 0) + lane; j < j1; j += kWave) any |= a.flags[(size_t)i * a.B + j] != 0;
+            if (__builtin_amdgcn_ballot_w64(any) == 0) continue; // (one wavefront per workgroup: uniform)
+        }
 
         double *slab = GRAD ? a.partials + ((size_t)i * a.nchunks + chunk) * T * d : nullptr;
         if (GRAD && big)
@@ -134,7 +145,20 @@ __global__ __launch_bounds__(64) void gram_generic_kernel(GenericArgs a)
             xn[t] = s;
         }
 
+        unsigned long long fmask = 0; // fp64 pass: flagged columns among fbase .. fbase + 63 not visited yet
+        int fbase = j0 - kWave;
         for (int j = empty ? j1 : j0; j < j1; ++j) {
+            if (a.flags) { // the next flagged column (64 flags per load, the set bits taken in order)
+                while (fmask == 0 && fbase + kWave < j1) {
+                    fbase += kWave;
+                    const int jc = fbase + lane;
+                    const bool f = jc < j1 && !(a.yx && jc < i) && a.flags[(size_t)i * a.B + jc] != 0;
+                    fmask = __builtin_amdgcn_ballot_w64(f);
+                }
+                if (fmask == 0) break;
+                j = fbase + __builtin_ctzll(fmask);
+                fmask &= fmask - 1;
+            }
             if (a.yx && j < i) continue; // (one wavefront per workgroup: uniform)
             const IO *yj = Y + (size_t)j * T * d;
             __syncthreads();
@@ -563,6 +587,7 @@ int generic_launch(const GramProblem &p)
     a.sym = sym ? 1 : 0; a.want_grad = want_grad; a.inv_h = p.inv_h;
     a.inv_r2 = 1.0 / ((double)pl.r * (double)pl.r);
     a.total_items = pl.items; a.wsk_per_block = pl.wsk_per_block; a.big = pl.big;
+    a.flags = nullptr; a.tm = make_tilemap(1, 0, 1, false); a.tile_rows = 1;
 
 #ifdef SIGSVGD_PHASE_STAMPS
     {
@@ -606,6 +631,42 @@ int generic_launch(const GramProblem &p)
         e = hipGetLastError();
         if (e != hipSuccess) return hip_fail(e, "launch reduce_partials_kernel");
     }
+    return SIGSVGD_OK;
+}
+
+// ---- fp64 pass over flagged pairs ------------------------------------------------------------------------------------
+// The fp32-sweep kernels (gram_quad.hip) mark the pairs whose solution cancelled; this launch of the forward-only
+// coverage kernel takes one row of K per work item, skips every row without a flag before staging anything (a few
+// microseconds when nothing is flagged) and stores K of the flagged pairs again, from fp64 sweeps.  Items are assigned
+// statically; no counter, no memset.
+size_t generic_repair_bytes() { return 1024; }
+
+int generic_repair_launch(const GramProblem &p, const unsigned char *flags, void *ws, bool sym, const TileMap &tm, int tile_rows)
+{
+    (void)ws;
+    GenericPlan pl;
+    int rc = make_plan(p.A, p.B, p.T, p.d, p.n, 0, pl, false);
+    if (rc) return rc;
+    GenericArgs a;
+    a.X = p.X; a.Y = p.Y; a.grad_out = nullptr; a.K_out = p.K_out;
+    a.next_item = nullptr; a.partials = nullptr; a.colslab = nullptr; a.wsk = nullptr;
+    a.yx = sym ? 1 : 0;
+    a.A = p.A; a.B = p.B; a.T = p.T; a.d = p.d; a.dp = pl.dp; a.n = p.n; a.r = pl.r; a.P = pl.P;
+    a.Tm = pl.Tm; a.TmS = pl.TmS; a.nbands = pl.nbands; a.nsteps = pl.nsteps; a.JC = pl.JC;
+    a.nchunks = pl.nchunks; a.kind = p.kind; a.naive = 0; a.sym = 0; a.want_grad = 0; a.inv_h = p.inv_h;
+    a.inv_r2 = 1.0 / ((double)pl.r * (double)pl.r);
+    // one item per row: its B flags are scanned 64 per load, and a row without a flag costs one pass over them
+    a.JC = p.B; a.nchunks = 1;
+    a.total_items = p.A; a.wsk_per_block = 0; a.big = 0;
+    if ((long long)pl.grid > a.total_items) pl.grid = (int)a.total_items;
+    a.flags = flags; a.tm = tm; a.tile_rows = tile_rows;
+#ifdef SIGSVGD_PHASE_STAMPS
+    a.stamps = nullptr;
+#endif
+    hipError_t e = generic_dispatch(p.dtype == SIGSVGD_F64, false, false, false, pl, p.stream, a);
+    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(generic, fp64 pass)");
+    e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "launch gram_generic_kernel (fp64 pass)");
     return SIGSVGD_OK;
 }
 

@@ -55,6 +55,8 @@ struct QuadArgs {
     float *dcache;                // [gridDim.x][8 waves][3 quadrants][64 slots][64 lanes] fp32: increments kept between
                                   // the forward-only and the full pass over a quadrant (gradient launches; may be NULL)
     double inv_h;
+    unsigned char *kflag; // [A][B]: 1 where the fp32 solution of the pair cancelled (max |K_grid| > 4 max(|K|, 0.1)): the
+                          // launcher lets the coverage kernel solve those pairs' K again in fp64 (generic_repair_launch)
 #ifdef SIGSVGD_PHASE_STAMPS
     unsigned long long *stamps; // diagnostic build only (scripts/dev/phase_stamps.py): shader-clock totals per phase
 #endif
@@ -76,6 +78,14 @@ namespace {
 #define SIGQ_NW 8
 #endif
 constexpr int QNW = SIGQ_NW; // wavefronts (rows i) per workgroup
+#ifndef SIGQ_CANCEL_RATIO
+#define SIGQ_CANCEL_RATIO 8.f
+#endif
+// A pair is solved again in fp64 when max |K_grid| > QUAD_CANCEL_RATIO * max(|K[P][P]|, 0.1): the fp32 sweeps lose
+// about 5e-7 (T = 64) .. 1e-6 (T = 128) of the LARGEST value on the grid, so 8 keeps every entry within 8e-6 while the
+// pairs that merely decay from the boundary value 1 to K >= 0.125 -- common with few channels, and cheap to get right in
+// fp32 -- stay out of the coverage kernel's fp64 pass (at 4, N=256 T=96 d=3 sent enough of them there to cost 25 %).
+constexpr float QUAD_CANCEL_RATIO = SIGQ_CANCEL_RATIO;
 // floats of a wavefront's column-side records of one pair: 4 quadrant passes + 2 halves of point row 64, each
 // [DPAD + 1 values][64 lanes], + 4 seam-column records of DPAD + 1 values (sized for DPAD = 16)
 constexpr int QREC = 6656;
@@ -107,6 +117,11 @@ __device__ __forceinline__ void q_ldrow(const void *b, size_t i0, int nvalid, in
 #pragma unroll
         for (int c = 0; c < N; ++c) out[c] = (c < nvalid) ? (double)tmp[c] : 0.0;
     }
+}
+__device__ __forceinline__ float q_max3_abs(float m, float a, float b)
+{
+    asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(m) : "v"(a), "v"(b));
+    return m;
 }
 __device__ __forceinline__ void q_stany(void *b, size_t i, double v, int io64)
 {
@@ -420,6 +435,7 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
             for (int c = 0; c < DPAD / 2; ++c) acc[c] = qf32x2{0.f, 0.f};
             int rev_band = -1;
             bool kdone = false;
+            float kmax = 1.f; // largest |K| this lane has seen on the pair's grid (boundary: 1)
 
             // visit list, 8 bits per visit: band | half << 1 | reverse << 2 | leave K[64][.] << 3 | increments << 4 (0 compute,
             // 1 compute and keep in the launch's scratch, 2 take from there) | scratch slot << 6
@@ -588,6 +604,11 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                     asm volatile("" ::: "memory");
                     quad_fwd_all<0, EARLY>(fc, fuA, fuB, fV, Dsl, Ssl, wr, rows, hbf, haddr, hinc, r3, nrows + ncols);
                     asm volatile("" ::: "memory");
+                    if (!kdone) { // (the slots: K at the cells' upper left corners; fc: the row's last value so far)
+                        kmax = q_max3_abs(kmax, fc, fc);
+#pragma unroll
+                        for (int k = 0; k < 64; k += 2) kmax = q_max3_abs(kmax, Ssl[k], Ssl[k + 1]);
+                    }
                     if (KSTORE && dmode == 1) { // reverse sweep and gradient pass follow on a later visit
                         float *kp = dcw + (3 + dslot) * 4096 + lv;
 #pragma unroll
@@ -603,9 +624,13 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                 SIG_QSTAMP(2)
                 if (!kdone && b == b_last && h == h_last) { // K[P][P]: last value of the last row with cells
                     kdone = true;
+                    // a pair whose solution cancelled (see gram_fast.hip, resweep_fwd_fp64) is marked for the fp64 pass
+                    const float kfin = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fc), nrows - 1));
+                    const bool cancelled = __builtin_amdgcn_ballot_w64(kmax > QUAD_CANCEL_RATIO * fmaxf(fabsf(kfin), 0.1f)) != 0;
                     if (lanep == nrows - 1) {
                         q_stany(a.K, (size_t)i * a.B + j, (double)fc, io64);
                         if (SYM && j != i) q_stany(a.K, (size_t)j * a.B + i, (double)fc, io64);
+                        if (a.kflag) a.kflag[(size_t)i * a.B + j] = cancelled ? 1 : 0;
                     }
                 }
                 if (!GRAD || !rev) continue;
@@ -934,9 +959,13 @@ inline QuadCut quad_cut(const GradGeom &g, int d, bool sym)
 }
 } // namespace
 
+// every launch: [A][B] bytes of cancellation flags + the (small) workspace of the fp64 pass over the flagged pairs, in
+// front of the gradient launch's own areas
+inline size_t quad_flag_bytes(int A, int B) { return (((size_t)A * B + 255) & ~(size_t)255) + generic_repair_bytes(); }
+
 int quad_workspace_bytes(int A, int B, int T, int d, int want_grad, size_t *bytes)
 {
-    *bytes = 0;
+    *bytes = quad_flag_bytes(A, B) + 512;
     if (!want_grad) return SIGSVGD_OK;
     // the larger of the ordered and the symmetric launch (the query carries no Y_IS_X promise); the increment scratch of a
     // full grid is 100 MB on 256 CUs and lives in L2 / MALL
@@ -945,7 +974,7 @@ int quad_workspace_bytes(int A, int B, int T, int d, int want_grad, size_t *byte
         const size_t y = quad_cut(quad_geometry(A, B, T, d, true), d, true).total;
         if (y > need) need = y;
     }
-    *bytes = need + 512;
+    *bytes = need + quad_flag_bytes(A, B) + 512;
     return SIGSVGD_OK;
 }
 
@@ -1016,7 +1045,21 @@ void quad_fill_args(const GramProblem &p, QuadArgs &a)
     a.io64 = p.dtype == SIGSVGD_F64; a.A = p.A; a.B = p.B; a.T = p.T; a.d = p.d;
     a.symw = (p.flags & SIGSVGD_FLAG_SYM) ? 1 : 0; a.inv_h = p.inv_h;
     a.tm = make_tilemap(1, 0, 1, false); // (a full launch; quad_launch_variant derives the tile count)
-    a.nitems = 0; a.dcache = nullptr;
+    a.nitems = 0; a.dcache = nullptr; a.kflag = nullptr;
+}
+
+// the flag area at the head of the workspace (every launch has one), and the fp64 pass that follows the kernel
+unsigned char *quad_ws_base(const GramProblem &p, size_t need)
+{
+    if (!p.ws || p.ws_bytes < need + quad_flag_bytes(p.A, p.B) + 256) {
+        set_error("quad: workspace %zu B < required %zu B", p.ws_bytes, need + quad_flag_bytes(p.A, p.B) + 256);
+        return nullptr;
+    }
+    return reinterpret_cast<unsigned char *>((reinterpret_cast<uintptr_t>(p.ws) + 255) & ~(uintptr_t)255);
+}
+int quad_repair(const GramProblem &p, const QuadArgs &a, bool sym)
+{
+    return generic_repair_launch(p, a.kflag, a.kflag + (((size_t)p.A * p.B + 255) & ~(size_t)255), sym, a.tm, QNW);
 }
 
 // cut the workspace, enqueue kernel + fixed-order reduction into `out` (the I/O type, or fp64 for the partial solve)
@@ -1024,17 +1067,19 @@ int quad_run_grad(const GramProblem &p, QuadArgs &a, bool sym, void *out, int ou
 {
     const GradGeom g = quad_geometry(p.A, p.B, p.T, p.d, sym, a.tm);
     const QuadCut c = quad_cut(g, p.d, sym);
-    if (!p.ws || p.ws_bytes < c.total + 256) {
-        set_error("quad: workspace %zu B < required %zu B", p.ws_bytes, c.total + 256);
-        return SIGSVGD_E_WORKSPACE;
-    }
-    unsigned char *base = reinterpret_cast<unsigned char *>((reinterpret_cast<uintptr_t>(p.ws) + 255) & ~(uintptr_t)255);
+    unsigned char *base = quad_ws_base(p, c.total);
+    if (!base) return SIGSVGD_E_WORKSPACE;
+    a.kflag = base;
+    base += quad_flag_bytes(p.A, p.B);
     a.rseg = reinterpret_cast<double *>(base + c.rseg);
     a.cslab = sym ? reinterpret_cast<float *>(base + c.cslab) : nullptr;
     a.crec = sym ? reinterpret_cast<float *>(base + c.crec) : nullptr;
     a.rowg = p.d > 14 ? reinterpret_cast<float *>(base + c.rowg) : nullptr;
     a.dcache = reinterpret_cast<float *>(base + c.dcache);
     int rc = quad_dispatch(p, a, true, sym);
+    if (rc) return rc;
+    a.tm = g.tm;
+    rc = quad_repair(p, a, sym);
     if (rc) return rc;
     return grad_reduce_launch(g, a.rseg, a.cslab, out, out64, p.A, p.B, p.T * p.d, sym, p.stream);
 }
@@ -1050,7 +1095,15 @@ int quad_launch(const GramProblem &p)
         set_error("sym backward needs A == B");
         return SIGSVGD_E_BADARG;
     }
-    if (!grad) return quad_dispatch(p, a, false, sym);
+    if (!grad) {
+        unsigned char *base = quad_ws_base(p, 0);
+        if (!base) return SIGSVGD_E_WORKSPACE;
+        a.kflag = base;
+        int rc = quad_dispatch(p, a, false, sym);
+        if (rc) return rc;
+        a.tm = quad_geometry(p.A, p.B, p.T, p.d, sym, a.tm).tm;
+        return quad_repair(p, a, sym);
+    }
     return quad_run_grad(p, a, sym, p.gradX_out, p.dtype == SIGSVGD_F64);
 }
 

@@ -214,6 +214,11 @@ GradGeom grad_geometry(int A, int B, int TD, bool sym, int off, int stride, bool
 int grad_reduce_launch(const GradGeom &g, const double *rseg, const float *cslab, void *out, int out64, int A, int B, int TD,
                        bool sym, hipStream_t stream);
 
+// fp64 pass of the coverage kernel over the pairs a fp32-sweep kernel flagged (flags [A][B] bytes; `sym`: the pairs j >= i,
+// K mirrored; rows of the tiles `tm` owns, `tile_rows` rows each; ws: generic_repair_bytes() of scratch) -- gram_generic.hip
+size_t generic_repair_bytes();
+int generic_repair_launch(const GramProblem &p, const unsigned char *flags, void *ws, bool sym, const TileMap &tm, int tile_rows);
+
 // register-resident fast path (n == 0, T <= 64, RBF/linear) -- gram_fast.hip
 bool fast_supported(int A, int B, int T, int d, int n, int kind, unsigned flags);
 int fast_workspace_bytes(int A, int B, int T, int d, int want_grad, unsigned flags, size_t *bytes);

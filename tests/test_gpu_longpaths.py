@@ -173,3 +173,29 @@ def test_stored_forward_quadrant_kernel(gpu, A, B, T, d, sym, scale):
                 Ks += Kp
                 gs += gp
             assert torch.equal(Ks, K) and _rel(gs.cpu().numpy(), gref) < TOL
+
+
+@pytest.mark.parametrize("T,d,scale,h", [(100, 2, 0.2, 0.1), (100, 2, 0.5, 1.0), (128, 2, 0.2, 1.0), (80, 2, 0.2, 0.1)])
+def test_long_oscillating_solutions_per_entry(gpu, T, d, scale, h):
+    """Rough paths in few channels: the discrete solution oscillates and K[P][P] can be a small remainder of much larger
+    values on the pair's grid (fp32 sweeps alone: up to 2.7e-5 per entry at T = 100, d = 2).  The quadrant kernel flags the
+    pairs with max |K_grid| > 4 max(|K|, 0.1) and the coverage kernel solves their K again in fp64 (gram_generic.hip,
+    generic_repair_launch): every entry inside the tolerance in every launch form, the sharded partial solve included."""
+    from sigsvgd_amd import ops
+
+    N = 10
+    rng = np.random.default_rng(0)
+    X = np.cumsum(scale * rng.standard_normal((N, T, d)), axis=1).astype(np.float32)
+    Kref, gref = C.gram_fwd_bwd(X, X, h, 0)
+    assert Kref.min() < 0.5  # (the regime the test is about: solutions that cancel)
+    Xg = torch.as_tensor(X, device=gpu)
+    for K, g in [ops.gram_fwd_bwd(Xg, Xg, 1.0 / h, y_is_x=True), ops.gram_fwd_bwd(Xg, Xg.clone(), 1.0 / h)]:
+        assert _relK(K.cpu().numpy(), Kref) < 8e-6
+        assert _rel(g.cpu().numpy(), gref) < TOL
+    for K in [ops.gram_fwd(Xg, Xg, 1.0 / h, y_is_x=True), ops.gram_fwd(Xg, Xg.clone(), 1.0 / h)]:
+        assert _relK(K.cpu().numpy(), Kref) < 8e-6
+    Ks = torch.zeros(N, N, device=gpu)
+    for r in range(2):
+        Kp, _ = ops.gram_sym_partial(Xg, 1.0 / h, r, 2, fold=True)
+        Ks += Kp
+    assert _relK(Ks.cpu().numpy(), Kref) < 8e-6
