@@ -40,7 +40,11 @@
  *     (dyadic order 0, T <= 128): fp64 static kernel + 4-corner increments, fp32 PDE sweeps in
  *     difference form, fp32 storage of per-pair intermediates, fp32 gradient contraction, fp64
  *     reduction over pairs; the coverage kernel (dyadic refinement, longer paths, linear kernel,
- *     naive solver) runs its sweeps in fp64 (DESIGN.md "precision plan");
+ *     naive solver) runs its sweeps in fp64 (DESIGN.md "precision plan").  A pair whose fp32 solution
+ *     cancelled -- the largest |K| on its PDE grid exceeds 4x (T <= 64) / 8x (T <= 128) max(|K|, 0.1):
+ *     oscillating discrete solutions of rough paths in few channels -- has its K solved again in fp64
+ *     inside the same call, so every entry of K_out is within 1e-5 of the fp64 reference's, relative to
+ *     max(|K|, 0.1);
  *   - results are bit-reproducible: every reduction over pairs runs in an order fixed by the launch
  *     geometry (no floating-point atomics), so two calls on the same inputs return the same bits.
  */
