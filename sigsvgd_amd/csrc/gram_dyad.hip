@@ -36,7 +36,8 @@ struct DyadArgs {
 };
 
 namespace {
-constexpr int DNW = 8;   // wavefronts (rows i) per workgroup
+// wavefronts (rows i) per workgroup: 8 (two per SIMD) when there are pairs to fill the chip, 4 (one per SIMD: a wavefront's
+// dependent chain then has the SIMD to itself) when the launch is a handful of workgroups (C1: 136 pairs)
 constexpr int DTMAX = 33; // coarse points per path
 constexpr int DHN = 136;  // hand-over rows: entries 0 .. 129 are read
 
@@ -55,8 +56,8 @@ __device__ __forceinline__ void d_stany(void *b, size_t i, double v, int io64)
 }
 } // namespace
 
-template <int DPAD, bool GRAD, bool SYM>
-__global__ __launch_bounds__(DNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void gram_dyad_kernel(DyadArgs a)
+template <int DPAD, bool GRAD, bool SYM, int DNW>
+__global__ __launch_bounds__(DNW * 64) __attribute__((amdgpu_waves_per_eu(DNW == 8 ? 2 : 1, 2))) void gram_dyad_kernel(DyadArgs a)
 {
     constexpr int NT = DNW * 64;
     constexpr int TM = DTMAX - 1; // coarse cells per side at most
@@ -423,9 +424,17 @@ bool dyad_supported(int A, int B, int T, int d, int n, int kind, unsigned flags)
 }
 
 namespace {
-inline GradGeom dyad_geometry(int A, int B, int T, int d, bool sym)
+// small launches: every 4-row workgroup gets a CU of its own (measured, Gram + gradient, symmetric: N=16 T=20 order 2
+// 0.086 -> 0.071 ms, N=30 T=5 order 5 0.091 -> 0.076; with two such workgroups per CU the 8-row form is faster again:
+// N=64 T=20 0.165 against 0.257 ms -- half the rows per staged column trajectory)
+inline int dyad_nw(int A, int B, bool sym)
 {
-    return grad_geometry(A, B, T * d, sym, 0, 1, false, DNW, (long long)device_cu_count());
+    const long long pairs = sym ? (long long)A * (A + 1) / 2 : (long long)A * B;
+    return pairs <= 4ll * device_cu_count() ? 4 : 8;
+}
+inline GradGeom dyad_geometry(int A, int B, int T, int d, bool sym, int nw)
+{
+    return grad_geometry(A, B, T * d, sym, 0, 1, false, nw, (long long)device_cu_count());
 }
 } // namespace
 
@@ -433,10 +442,10 @@ int dyad_workspace_bytes(int A, int B, int T, int d, int want_grad, size_t *byte
 {
     *bytes = 256;
     if (!want_grad) return SIGSVGD_OK;
-    const GradGeom o = dyad_geometry(A, B, T, d, false);
+    const GradGeom o = dyad_geometry(A, B, T, d, false, dyad_nw(A, B, false));
     size_t need = o.rseg_bytes;
     if (A == B) {
-        const GradGeom y = dyad_geometry(A, B, T, d, true);
+        const GradGeom y = dyad_geometry(A, B, T, d, true, dyad_nw(A, B, true));
         if (y.rseg_bytes + y.cslab_bytes > need) need = y.rseg_bytes + y.cslab_bytes;
     }
     *bytes = need + 512;
@@ -444,7 +453,7 @@ int dyad_workspace_bytes(int A, int B, int T, int d, int want_grad, size_t *byte
 }
 
 namespace {
-template <int DPAD>
+template <int DPAD, int DNW>
 int dyad_launch_variant(const GramProblem &p, DyadArgs &a, const GradGeom &g, bool grad, bool sym)
 {
     if (g.tm.owned <= 0 || g.nitems <= 0) return SIGSVGD_OK;
@@ -452,13 +461,13 @@ int dyad_launch_variant(const GramProblem &p, DyadArgs &a, const GradGeom &g, bo
     a.nitems = g.nitems;
     dim3 grid((unsigned)g.grid), block(DNW * 64);
     if (grad && sym)
-        hipLaunchKernelGGL((gram_dyad_kernel<DPAD, true, true>), grid, block, 0, p.stream, a);
+        hipLaunchKernelGGL((gram_dyad_kernel<DPAD, true, true, DNW>), grid, block, 0, p.stream, a);
     else if (grad)
-        hipLaunchKernelGGL((gram_dyad_kernel<DPAD, true, false>), grid, block, 0, p.stream, a);
+        hipLaunchKernelGGL((gram_dyad_kernel<DPAD, true, false, DNW>), grid, block, 0, p.stream, a);
     else if (sym)
-        hipLaunchKernelGGL((gram_dyad_kernel<DPAD, false, true>), grid, block, 0, p.stream, a);
+        hipLaunchKernelGGL((gram_dyad_kernel<DPAD, false, true, DNW>), grid, block, 0, p.stream, a);
     else
-        hipLaunchKernelGGL((gram_dyad_kernel<DPAD, false, false>), grid, block, 0, p.stream, a);
+        hipLaunchKernelGGL((gram_dyad_kernel<DPAD, false, false, DNW>), grid, block, 0, p.stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "launch gram_dyad_kernel");
     return SIGSVGD_OK;
@@ -478,7 +487,8 @@ int dyad_launch(const GramProblem &p)
         set_error("sym backward needs A == B");
         return SIGSVGD_E_BADARG;
     }
-    const GradGeom g = dyad_geometry(p.A, p.B, p.T, p.d, sym);
+    const int nw = dyad_nw(p.A, p.B, sym);
+    const GradGeom g = dyad_geometry(p.A, p.B, p.T, p.d, sym, nw);
     if (grad) {
         const size_t need = g.rseg_bytes + g.cslab_bytes + 256;
         if (!p.ws || p.ws_bytes < need) {
@@ -489,7 +499,11 @@ int dyad_launch(const GramProblem &p)
         a.rseg = reinterpret_cast<double *>(base);
         a.cslab = sym ? reinterpret_cast<float *>(base + g.rseg_bytes) : nullptr;
     }
-    int rc = p.d <= 8 ? dyad_launch_variant<8>(p, a, g, grad, sym) : dyad_launch_variant<16>(p, a, g, grad, sym);
+    int rc;
+    if (nw == 4)
+        rc = p.d <= 8 ? dyad_launch_variant<8, 4>(p, a, g, grad, sym) : dyad_launch_variant<16, 4>(p, a, g, grad, sym);
+    else
+        rc = p.d <= 8 ? dyad_launch_variant<8, 8>(p, a, g, grad, sym) : dyad_launch_variant<16, 8>(p, a, g, grad, sym);
     if (rc || !grad) return rc;
     return grad_reduce_launch(g, a.rseg, a.cslab, p.gradX_out, p.dtype == SIGSVGD_F64, p.A, p.B, p.T * p.d, sym, p.stream);
 }
