@@ -60,7 +60,7 @@ struct GenericArgs {
 #endif
 };
 
-__host__ __device__ inline size_t generic_lds_bytes(int T, int d, int n, int want_grad, int big)
+__host__ __device__ inline size_t generic_lds_bytes(int T, int d, int n, int want_grad, int big, int dd = 0)
 {
     const int dp = (d % 2 == 0) ? d + 1 : d;
     const int Tm = T - 1, TmS = Tm | 1, P = (1 << n) * Tm;
@@ -68,12 +68,18 @@ __host__ __device__ inline size_t generic_lds_bytes(int T, int d, int n, int wan
     size_t flt = (size_t)Tm * TmS;
     if (want_grad && !big) dbl += (size_t)Tm * Tm + (size_t)T * dp; // S fp64 + gradient accumulator
     if (want_grad && big) flt += (size_t)Tm * Tm;                   // S fp32 only
+    if (dd) dbl += (size_t)Tm * TmS, flt -= (size_t)Tm * TmS; // increments kept in fp64 (see DT below)
     return dbl * sizeof(double) + flt * sizeof(float);
 }
 
 // NAIVE / GRAD / BIG are compile-time: tested per sweep step, each of them was a taken branch on the one wave's
 // dependent chain.
-template <typename IO, bool NAIVE, bool GRAD, bool BIG>
+// DT: storage type of the increment table.  float (rounds 1-2): 6e-8 per increment, invisible while K grows along the
+// grid -- but where the discrete solution oscillates (rough paths in one or two channels) K[P][P] is
+// a small remainder of much larger values and inherits ~3e-7 .. 3e-6 (T = 64 .. 128) of their ratio to it from the rounded
+// increments, whatever the precision of the sweeps.  double wherever the table fits next to the rest (always for the
+// reference's own shapes; the fp64 pass over flagged pairs and force_generic whenever 160 KB allow).
+template <typename IO, bool NAIVE, bool GRAD, bool BIG, typename DT>
 __global__ __launch_bounds__(64) void gram_generic_kernel(GenericArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -91,8 +97,8 @@ __global__ __launch_bounds__(64) void gram_generic_kernel(GenericArgs a)
     double *dump = rowbuf + (P + 2); // [64]: where the lanes that have nothing to hand over store
     double *Sm = dump + kWave;
     double *acc = Sm + ((GRAD && !big) ? (size_t)Tm * Tm : 0);
-    float *Dm = reinterpret_cast<float *>(acc + ((GRAD && !big) ? (size_t)T * dp : 0));
-    float *Sm32 = Dm + (size_t)Tm * TmS; // big mode: S in fp32 (dyadic order 0: each entry written once)
+    DT *Dm = reinterpret_cast<DT *>(acc + ((GRAD && !big) ? (size_t)T * dp : 0));
+    float *Sm32 = reinterpret_cast<float *>(Dm + (size_t)Tm * TmS); // big mode: S in fp32 (dyadic order 0: each entry written once)
 
     const IO *X = static_cast<const IO *>(a.X);
     const IO *Y = static_cast<const IO *>(a.Y);
@@ -194,7 +200,7 @@ __global__ __launch_bounds__(64) void gram_generic_kernel(GenericArgs a)
                     const double rd = gq - g_prev;
                     g_prev = gq;
                     const double rdn = shfl_down_f64(rd);
-                    if (q >= 1 && lane < kWave - 1 && p + 1 < T) Dm[p * TmS + (q - 1)] = (float)(rdn - rd);
+                    if (q >= 1 && lane < kWave - 1 && p + 1 < T) Dm[p * TmS + (q - 1)] = (DT)(rdn - rd);
                 }
             }
             __syncthreads();
@@ -210,16 +216,16 @@ __global__ __launch_bounds__(64) void gram_generic_kernel(GenericArgs a)
                 const int p = kb * kWave + lane;
                 const bool rowvalid = p < P;
                 const bool first = kb == 0;
-                const float *Drow = Dm + (size_t)(min(p, P - 1) >> n) * TmS;
+                const DT *Drow = Dm + (size_t)(min(p, P - 1) >> n) * TmS;
                 float *wp = wsk + (size_t)kb * a.nsteps * kWave + lane;
                 double cur = 1.0, upprev = 1.0;
                 int q = -lane;
-                float gf = Drow[0];                     // step 0 (only lane 0 is inside the grid)
+                DT gf = Drow[0];                        // step 0 (only lane 0 is inside the grid)
                 double rb = rowbuf[1];                  // lane 0's upper neighbour on step s: rowbuf[s + 1]
                 rb = first ? 1.0 : rb;
                 for (int s = 0; s < a.nsteps; ++s, ++q) {
                     const bool active = rowvalid && q >= 0 && q < P;
-                    const float gfn = Drow[min(max(q + 1, 0), P - 1) >> n];
+                    const DT gfn = Drow[min(max(q + 1, 0), P - 1) >> n];
                     const double rbr = rowbuf[min(s + 2, P)];
                     const double rbn = first ? 1.0 : rbr;
                     double up_in = shfl_up_f64(cur);
@@ -256,7 +262,7 @@ __global__ __launch_bounds__(64) void gram_generic_kernel(GenericArgs a)
                 const bool rowvalid = p < P;
                 const int L = min(kWave, P - kb * kWave);
                 const int arow = min(p, P - 1) >> n;
-                const float *Drow = Dm + (size_t)arow * TmS;
+                const DT *Drow = Dm + (size_t)arow * TmS;
                 const bool lastband = kb == a.nbands - 1;
                 const bool hands_over = lane == 0 && kb > 0;
                 double cur = 1.0, dprev = 1.0, sb = 0.0;
@@ -265,7 +271,7 @@ __global__ __launch_bounds__(64) void gram_generic_kernel(GenericArgs a)
                 // K_fwd[p, q] was stored on forward step p_local + q = lane + q: one row of 64 per reverse step, descending
                 const float *wrow = wsk + (size_t)kb * a.nsteps * kWave + lane;
                 int R = P - 1 + L - 1; // row of step sp = 0
-                float gf = Drow[min(max(q, 0), P - 1) >> n];
+                DT gf = Drow[min(max(q, 0), P - 1) >> n];
                 double rb = rowbuf[P - 1]; // lane L-1's lower neighbour on step sp: rowbuf[P - 1 - sp]
                 rb = lastband ? 1.0 : rb;
                 // ring of the next KPF rows of the stored forward solution (an L2 round trip is ~8 steps long); the loop
@@ -279,7 +285,7 @@ __global__ __launch_bounds__(64) void gram_generic_kernel(GenericArgs a)
                     for (int u = 0; u < KPF; ++u, --q, --R) {
                         const int sp = sp0 + u;
                         const bool active = rowvalid && q >= 0 && q < P;
-                        const float gfn = Drow[min(max(q - 1, 0), P - 1) >> n];
+                        const DT gfn = Drow[min(max(q - 1, 0), P - 1) >> n];
                         const double rbr = rowbuf[max(P - 2 - sp, 0)];
                         const double rbn = lastband ? 1.0 : rbr;
                         const double kf = (double)kfr[u];
@@ -453,12 +459,14 @@ bool generic_solves_unordered(int A, int B, int T, int d, int want_grad, unsigne
     return true;
 }
 struct GenericPlan {
-    int dp, Tm, TmS, r, P, nbands, nsteps, JC, nchunks, grid, big;
+    int dp, Tm, TmS, r, P, nbands, nsteps, JC, nchunks, grid, big, dd;
     long long items;
     size_t lds, partial_bytes, col_bytes, wsk_per_block, wsk_bytes;
 };
 
-int make_plan(int A, int B, int T, int d, int n, int want_grad, GenericPlan &pl, bool yx = false)
+// precise: keep the increments in fp64 whenever the table fits 160 KB (force_generic, the fp64 pass over flagged pairs);
+// otherwise only where it costs no occupancy (<= 20 KB per pair: every shape of the reference's own calls)
+int make_plan(int A, int B, int T, int d, int n, int want_grad, GenericPlan &pl, bool yx = false, bool precise = false)
 {
     if (A < 1 || B < 1 || T < 2 || d < 1 || n < 0 || n > 10) {
         set_error("generic: bad shape A=%d B=%d T=%d d=%d n=%d", A, B, T, d, n);
@@ -485,6 +493,14 @@ int make_plan(int A, int B, int T, int d, int n, int want_grad, GenericPlan &pl,
     if (pl.lds > 160 * 1024) {
         set_error("generic: per-pair state needs %zu B of LDS (> 160 KiB): T=%d d=%d n=%d", pl.lds, T, d, n);
         return SIGSVGD_E_UNSUPPORTED;
+    }
+    pl.dd = 0;
+    if (!pl.big) {
+        const size_t l2 = generic_lds_bytes(T, d, n, want_grad, 0, 1);
+        if (l2 <= (precise ? (size_t)160 * 1024 : (size_t)20 * 1024)) {
+            pl.dd = 1;
+            pl.lds = l2;
+        }
     }
     // j-chunk: enough work items to fill the chip, few enough partial slabs
     int JC = 32;
@@ -525,27 +541,35 @@ int generic_workspace_bytes(int A, int B, int T, int d, int n, int want_grad, si
 }
 
 namespace {
-template <typename IO, bool NAIVE, bool GRAD, bool BIG>
+template <typename IO, bool NAIVE, bool GRAD, bool BIG, typename DT>
 hipError_t generic_launch_one(const GenericPlan &pl, hipStream_t stream, const GenericArgs &a)
 {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gram_generic_kernel<IO, NAIVE, GRAD, BIG>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gram_generic_kernel<IO, NAIVE, GRAD, BIG, DT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((gram_generic_kernel<IO, NAIVE, GRAD, BIG>), dim3(pl.grid), dim3(kWave), pl.lds, stream, a);
+    hipLaunchKernelGGL((gram_generic_kernel<IO, NAIVE, GRAD, BIG, DT>), dim3(pl.grid), dim3(kWave), pl.lds, stream, a);
     return hipSuccess;
 }
-template <typename IO, bool NAIVE>
+template <typename IO, bool NAIVE, typename DT>
 hipError_t generic_dispatch2(bool grad, bool big, const GenericPlan &pl, hipStream_t stream, const GenericArgs &a)
 {
-    if (!grad) return generic_launch_one<IO, NAIVE, false, false>(pl, stream, a);
-    return big ? generic_launch_one<IO, NAIVE, true, true>(pl, stream, a) : generic_launch_one<IO, NAIVE, true, false>(pl, stream, a);
+    if (!grad) return generic_launch_one<IO, NAIVE, false, false, DT>(pl, stream, a);
+    if constexpr (sizeof(DT) == 8) // (the compact long-path layout keeps fp32 increments: make_plan)
+        return generic_launch_one<IO, NAIVE, true, false, DT>(pl, stream, a);
+    else
+        return big ? generic_launch_one<IO, NAIVE, true, true, DT>(pl, stream, a) : generic_launch_one<IO, NAIVE, true, false, DT>(pl, stream, a);
+}
+template <typename IO>
+hipError_t generic_dispatch1(bool naive, bool grad, bool big, const GenericPlan &pl, hipStream_t stream, const GenericArgs &a)
+{
+    if (pl.dd)
+        return naive ? generic_dispatch2<IO, true, double>(grad, big, pl, stream, a) : generic_dispatch2<IO, false, double>(grad, big, pl, stream, a);
+    return naive ? generic_dispatch2<IO, true, float>(grad, big, pl, stream, a) : generic_dispatch2<IO, false, float>(grad, big, pl, stream, a);
 }
 hipError_t generic_dispatch(bool f64, bool naive, bool grad, bool big, const GenericPlan &pl, hipStream_t stream,
                             const GenericArgs &a)
 {
-    if (f64)
-        return naive ? generic_dispatch2<double, true>(grad, big, pl, stream, a) : generic_dispatch2<double, false>(grad, big, pl, stream, a);
-    return naive ? generic_dispatch2<float, true>(grad, big, pl, stream, a) : generic_dispatch2<float, false>(grad, big, pl, stream, a);
+    return f64 ? generic_dispatch1<double>(naive, grad, big, pl, stream, a) : generic_dispatch1<float>(naive, grad, big, pl, stream, a);
 }
 } // namespace
 
@@ -554,7 +578,7 @@ int generic_launch(const GramProblem &p)
     const int want_grad = p.gradX_out != nullptr;
     const bool yx = generic_solves_unordered(p.A, p.B, p.T, p.d, want_grad, p.flags);
     GenericPlan pl;
-    int rc = make_plan(p.A, p.B, p.T, p.d, p.n, want_grad, pl, yx);
+    int rc = make_plan(p.A, p.B, p.T, p.d, p.n, want_grad, pl, yx, (p.flags & SIGSVGD_FLAG_FORCE_GENERIC) != 0);
     if (rc) return rc;
     const size_t need = plan_bytes(pl);
     if (p.ws == nullptr || p.ws_bytes < need) {
@@ -645,7 +669,7 @@ int generic_repair_launch(const GramProblem &p, const unsigned char *flags, void
 {
     (void)ws;
     GenericPlan pl;
-    int rc = make_plan(p.A, p.B, p.T, p.d, p.n, 0, pl, false);
+    int rc = make_plan(p.A, p.B, p.T, p.d, p.n, 0, pl, false, true);
     if (rc) return rc;
     GenericArgs a;
     a.X = p.X; a.Y = p.Y; a.grad_out = nullptr; a.K_out = p.K_out;
