@@ -185,7 +185,7 @@ __global__ __launch_bounds__(64) void gram_generic_kernel(GenericArgs a)
             __syncthreads();
 
             SIG_GSTAMP(0)
-            // ---- phase 1: static kernel rows -> increments D (fp64 arithmetic, fp32 storage) --
+            // ---- phase 1: static kernel rows -> increments D (fp64 arithmetic, stored as DT) ----
             for (int rb = 0; rb < Tm; rb += kWave - 1) {
                 const int p = rb + lane;
                 const bool valid = p < T;
