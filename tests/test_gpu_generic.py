@@ -114,3 +114,26 @@ def test_generic_symmetric_solve(gpu, N, T, d, n, kind, weights):
     assert _relK(K.cpu().numpy(), Kref) < TOL and _rel(g.cpu().numpy(), gref) < TOL
     Kf = ops.gram_fwd(Xg, Xg, 1.0 / h, n, static_kind=kind, force_generic=True, y_is_x=True)
     assert _relK(Kf.cpu().numpy(), Kref) < TOL
+
+
+@pytest.mark.parametrize("T,d,n,scale,h", [(64, 1, 0, 0.5, 1.0), (100, 1, 0, 0.1, 0.1), (100, 1, 0, 0.2, 0.1), (33, 1, 2, 0.2, 0.1),
+                                           (20, 1, 2, 0.2, 0.1), (64, 2, 0, 0.2, 0.1)])
+def test_coverage_kernel_is_fp64_end_to_end(gpu, T, d, n, scale, h):
+    """Rough paths in one channel: the discrete solution oscillates and K[P][P] is ill-conditioned with respect to the
+    increments -- the fp32-sweep kernels reach 6e-5 there, and so did this kernel while it stored its
+    increment table in fp32 (1.9e-5 at T = 100).  With the table in fp64 (`force_generic=True`: whenever it fits 160 KB)
+    every entry is the fp64 reference's up to the fp32 store of K, and the gradient with it."""
+    from sigsvgd_amd import ops
+
+    rng = np.random.default_rng(3)
+    X = np.cumsum(scale * rng.standard_normal((9, T, d)), axis=1).astype(np.float32)
+    Y = np.cumsum(scale * rng.standard_normal((11, T, d)), axis=1).astype(np.float32)
+    Kref, gref = C.gram_fwd_bwd(X, Y, h, n)
+    Xg, Yg = torch.as_tensor(X, device=gpu), torch.as_tensor(Y, device=gpu)
+    K, g = ops.gram_fwd_bwd(Xg, Yg, 1.0 / h, n, force_generic=True)
+    Kf = ops.gram_fwd(Xg, Yg, 1.0 / h, n, force_generic=True)
+    assert _relK(K.cpu().numpy(), Kref) < 2e-7
+    assert _relK(Kf.cpu().numpy(), Kref) < 2e-7
+    assert _rel(g.cpu().numpy(), gref) < 1e-6
+    K64, g64 = ops.gram_fwd_bwd(Xg.double(), Yg.double(), 1.0 / h, n, force_generic=True)
+    assert _relK(K64.cpu().numpy(), Kref) < 1e-10
