@@ -15,7 +15,7 @@ _CSRC = os.path.join(_PKG, "csrc")
 # SIGSVGD_LIB_PATH: A/B benchmarking of two builds on the same GPU box (scripts/ab.py); never set in tests
 LIB_PATH = os.environ.get("SIGSVGD_LIB_PATH") or os.path.join(_PKG, "libsigsvgd_hip.so")
 SOURCES = ["capi.hip", "gram_generic.hip", "gram_fast.hip", "gram_quad.hip", "svgd_phi.hip",
-           "vec_kernels.hip", "vec_fused.hip", "cost_kernels.hip", "sig_backward.hip", "gram_dyad.hip"]
+           "vec_kernels.hip", "vec_fused.hip", "cost_kernels.hip", "sig_backward.hip", "gram_dyad.hip", "gram_band.hip"]
 HEADERS = [os.path.join(_CSRC, "sig_common.h"), os.path.join(_CSRC, "quad_sweeps.h"),
            os.path.join(_PKG, "..", "include", "sigsvgd_hip.h")]
 

@@ -125,6 +125,8 @@ static int dispatch(const GramProblem &p)
     // short paths with dyadic refinement whose refined grid has 64 .. 128 cells per side (the reference's own call shapes)
     if (!(p.flags & SIGSVGD_FLAG_FORCE_GENERIC) && dyad_supported(p.A, p.B, p.T, p.d, p.n, p.kind, p.flags))
         return dyad_launch(p);
+    if (!(p.flags & SIGSVGD_FLAG_FORCE_GENERIC) && band_supported(p.A, p.B, p.T, p.d, p.n, p.kind, p.flags))
+        return band_launch(p);
     return generic_launch(p);
 }
 
@@ -152,6 +154,8 @@ int sigsvgd_gram_workspace_bytes(int A, int B, int T, int d, int dyadic_order, i
         return quad_workspace_bytes(A, B, T, d, want_grad, bytes);
     if (!(flags & SIGSVGD_FLAG_FORCE_GENERIC) && dyad_supported(A, B, T, d, dyadic_order, SIGSVGD_STATIC_RBF, flags))
         return dyad_workspace_bytes(A, B, T, d, want_grad, bytes);
+    if (!(flags & SIGSVGD_FLAG_FORCE_GENERIC) && band_supported(A, B, T, d, dyadic_order, SIGSVGD_STATIC_RBF, flags))
+        return band_workspace_bytes(A, B, T, d, dyadic_order, want_grad, bytes);
     return generic_workspace_bytes(A, B, T, d, dyadic_order, want_grad, bytes);
 }
 

@@ -237,4 +237,9 @@ bool dyad_supported(int A, int B, int T, int d, int n, int kind, unsigned flags)
 int dyad_workspace_bytes(int A, int B, int T, int d, int want_grad, size_t *bytes);
 int dyad_launch(const GramProblem &p);
 
+// the same with 129 .. 256 refined cells per side, swept in bands of 64 rows (fp32 difference form) -- gram_band.hip
+bool band_supported(int A, int B, int T, int d, int n, int kind, unsigned flags);
+int band_workspace_bytes(int A, int B, int T, int d, int n, int want_grad, size_t *bytes);
+int band_launch(const GramProblem &p);
+
 } // namespace sigsvgd

@@ -1,6 +1,8 @@
-"""GPU parity: the refined-grid kernel (gram_dyad.hip: short paths with dyadic refinement, refined grid of 64 .. 128 cells
+"""GPU parity: the refined-grid kernels (gram_dyad.hip: short paths with dyadic refinement, refined grid of 64 .. 128 cells
 per side -- the reference's own call shapes: examples/script_planning_obstacle_field.py:156-158,325 order 5 on 5 points,
-script_planning_robot.py:391 order 6 on 3 points, BASELINE.json C1 order 2 on 20 points) vs the fp64 oracle, via the C ABI."""
+script_planning_robot.py:391 order 6 on 3 points, BASELINE.json C1 order 2 on 20 points; gram_band.hip: 129 .. 256 cells --
+examples/script_sequential_distribution.ipynb order 4 on 10 points, script_control_particle_maze.py:43-44 order 3 on 30
+points) vs the fp64 oracle, via the C ABI."""
 import numpy as np
 import pytest
 import torch
@@ -31,12 +33,17 @@ def _relK(a, b):
 
 # T, dyadic order, d  (refined cells per side = (T - 1) * 2^n)
 SHAPES = [(20, 2, 2), (5, 5, 2), (3, 6, 7), (9, 3, 3), (17, 2, 14), (33, 2, 5), (10, 3, 16), (30, 2, 4), (5, 4, 8), (3, 5, 1)]
+# the band kernel: 129 .. 256 cells (the notebook's and the maze script's shapes first; ragged last bands; 256 = the limit)
+BAND_SHAPES = [(10, 4, 2), (30, 3, 2), (33, 3, 3), (18, 3, 14), (3, 7, 2), (20, 3, 7), (5, 6, 16), (27, 3, 1)]
+SHAPES = SHAPES + BAND_SHAPES
 
 
 def test_shapes_take_the_refined_grid_kernel():
-    """the dispatch is a host-side predicate: cells per side in [64, 128], at most 33 points"""
+    """the dispatch is a host-side predicate: cells per side in [64, 128] / (128, 256], at most 33 points"""
     for T, n, d in SHAPES:
-        assert 64 <= (T - 1) << n <= 128 and T <= 33
+        assert 64 <= (T - 1) << n <= 256 and T <= 33
+    for T, n, d in BAND_SHAPES:
+        assert 128 < (T - 1) << n
 
 
 @pytest.mark.parametrize("T,n,d", SHAPES)
@@ -91,10 +98,11 @@ def test_dyadic_symmetric(gpu, T, n, d, weights):
 
 def test_dyadic_reference_shapes_at_their_sizes(gpu):
     """the reference's planning experiment (30 particles x 5 knots in R^2, order 5) and BASELINE C1 (16 x 20 x 2, order 2)
-    plus a launch with more items than workgroups (N = 300: 5,700 items)"""
+    plus a launch with more items than workgroups (N = 300: 5,700 items); the notebook's experiment (100 x 10 x 2, order 4,
+    bandwidth 5) and the maze controller's (35 policies x 30 steps x 2, order 3, sigma^2 = 32)"""
     from sigsvgd_amd import ops
 
-    for N, T, d, n, h in [(30, 5, 2, 5, 0.9), (16, 20, 2, 2, 1.0), (300, 5, 2, 5, 1.0)]:
+    for N, T, d, n, h in [(30, 5, 2, 5, 0.9), (16, 20, 2, 2, 1.0), (300, 5, 2, 5, 1.0), (100, 10, 2, 4, 5.0), (35, 30, 2, 3, 5.6)]:
         X = _paths(N, T, d, 11, 0.3)
         Xg = torch.as_tensor(X, device=gpu)
         K, g = ops.gram_fwd_bwd(Xg, Xg, 1.0 / h, n, y_is_x=True)
