@@ -63,12 +63,28 @@ __device__ __forceinline__ float b_shl(float v)
 {
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x130, 0xF, 0xF, false));
 }
-// v, with the value that lane `src` (uniform) of `from` holds in the lane where `here` is set (one v_readlane, one select
-// on a mask that does not change over the sweep)
-__device__ __forceinline__ float b_take(float v, bool here, float from, int src)
+// The forward neighbour shift of a sweep step: lane 0 of `dst` takes the value lane `src` of `from` holds (v_readlane ->
+// v_writelane), every other lane its upper neighbour's `v` (DPP move; lane 0 has no source and keeps what v_writelane put
+// there).  One asm statement because the hazards between its instructions are not hipcc's to pad: a VALU-written SGPR
+// wants wait states before the next VALU instruction reads it (s_nop), and the three instructions in front of the DPP move
+// are also the wait states between the stencil's write of `v` and the DPP read.
+__device__ __forceinline__ void b_shr_take(float &dst, float v, float from, int src)
+{
+    int sb;
+    asm("v_readlane_b32 %1, %2, %3\n\ts_nop 3\n\tv_writelane_b32 %0, %1, 0\n\t"
+        "v_mov_b32_dpp %0, %4 wave_shr:1 row_mask:0xf bank_mask:0xf"
+        : "+v"(dst), "=&s"(sb)
+        : "v"(from), "s"(src), "v"(v));
+}
+// (the reverse shift's boundary lane is the band's last row, known at run time only: a second scalar operand is one too
+//  many for v_writelane, so that lane takes its value through a select on a mask that does not change over the sweep.
+//  `shifted` is an argument on purpose: written as `here ? sb : b_shl(v)` the DPP move is evaluated where `here` is false
+//  only, i.e. with the boundary lane switched off in EXEC -- and a DPP move does not write a lane whose SOURCE lane is
+//  switched off: the lane next to the boundary kept a stale value and every gradient was wrong by O(1))
+__device__ __forceinline__ float b_shl_take(float shifted, float from, int src, bool here)
 {
     const float sb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(from), src));
-    return here ? sb : v;
+    return here ? sb : shifted;
 }
 } // namespace
 
@@ -195,34 +211,40 @@ __global__ __launch_bounds__(BNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                 const int p = 64 * kb + lanep;
                 const bool rowvalid = p < P;
                 const float *dcrow = wl.Dc + (min(p, P - 1) >> n) * Tm;
-                float *wp = GRAD ? wsw + (size_t)kb * nsteps * 64 + lanep : nullptr;
-                float cur = 1.f, upprev = 1.f, V = 0.f, hbv = 1.f;
-                int q = -lanep;
-                // lane 63 hands K[64 kb + 64][q + 1] over through entry q + 1 of hK (entries below 1 and beyond P are padding);
-                // the other lanes store into their own dump cell
-                float *ho = (lanep == 63) ? wl.hK + BPAD + q + 1 : wl.dump + lanep;
+                float *wb = GRAD ? wsw + (size_t)kb * nsteps * 64 : nullptr; // (uniform: the store takes it as a scalar base)
+                float cur = 1.f, upprev = 1.f, V = 0.f, hbv = 1.f, up = 1.f;
+                int q1 = 1 - lanep; // column + 1 of the cell in work
+                // lane 63 hands K[64 kb + 64][q + 1] over through entry q + 1 of hK (entries below 1 and beyond P are padding:
+                // a lane outside the grid writes whatever it computed there); the other lanes store into their own dump cell
+                float *ho = (lanep == 63) ? wl.hK + BPAD + q1 : wl.dump + lanep;
                 const int hinc = (lanep == 63) ? 1 : 0;
-                float g = dcrow[q >> n]; // (q < 0: a harmless read below the row; the lane is outside the grid)
+                const unsigned qlim = rowvalid ? (unsigned)P : 0u; // (no row: never inside the grid)
+                float g = dcrow[(q1 - 1) >> n]; // (q < 0: a harmless read below the row; the lane is outside the grid)
 #pragma unroll 1
-                for (int s = 0; s < nsteps; ++s, ++q) {
+                for (int s0 = 0; s0 < nsteps; s0 += 64) {
                     // lane 0's upper neighbour on step s is entry s + 1 of the row band kb - 1 left: 64 entries per refill
-                    if ((s & 63) == 0) hbv = kb ? wl.hK[BPAD + s + lanep + 1] : 1.f;
-                    const bool active = rowvalid && (unsigned)q < (unsigned)P;
-                    const float gnx = dcrow[(q + 1) >> n];
-                    const float up = b_take(b_shr(cur), lanep == 0, hbv, s & 63);
-                    // K11 - K01 = (K10 - K00) + F,  F = gamma (sqrt(3) t + gamma (t + K00)),  t = K10 + K01
-                    const float t = cur + up;
-                    float y = 1.7320508075688772f * t;
-                    y = __builtin_fmaf(t + upprev, g, y);
-                    const float Vn = __builtin_fmaf(g, y, V);
-                    const float nw = up + Vn;
-                    if (GRAD) wp[(size_t)s * 64] = upprev; // K[p][q]: only the entries of grid cells are read back
-                    *ho = active ? nw : 1.f;
-                    ho += hinc;
-                    cur = active ? nw : cur;
-                    V = active ? Vn : V;
-                    upprev = active ? up : upprev;
-                    g = gnx;
+                    hbv = kb ? wl.hK[BPAD + s0 + lanep + 1] : 1.f;
+                    const int send = min(64, nsteps - s0);
+#pragma unroll 1
+                    for (int u = 0; u < send; ++u) {
+                        const bool active = (unsigned)(q1 - 1) < qlim;
+                        const float gnx = dcrow[q1 >> n];
+                        b_shr_take(up, cur, hbv, u);
+                        // K11 - K01 = (K10 - K00) + F,  F = gamma (sqrt(3) t + gamma (t + K00)),  t = K10 + K01
+                        const float t = cur + up;
+                        float y = 1.7320508075688772f * t;
+                        y = __builtin_fmaf(t + upprev, g, y);
+                        const float Vn = __builtin_fmaf(g, y, V);
+                        const float nw = up + Vn;
+                        if (GRAD) wb[(size_t)(s0 + u) * 64 + lanep] = upprev; // K[p][q]: only the entries of grid cells are read back
+                        *ho = nw;
+                        ho += hinc;
+                        cur = active ? nw : cur;
+                        V = active ? Vn : V;
+                        upprev = active ? up : upprev;
+                        g = gnx;
+                        ++q1;
+                    }
                 }
                 if (p == P - 1) kfin = cur;
                 __builtin_amdgcn_wave_barrier();
@@ -270,7 +292,7 @@ __global__ __launch_bounds__(BNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                             const float gnx = dcrow[max(q - 1, 0) >> n];
                             const float kf = kfr[u];
                             kfr[u] = wrow[(size_t)max(R - KPF, 0) * 64];
-                            const float down = b_take(b_shl(cur), lanep == L - 1, hbv, sp & 63);
+                            const float down = b_shl_take(b_shl(cur), hbv, sp & 63, lanep == L - 1);
                             run = active ? __builtin_fmaf(kf, dprev, run) : run;
                             if (active && (q & (r - 1)) == 0) { // leftmost fine column of the coarse cell: the run is complete
                                 unsafeAtomicAdd(scrow + (q >> n), (double)run); // ds_add_f64 (this wavefront only)
@@ -281,7 +303,7 @@ __global__ __launch_bounds__(BNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                             y = __builtin_fmaf(t + dprev, g, y);
                             const float Vn = __builtin_fmaf(g, y, V);
                             const float nw = down + Vn;
-                            *ho = active ? nw : 1.f;
+                            *ho = nw; // (a lane outside the grid writes into the padding, or entries nobody reads)
                             ho += hinc;
                             cur = active ? nw : cur;
                             V = active ? Vn : V;
