@@ -10,7 +10,7 @@ def t(fn, n=50):
     torch.cuda.synchronize(); return (time.time() - t0) / n * 1e3
 # default dispatch (refined-grid kernel where its shapes apply) next to the coverage kernel (force_generic)
 for (N, T, d, n) in [(16, 20, 2, 2), (64, 20, 2, 2), (256, 20, 2, 2), (30, 5, 2, 5), (100, 5, 2, 5), (50, 3, 7, 6), (1024, 5, 2, 5),
-                     (16, 10, 2, 4), (100, 10, 2, 4)]:
+                     (16, 10, 2, 4), (100, 10, 2, 4), (35, 30, 2, 3)]:
     X, s = synthetic_inputs(N, T, d); X = X.to(dev)
     for fg in (False, True):
         print(f"N={N} T={T} d={d} n={n} {'coverage kernel' if fg else 'default dispatch'}: fwd+bwd sym %.3f ms | fwd+bwd ordered %.3f | fwd only %.3f" % (

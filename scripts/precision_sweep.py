@@ -3,7 +3,7 @@
 gradient (symmetric and ordered launches) against oracle/sigkernel_c.c; reported: worst per-entry |K - K_ref| / |K_ref|
 over the entries with |K| >= 0.1, worst absolute error over the entries with |K| < 0.1 (pairs whose solution has cancelled 90 % of the
 boundary value 1: the fp32 sweeps resolve K like values near 1), worst gradient error relative to max |grad_ref|, and the
-range of K.  Shapes: the register-resident, quadrant and refined-grid kernels.  Writes a markdown table (argv[1])."""
+range of K.  Shapes: the register-resident, quadrant, refined-grid and band kernels.  Writes a markdown table (argv[1])."""
 import sys
 
 import numpy as np
@@ -18,7 +18,7 @@ SCALES = [0.01, 0.02, 0.05, 0.1, 0.2, 0.5]
 HS = [0.02, 0.1, 0.5, 1.0, 3.0, 10.0]
 OFFSETS = [0.0, 100.0]
 SHAPES = [(12, 64, 7, 0), (12, 32, 7, 0), (10, 128, 14, 0), (10, 100, 5, 0), (12, 64, 2, 0), (10, 100, 2, 0), (12, 20, 2, 2), (12, 5, 2, 5),
-          (12, 30, 4, 2), (12, 64, 1, 0), (10, 100, 1, 0)]  # (d = 1 last: the summary splits there)
+          (12, 30, 4, 2), (12, 10, 2, 4), (12, 30, 2, 3), (12, 5, 2, 6), (12, 64, 1, 0), (10, 100, 1, 0)]  # (d = 1 last: the summary splits there)
 KFLOOR = 0.1  # entries below it are held to an absolute error (fp32 sweeps resolve K like values near 1)
 
 

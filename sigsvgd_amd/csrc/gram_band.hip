@@ -30,6 +30,8 @@ struct BandArgs {
     float *cslab; // [items][T*d] (symmetric launches)
     float *wsk;   // [gridDim.x][8 waves][bands][steps][64]: forward solution of the pair in work (gradient launches)
     size_t wsk_per_wave;
+    unsigned char *kflag; // [A][B]: 1 where the fp32 solution of the pair cancelled (max |K_grid| > 8 max(|K|, 0.1), as in
+                          // gram_quad.hip): the launcher lets the coverage kernel solve those pairs' K again in fp64
     int io64, A, B, T, d, n, symw;
     TileMap tm;
     long long nitems;
@@ -88,7 +90,11 @@ __device__ __forceinline__ float b_shl_take(float shifted, float from, int src, 
 }
 } // namespace
 
-template <int DPAD, bool GRAD, bool SYM>
+// COMP: the forward sweep's full-magnitude add in two floats (see `clo` below): dyadic order >= 5, where the refined
+// increments are so uniform that its rounding drifts (order 6, 256 cells, smooth paths: 1.2e-5 without, 1e-7 with); at the
+// reference's orders 3 and 4 the plain add stays inside 5e-6 and the six instructions per step (+8 % / +19 % forward-only)
+// are left out.
+template <int DPAD, bool GRAD, bool SYM, bool COMP>
 __global__ __launch_bounds__(BNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void gram_band_kernel(BandArgs a)
 {
     constexpr int NT = BNW * 64;
@@ -205,7 +211,8 @@ __global__ __launch_bounds__(BNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
             __builtin_amdgcn_s_waitcnt(0xc07f);
 
             // ---- forward sweep, band by band -------------------------------------------------------------------------
-            float kfin = 1.f;
+            double kfin = 1.0;
+            float kmax = 1.f; // largest |K| this lane has seen on the pair's grid
 #pragma unroll 1
             for (int kb = 0; kb < nb; ++kb) {
                 const int p = 64 * kb + lanep;
@@ -213,6 +220,12 @@ __global__ __launch_bounds__(BNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                 const float *dcrow = wl.Dc + (min(p, P - 1) >> n) * Tm;
                 float *wb = GRAD ? wsw + (size_t)kb * nsteps * 64 : nullptr; // (uniform: the store takes it as a scalar base)
                 float cur = 1.f, upprev = 1.f, V = 0.f, hbv = 1.f, up = 1.f;
+                // K[p+1][q] = cur + clo: the one full-magnitude add of a step, K11 = K01 + V, is made in two floats.  On a
+                // refined grid the increments of neighbouring cells are nearly identical, so its rounding has the same sign row
+                // after row and K drifts by up to 6e-8 per ROW (1.2e-5 at 256 cells per side with smooth paths, K ~ 1);
+                // the rounding error of each add travels down the rows as the low word (one more DPP move, three adds and a
+                // select per step) and the drift is gone.  It feeds nothing else: the stencil takes the high words.
+                float clo = 0.f;
                 int q1 = 1 - lanep; // column + 1 of the cell in work
                 // lane 63 hands K[64 kb + 64][q + 1] over through entry q + 1 of hK (entries below 1 and beyond P are padding:
                 // a lane outside the grid writes whatever it computed there); the other lanes store into their own dump cell
@@ -235,24 +248,36 @@ __global__ __launch_bounds__(BNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                         float y = 1.7320508075688772f * t;
                         y = __builtin_fmaf(t + upprev, g, y);
                         const float Vn = __builtin_fmaf(g, y, V);
-                        const float nw = up + Vn;
+                        // (lane 0: the row the band above handed over carries its low word already -- 0 from the shift)
+                        float Vt = Vn, nlo = 0.f;
+                        if constexpr (COMP)
+                            Vt += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(clo), 0x138, 0xF, 0xF, true));
+                        const float nw = up + Vt;
+                        if constexpr (COMP) nlo = Vt - (nw - up); // (exact while |K01| >= |V|; otherwise merely no better than before)
                         if (GRAD) wb[(size_t)(s0 + u) * 64 + lanep] = upprev; // K[p][q]: only the entries of grid cells are read back
-                        *ho = nw;
+                        *ho = COMP ? nw + nlo : nw;
                         ho += hinc;
                         cur = active ? nw : cur;
+                        kmax = fmaxf(kmax, fabsf(cur));
+                        if constexpr (COMP) clo = active ? nlo : clo;
                         V = active ? Vn : V;
                         upprev = active ? up : upprev;
                         g = gnx;
                         ++q1;
                     }
                 }
-                if (p == P - 1) kfin = cur;
+                if (p == P - 1) kfin = (double)cur + (double)clo;
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_s_waitcnt(0xc07f); // the row is in LDS before the next band reads it
             }
-            if (lanep == ((P - 1) & 63)) {
-                b_stany(a.K, (size_t)i * a.B + j, (double)kfin, io64);
-                if (SYM && j != i) b_stany(a.K, (size_t)j * a.B + i, (double)kfin, io64);
+            {
+                const float kfv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int((float)kfin), (P - 1) & 63));
+                const bool cancelled = __builtin_amdgcn_ballot_w64(kmax > 8.f * fmaxf(fabsf(kfv), 0.1f)) != 0;
+                if (lanep == ((P - 1) & 63)) {
+                    b_stany(a.K, (size_t)i * a.B + j, kfin, io64);
+                    if (SYM && j != i) b_stany(a.K, (size_t)j * a.B + i, kfin, io64);
+                    a.kflag[(size_t)i * a.B + j] = cancelled ? 1 : 0;
+                }
             }
 
             if (GRAD) {
@@ -437,9 +462,13 @@ inline size_t band_wsk_bytes(int T, int n)
 }
 } // namespace
 
+namespace {
+inline size_t band_flag_bytes(int A, int B) { return (((size_t)A * B + 255) & ~(size_t)255) + generic_repair_bytes(); }
+} // namespace
+
 int band_workspace_bytes(int A, int B, int T, int d, int n, int want_grad, size_t *bytes)
 {
-    *bytes = 256;
+    *bytes = band_flag_bytes(A, B) + 512;
     if (!want_grad) return SIGSVGD_OK;
     const GradGeom o = band_geometry(A, B, T, d, false);
     size_t need = o.rseg_bytes;
@@ -447,7 +476,7 @@ int band_workspace_bytes(int A, int B, int T, int d, int n, int want_grad, size_
         const GradGeom y = band_geometry(A, B, T, d, true);
         if (y.rseg_bytes + y.cslab_bytes > need) need = y.rseg_bytes + y.cslab_bytes;
     }
-    *bytes = need + band_wsk_bytes(T, n) + 1024;
+    *bytes = need + band_wsk_bytes(T, n) + band_flag_bytes(A, B) + 1024;
     return SIGSVGD_OK;
 }
 
@@ -459,14 +488,21 @@ int band_launch_variant(const GramProblem &p, BandArgs &a, const GradGeom &g, bo
     a.tm = g.tm;
     a.nitems = g.nitems;
     dim3 grid((unsigned)g.grid), block(BNW * 64);
+    const bool comp = p.n >= 5;
+#define SIGB_LAUNCH(G, S)                                                                                       \
+    {                                                                                                           \
+        if (comp) hipLaunchKernelGGL((gram_band_kernel<DPAD, G, S, true>), grid, block, 0, p.stream, a);        \
+        else hipLaunchKernelGGL((gram_band_kernel<DPAD, G, S, false>), grid, block, 0, p.stream, a);            \
+    }
     if (grad && sym)
-        hipLaunchKernelGGL((gram_band_kernel<DPAD, true, true>), grid, block, 0, p.stream, a);
+        SIGB_LAUNCH(true, true)
     else if (grad)
-        hipLaunchKernelGGL((gram_band_kernel<DPAD, true, false>), grid, block, 0, p.stream, a);
+        SIGB_LAUNCH(true, false)
     else if (sym)
-        hipLaunchKernelGGL((gram_band_kernel<DPAD, false, true>), grid, block, 0, p.stream, a);
+        SIGB_LAUNCH(false, true)
     else
-        hipLaunchKernelGGL((gram_band_kernel<DPAD, false, false>), grid, block, 0, p.stream, a);
+        SIGB_LAUNCH(false, false)
+#undef SIGB_LAUNCH
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "launch gram_band_kernel");
     return SIGSVGD_OK;
@@ -488,19 +524,24 @@ int band_launch(const GramProblem &p)
         return SIGSVGD_E_BADARG;
     }
     const GradGeom g = band_geometry(p.A, p.B, p.T, p.d, sym);
+    const size_t slabs = grad ? (g.rseg_bytes + g.cslab_bytes + 255) & ~(size_t)255 : 0;
+    const size_t need = band_flag_bytes(p.A, p.B) + slabs + (grad ? band_wsk_bytes(p.T, p.n) : 0) + 256;
+    if (!p.ws || p.ws_bytes < need) {
+        set_error("band: workspace %zu B < required %zu B", p.ws_bytes, need);
+        return SIGSVGD_E_WORKSPACE;
+    }
+    unsigned char *base = reinterpret_cast<unsigned char *>((reinterpret_cast<uintptr_t>(p.ws) + 255) & ~(uintptr_t)255);
+    a.kflag = base;
+    base += band_flag_bytes(p.A, p.B);
     if (grad) {
-        const size_t slabs = (g.rseg_bytes + g.cslab_bytes + 255) & ~(size_t)255;
-        const size_t need = slabs + band_wsk_bytes(p.T, p.n) + 256;
-        if (!p.ws || p.ws_bytes < need) {
-            set_error("band: workspace %zu B < required %zu B", p.ws_bytes, need);
-            return SIGSVGD_E_WORKSPACE;
-        }
-        unsigned char *base = reinterpret_cast<unsigned char *>((reinterpret_cast<uintptr_t>(p.ws) + 255) & ~(uintptr_t)255);
         a.rseg = reinterpret_cast<double *>(base);
         a.cslab = sym ? reinterpret_cast<float *>(base + g.rseg_bytes) : nullptr;
         a.wsk = reinterpret_cast<float *>(base + slabs);
     }
     int rc = p.d <= 8 ? band_launch_variant<8>(p, a, g, grad, sym) : band_launch_variant<16>(p, a, g, grad, sym);
+    if (rc) return rc;
+    // fp64 pass of the coverage kernel over the flagged pairs (a few microseconds when there are none)
+    rc = generic_repair_launch(p, a.kflag, nullptr, sym, g.tm, BNW);
     if (rc || !grad) return rc;
     return grad_reduce_launch(g, a.rseg, a.cslab, p.gradX_out, p.dtype == SIGSVGD_F64, p.A, p.B, p.T * p.d, sym, p.stream);
 }

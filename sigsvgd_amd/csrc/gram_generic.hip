@@ -544,9 +544,15 @@ namespace {
 template <typename IO, bool NAIVE, bool GRAD, bool BIG, typename DT>
 hipError_t generic_launch_one(const GenericPlan &pl, hipStream_t stream, const GenericArgs &a)
 {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gram_generic_kernel<IO, NAIVE, GRAD, BIG, DT>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
-    if (e != hipSuccess) return e;
+    // (once per instantiation and process, for the largest size any plan can ask for: the call costs ~10 us of host time,
+    //  which a small launch -- the fp64 pass behind a 50-us kernel -- would pay every time)
+    static bool raised = false;
+    if (!raised) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gram_generic_kernel<IO, NAIVE, GRAD, BIG, DT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        raised = true;
+    }
     hipLaunchKernelGGL((gram_generic_kernel<IO, NAIVE, GRAD, BIG, DT>), dim3(pl.grid), dim3(kWave), pl.lds, stream, a);
     return hipSuccess;
 }
