@@ -37,11 +37,13 @@
  *   - return value 0 = ok, negative = error (see SIGSVGD_E_*); sigsvgd_last_error() gives text;
  *   - `dtype` selects the I/O element type of X, Y, grad_out, K_out, gradX_out:
  *     SIGSVGD_F32 or SIGSVGD_F64.  Arithmetic of the register-resident and quadrant kernels
- *     (dyadic order 0, T <= 128): fp64 static kernel + 4-corner increments, fp32 PDE sweeps in
- *     difference form, fp32 storage of per-pair intermediates, fp32 gradient contraction, fp64
- *     reduction over pairs; the coverage kernel (dyadic refinement, longer paths, linear kernel,
- *     naive solver) runs its sweeps in fp64 (DESIGN.md "precision plan").  A pair whose fp32 solution
- *     cancelled -- the largest |K| on its PDE grid exceeds 4x (T <= 64) / 8x (T <= 128) max(|K|, 0.1):
+ *     (dyadic order 0, T <= 128) and of the refined-grid kernels (T <= 33 with dyadic refinement to
+ *     64 .. 256 cells per side: the reference's own call shapes): fp64 static kernel + 4-corner
+ *     increments, fp32 PDE sweeps in difference form, fp32 storage of per-pair intermediates, fp32
+ *     gradient contraction, fp64 reduction over pairs; the coverage kernel (other refinements, longer
+ *     paths, linear kernel, naive solver, SIGSVGD_FLAG_FORCE_GENERIC) is fp64 end to end (DESIGN.md
+ *     "precision plan").  A pair whose fp32 solution
+ *     cancelled -- the largest |K| on its PDE grid exceeds 4x (T <= 64) / 8x (otherwise) max(|K|, 0.1):
  *     oscillating discrete solutions of rough paths in few channels -- has its K solved again in fp64
  *     inside the same call, so every entry of K_out is within 1e-5 of the fp64 reference's, relative to
  *     max(|K|, 0.1);
@@ -87,7 +89,9 @@ extern "C" {
                                       /* their mirror images ntile-1 - (tile_offset + k*tile_stride): a tile and its mirror image  */
                                       /* together always hold the same number of pairs of the upper triangle, so every rank of   */
                                       /* the sharded step gets the same share (cyclic ownership alone: +5.4 % on the first rank)    */
-#define SIGSVGD_FLAG_FORCE_GENERIC 8u /* use the coverage kernel (forward solution in HBM scratch): tests */
+#define SIGSVGD_FLAG_FORCE_GENERIC 8u /* use the coverage kernel: fp64 end to end (every entry of K is the fp64 reference's up to */
+                                      /* the store in `dtype`, in any regime), one wavefront per pair; tests, and callers who   */
+                                      /* work with rough paths in one channel                            */
 
 /* errors */
 #define SIGSVGD_OK 0
