@@ -39,7 +39,8 @@ struct BandArgs {
 };
 
 namespace {
-constexpr int BNW = 8;     // wavefronts (rows i) per workgroup
+// wavefronts (rows i) per workgroup: 8 (two per SIMD) when there are pairs to fill the chip, 4 (one per SIMD: a wavefront's
+// dependent chain has the SIMD to itself) for launches of at most 4 pairs per CU, as in gram_dyad.hip
 constexpr int BTMAX = 33;  // coarse points per path
 constexpr int BPMAX = 256; // refined cells per side
 constexpr int BPAD = 64;   // boundary rows: entry e lives at [BPAD + e]; lanes outside the grid write into the padding
@@ -94,8 +95,8 @@ __device__ __forceinline__ float b_shl_take(float shifted, float from, int src, 
 // increments are so uniform that its rounding drifts (order 6, 256 cells, smooth paths: 1.2e-5 without, 1e-7 with); at the
 // reference's orders 3 and 4 the plain add stays inside 5e-6 and the six instructions per step (+8 % / +19 % forward-only)
 // are left out.
-template <int DPAD, bool GRAD, bool SYM, bool COMP>
-__global__ __launch_bounds__(BNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void gram_band_kernel(BandArgs a)
+template <int DPAD, bool GRAD, bool SYM, bool COMP, int BNW>
+__global__ __launch_bounds__(BNW * 64) __attribute__((amdgpu_waves_per_eu(BNW == 8 ? 2 : 1, 2))) void gram_band_kernel(BandArgs a)
 {
     constexpr int NT = BNW * 64;
     constexpr int TM = BTMAX - 1; // coarse cells per side at most
@@ -447,9 +448,14 @@ bool band_supported(int A, int B, int T, int d, int n, int kind, unsigned flags)
 }
 
 namespace {
-inline GradGeom band_geometry(int A, int B, int T, int d, bool sym)
+inline int band_nw(int A, int B, bool sym)
 {
-    return grad_geometry(A, B, T * d, sym, 0, 1, false, BNW, (long long)device_cu_count());
+    const long long pairs = sym ? (long long)A * (A + 1) / 2 : (long long)A * B;
+    return pairs <= 4ll * device_cu_count() ? 4 : 8;
+}
+inline GradGeom band_geometry(int A, int B, int T, int d, bool sym, int nw)
+{
+    return grad_geometry(A, B, T * d, sym, 0, 1, false, nw, (long long)device_cu_count());
 }
 inline size_t band_wsk_per_wave(int T, int n)
 {
@@ -458,7 +464,7 @@ inline size_t band_wsk_per_wave(int T, int n)
 }
 inline size_t band_wsk_bytes(int T, int n)
 {
-    return (((size_t)device_cu_count() * BNW * band_wsk_per_wave(T, n) * sizeof(float)) + 255) & ~(size_t)255;
+    return (((size_t)device_cu_count() * 8 * band_wsk_per_wave(T, n) * sizeof(float)) + 255) & ~(size_t)255;
 }
 } // namespace
 
@@ -470,10 +476,10 @@ int band_workspace_bytes(int A, int B, int T, int d, int n, int want_grad, size_
 {
     *bytes = band_flag_bytes(A, B) + 512;
     if (!want_grad) return SIGSVGD_OK;
-    const GradGeom o = band_geometry(A, B, T, d, false);
+    const GradGeom o = band_geometry(A, B, T, d, false, band_nw(A, B, false));
     size_t need = o.rseg_bytes;
     if (A == B) {
-        const GradGeom y = band_geometry(A, B, T, d, true);
+        const GradGeom y = band_geometry(A, B, T, d, true, band_nw(A, B, true));
         if (y.rseg_bytes + y.cslab_bytes > need) need = y.rseg_bytes + y.cslab_bytes;
     }
     *bytes = need + band_wsk_bytes(T, n) + band_flag_bytes(A, B) + 1024;
@@ -481,7 +487,7 @@ int band_workspace_bytes(int A, int B, int T, int d, int n, int want_grad, size_
 }
 
 namespace {
-template <int DPAD>
+template <int DPAD, int BNW>
 int band_launch_variant(const GramProblem &p, BandArgs &a, const GradGeom &g, bool grad, bool sym)
 {
     if (g.tm.owned <= 0 || g.nitems <= 0) return SIGSVGD_OK;
@@ -491,8 +497,8 @@ int band_launch_variant(const GramProblem &p, BandArgs &a, const GradGeom &g, bo
     const bool comp = p.n >= 5;
 #define SIGB_LAUNCH(G, S)                                                                                       \
     {                                                                                                           \
-        if (comp) hipLaunchKernelGGL((gram_band_kernel<DPAD, G, S, true>), grid, block, 0, p.stream, a);        \
-        else hipLaunchKernelGGL((gram_band_kernel<DPAD, G, S, false>), grid, block, 0, p.stream, a);            \
+        if (comp) hipLaunchKernelGGL((gram_band_kernel<DPAD, G, S, true, BNW>), grid, block, 0, p.stream, a);   \
+        else hipLaunchKernelGGL((gram_band_kernel<DPAD, G, S, false, BNW>), grid, block, 0, p.stream, a);       \
     }
     if (grad && sym)
         SIGB_LAUNCH(true, true)
@@ -523,7 +529,8 @@ int band_launch(const GramProblem &p)
         set_error("sym backward needs A == B");
         return SIGSVGD_E_BADARG;
     }
-    const GradGeom g = band_geometry(p.A, p.B, p.T, p.d, sym);
+    const int nw = band_nw(p.A, p.B, sym);
+    const GradGeom g = band_geometry(p.A, p.B, p.T, p.d, sym, nw);
     const size_t slabs = grad ? (g.rseg_bytes + g.cslab_bytes + 255) & ~(size_t)255 : 0;
     const size_t need = band_flag_bytes(p.A, p.B) + slabs + (grad ? band_wsk_bytes(p.T, p.n) : 0) + 256;
     if (!p.ws || p.ws_bytes < need) {
@@ -538,10 +545,14 @@ int band_launch(const GramProblem &p)
         a.cslab = sym ? reinterpret_cast<float *>(base + g.rseg_bytes) : nullptr;
         a.wsk = reinterpret_cast<float *>(base + slabs);
     }
-    int rc = p.d <= 8 ? band_launch_variant<8>(p, a, g, grad, sym) : band_launch_variant<16>(p, a, g, grad, sym);
+    int rc;
+    if (nw == 4)
+        rc = p.d <= 8 ? band_launch_variant<8, 4>(p, a, g, grad, sym) : band_launch_variant<16, 4>(p, a, g, grad, sym);
+    else
+        rc = p.d <= 8 ? band_launch_variant<8, 8>(p, a, g, grad, sym) : band_launch_variant<16, 8>(p, a, g, grad, sym);
     if (rc) return rc;
     // fp64 pass of the coverage kernel over the flagged pairs (a few microseconds when there are none)
-    rc = generic_repair_launch(p, a.kflag, nullptr, sym, g.tm, BNW);
+    rc = generic_repair_launch(p, a.kflag, nullptr, sym, g.tm, nw);
     if (rc || !grad) return rc;
     return grad_reduce_launch(g, a.rseg, a.cslab, p.gradX_out, p.dtype == SIGSVGD_F64, p.A, p.B, p.T * p.d, sym, p.stream);
 }
