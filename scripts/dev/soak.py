@@ -38,8 +38,9 @@ def main():
         n = int(rng.choice([0, 0, 1, 2, 3, 4])) if T <= 20 else 0
         if n >= 3 and T > 8:
             n = 2
-        if rng.random() < 0.2: # the refined-grid kernel's shapes: 64 .. 128 refined cells per side
-            T, n = [(3, 5), (3, 6), (5, 4), (5, 5), (9, 3), (9, 4), (17, 2), (17, 3), (20, 2), (33, 1), (33, 2), (12, 3)][int(rng.integers(0, 12))]
+        if rng.random() < 0.25: # the refined-grid and band kernels' shapes: 64 .. 256 refined cells per side
+            T, n = [(3, 5), (3, 6), (5, 4), (5, 5), (9, 3), (9, 4), (17, 2), (17, 3), (20, 2), (33, 1), (33, 2), (12, 3),
+                    (10, 4), (30, 3), (33, 3), (3, 7), (20, 3), (5, 6), (18, 3), (17, 4)][int(rng.integers(0, 20))]
         h = float(rng.choice([0.3, 1.0, 4.0]))
         scale = 0.05 if T > 64 else 0.08
         if rng.random() < 0.25: # rough paths in few channels: oscillating discrete solutions (fp64 pass for cancelled pairs)
