@@ -49,6 +49,8 @@
  *     max(|K|, 0.1);
  *   - results are bit-reproducible: every reduction over pairs runs in an order fixed by the launch
  *     geometry (no floating-point atomics), so two calls on the same inputs return the same bits.
+ *     One exception: sigsvgd_vec_kernel_fused joins its column splits with fp32 atomics (dK_out may
+ *     differ in the last bits between calls); sigsvgd_vec_sqdist + sigsvgd_vec_kernel are reproducible.
  */
 #ifndef SIGSVGD_HIP_H
 #define SIGSVGD_HIP_H
