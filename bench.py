@@ -357,7 +357,11 @@ def main(argv=None, backend_cls=HipBackend, script=None) -> int:
     if rank == 0 and not use_dist and not args.headline_only:
         others = {}
         for name, (n_, t_, d_, dy) in {"C1": (16, 20, 2, 2), "C2": (128, 32, 7, 0), "C3": (512, 64, 3, 0),
-                                       "C5 path shape, N=256 of 4096": (256, 128, 14, 0)}.items():
+                                       "C5 path shape, N=256 of 4096": (256, 128, 14, 0),
+                                       # the reference's own experiment shapes, for the record
+                                       "reference notebook experiment (script_sequential_distribution.ipynb)": (100, 10, 2, 4),
+                                       "reference maze controller (script_control_particle_maze.py)": (35, 30, 2, 3),
+                                       "reference planning experiment (script_planning_obstacle_field.py)": (30, 5, 2, 5)}.items():
             Xo, so = synthetic_inputs(n_, t_, d_)
             Xo, so = Xo.to(dev), so.to(dev)
 
