@@ -114,3 +114,21 @@ def test_dyadic_reference_shapes_at_their_sizes(gpu):
         Ko, go_ = ops.gram_fwd_bwd(Xg, Xg.clone(), 1.0 / h, n)
         assert _relK(Ko.cpu().numpy(), K.double().cpu().numpy()) < TOL  # (two orientations of a pair: both within TOL of the oracle)
         assert _rel(go_.cpu().numpy(), g.double().cpu().numpy()) < TOL
+
+
+@pytest.mark.parametrize("T,n,d,scale,h,offset", [(30, 3, 2, 0.5, 3.0, 100.0), (30, 3, 2, 0.5, 1.0, 100.0), (30, 3, 2, 0.1, 0.1, 0.0),
+                                                   (5, 6, 2, 0.02, 10.0, 100.0)])
+def test_band_kernel_rough_and_smooth_extremes(gpu, T, n, d, scale, h, offset):
+    """The band kernel's two accuracy mechanisms (gram_band.hip): pairs whose solution cancelled are flagged and solved again
+    in fp64 by the coverage kernel (the maze shape in rough regimes: 1.4e-5 without), and at dyadic order >= 5 the
+    full-magnitude add of the forward sweep runs in two floats (order 6, 256 cells, smooth paths: 1.2e-5 without)."""
+    from sigsvgd_amd import ops
+
+    X = _paths(12, T, d, 0, scale=scale, offset=offset)
+    Kref, gref = C.gram_fwd_bwd(X, X, h, n)
+    Xg = torch.as_tensor(X, device=gpu)
+    for K, g in [ops.gram_fwd_bwd(Xg, Xg, 1.0 / h, n, y_is_x=True), ops.gram_fwd_bwd(Xg, Xg.clone(), 1.0 / h, n)]:
+        assert _relK(K.cpu().numpy(), Kref) < 5e-6
+        assert _rel(g.cpu().numpy(), gref) < TOL
+    for K in [ops.gram_fwd(Xg, Xg, 1.0 / h, n, y_is_x=True), ops.gram_fwd(Xg, Xg.clone(), 1.0 / h, n)]:
+        assert _relK(K.cpu().numpy(), Kref) < 5e-6
