@@ -108,6 +108,7 @@ __global__ __launch_bounds__(BNW * 64) __attribute__((amdgpu_waves_per_eu(BNW ==
         float Dc[TM * TM];     // coarse increments / (r^2 sqrt(12)); after the sweeps: the parked column-side sums
         float hK[BHN], hU[BHN]; // K[64 b][.] left by band b - 1 for band b; U[64 b][.] left by band b for band b - 1
         float dump[64];
+        double dumpd[64];           // where the lanes without a finished run add their zero (reverse sweep)
         float rowacc[BTMAX * DPAD]; // row-side gradient of the wavefront's particle over the columns of a segment
     };
     __shared__ WaveLds wl_all[BNW];
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(BNW * 64) __attribute__((amdgpu_waves_per_eu(BNW ==
                 for (int s0 = 0; s0 < nsteps; s0 += 64) {
                     // lane 0's upper neighbour on step s is entry s + 1 of the row band kb - 1 left: 64 entries per refill
                     hbv = kb ? wl.hK[BPAD + s0 + lanep + 1] : 1.f;
-                    const int send = min(64, nsteps - s0);
+                    const int send = __builtin_amdgcn_readfirstlane(min(64, nsteps - s0)); // (a scalar loop bound)
 #pragma unroll 1
                     for (int u = 0; u < send; ++u) {
                         const bool active = (unsigned)(q1 - 1) < qlim;
@@ -255,11 +256,16 @@ __global__ __launch_bounds__(BNW * 64) __attribute__((amdgpu_waves_per_eu(BNW ==
                             Vt += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(clo), 0x138, 0xF, 0xF, true));
                         const float nw = up + Vt;
                         if constexpr (COMP) nlo = Vt - (nw - up); // (exact while |K01| >= |V|; otherwise merely no better than before)
-                        if (GRAD) wb[(size_t)(s0 + u) * 64 + lanep] = upprev; // K[p][q]: only the entries of grid cells are read back
+                        if (GRAD) { // K[p][q]: only the entries of grid cells are read back.  (asm: a scalar row base + the lane's
+                                    //  constant offset instead of a 64-bit vector pointer bumped every step; the reverse sweep waits
+                                    //  for these stores with s_waitcnt vmcnt(0) and a compiler barrier)
+                            const float *rowp = wb + (size_t)(s0 + u) * 64;
+                            asm volatile("global_store_dword %0, %1, %2" ::"v"(lanep * 4), "v"(upprev), "s"(rowp));
+                        }
                         *ho = COMP ? nw + nlo : nw;
                         ho += hinc;
                         cur = active ? nw : cur;
-                        kmax = fmaxf(kmax, fabsf(cur));
+                        asm("v_max_f32 %0, |%1|, %0" : "+v"(kmax) : "v"(cur)); // (fmaxf costs two canonicalising moves more)
                         if constexpr (COMP) clo = active ? nlo : clo;
                         V = active ? Vn : V;
                         upprev = active ? up : upprev;
@@ -315,15 +321,17 @@ __global__ __launch_bounds__(BNW * 64) __attribute__((amdgpu_waves_per_eu(BNW ==
                             // lane L-1's lower neighbour on step sp is entry P - 1 - sp of the row band kb + 1 left
                             if ((sp & 63) == 0) hbv = lastband ? 1.f : wl.hU[BPAD + max(P - 1 - sp - lanep, -BPAD)];
                             const bool active = rowvalid && (unsigned)q < (unsigned)P;
-                            const float gnx = dcrow[max(q - 1, 0) >> n];
+                            const float gnx = dcrow[(q - 1) >> n]; // (q < 1: a harmless read below the row)
                             const float kf = kfr[u];
                             kfr[u] = wrow[(size_t)max(R - KPF, 0) * 64];
                             const float down = b_shl_take(b_shl(cur), hbv, sp & 63, lanep == L - 1);
-                            run = active ? __builtin_fmaf(kf, dprev, run) : run;
-                            if (active && (q & (r - 1)) == 0) { // leftmost fine column of the coarse cell: the run is complete
-                                unsafeAtomicAdd(scrow + (q >> n), (double)run); // ds_add_f64 (this wavefront only)
-                                run = 0.f;
-                            }
+                            // block sums without a branch: every lane adds every step -- its finished run to the coarse cell
+                            // when it has just taken the cell's leftmost fine column, a zero to its own dump cell otherwise
+                            // (two nested EXEC regions per step cost the unrolled loop more than the LDS add)
+                            run = __builtin_fmaf(active ? kf : 0.f, dprev, run);
+                            const bool fl = active && (q & (r - 1)) == 0;
+                            unsafeAtomicAdd(fl ? scrow + (q >> n) : wl.dumpd + lanep, (double)(fl ? run : 0.f)); // ds_add_f64
+                            run = fl ? 0.f : run;
                             const float t = cur + down;
                             float y = 1.7320508075688772f * t;
                             y = __builtin_fmaf(t + dprev, g, y);
