@@ -122,7 +122,7 @@ __global__ __launch_bounds__(BNW * 64) __attribute__((amdgpu_waves_per_eu(BNW ==
     const double dscale = 1.0 / ((double)r * (double)r * 3.46410161513775459); // 1 / (r^2 sqrt(12))
     const double inv_r2 = 1.0 / ((double)r * (double)r);
     WaveLds &wl = wl_all[wave];
-    float *wsw = GRAD ? a.wsk + ((size_t)blockIdx.x * BNW + wave) * a.wsk_per_wave : nullptr;
+    float *wsw = GRAD ? a.wsk + ((size_t)blockIdx.x * BNW + wave) * a.wsk_per_wave + 16 * 64 : nullptr; // (16 rows of padding in front)
 
     // static item ranges: (owned row tile, column), tile-major; symmetric launches only the columns from the tile's first row
     const long long it0 = a.nitems * blockIdx.x / gridDim.x, it1 = a.nitems * (blockIdx.x + 1) / gridDim.x;
@@ -305,6 +305,9 @@ __global__ __launch_bounds__(BNW * 64) __attribute__((amdgpu_waves_per_eu(BNW ==
                     // K_fwd[p][q] was stored on forward step lane + q: row R = P + L - 2 - sp of the band's scratch on step sp
                     const float *wrow = wsw + (size_t)kb * nsteps * 64 + lanep;
                     int R = P + L - 2;
+                    // (uniform row pointer of the ring's next load; the last groups of steps reach up to 15 rows below the band's
+                    //  first: the 16 rows of padding in front of a wavefront's scratch, or the band below -- read, never used)
+                    const float *rnext = wsw + ((size_t)kb * nsteps + (R - 8)) * 64;
                     // lane 0 hands U[64 kb][q] over through entry q of hU
                     float *ho = (lanep == 0) ? wl.hU + BPAD + q : wl.dump + lanep;
                     const int hinc = (lanep == 0) ? -1 : 0;
@@ -323,14 +326,17 @@ __global__ __launch_bounds__(BNW * 64) __attribute__((amdgpu_waves_per_eu(BNW ==
                             const bool active = rowvalid && (unsigned)q < (unsigned)P;
                             const float gnx = dcrow[(q - 1) >> n]; // (q < 1: a harmless read below the row)
                             const float kf = kfr[u];
-                            kfr[u] = wrow[(size_t)max(R - KPF, 0) * 64];
+                            kfr[u] = rnext[lanep];
+                            rnext -= 64;
                             const float down = b_shl_take(b_shl(cur), hbv, sp & 63, lanep == L - 1);
                             // block sums without a branch: every lane adds every step -- its finished run to the coarse cell
                             // when it has just taken the cell's leftmost fine column, a zero to its own dump cell otherwise
                             // (two nested EXEC regions per step cost the unrolled loop more than the LDS add)
                             run = __builtin_fmaf(active ? kf : 0.f, dprev, run);
                             const bool fl = active && (q & (r - 1)) == 0;
-                            unsafeAtomicAdd(fl ? scrow + (q >> n) : wl.dumpd + lanep, (double)(fl ? run : 0.f)); // ds_add_f64
+                            float addend = fl ? run : 0.f;
+                            asm volatile("" : "+v"(addend)); // (select, then convert: hipcc otherwise converts and selects both halves)
+                            unsafeAtomicAdd(fl ? scrow + (q >> n) : wl.dumpd + lanep, (double)addend); // ds_add_f64
                             run = fl ? 0.f : run;
                             const float t = cur + down;
                             float y = 1.7320508075688772f * t;
@@ -468,7 +474,7 @@ inline GradGeom band_geometry(int A, int B, int T, int d, bool sym, int nw)
 inline size_t band_wsk_per_wave(int T, int n)
 {
     const int P = (T - 1) << n;
-    return (size_t)((P + 63) >> 6) * (size_t)(P + 63) * 64; // floats
+    return (size_t)((P + 63) >> 6) * (size_t)(P + 63) * 64 + 16 * 64; // floats (+ 16 rows in front: the ring's loads need no clamp)
 }
 inline size_t band_wsk_bytes(int T, int n)
 {
