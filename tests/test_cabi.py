@@ -63,6 +63,25 @@ def test_workspace_query_is_host_only(lib):
     assert lib.sigsvgd_gram_workspace_bytes(4, 4, 10, 3, 0, 1, 0, None) == -1
 
 
+def test_workspace_query_covers_every_pair_kernel(lib):
+    """one query per kernel family (register-resident, quadrant, refined-grid, band, coverage), gradient and forward-only:
+    status 0 and a size; the kernels that flag cancelled pairs for the fp64 pass need A * B bytes of flags even forward-only"""
+    n = ctypes.c_size_t(0)
+    shapes = {"fast": (64, 7, 0), "fast32": (32, 7, 0), "quad": (128, 14, 0), "dyad": (20, 2, 2), "dyad5": (5, 2, 5),
+              "band notebook": (10, 2, 4), "band maze": (30, 2, 3), "coverage": (40, 3, 3), "coverage naive": (20, 2, 2)}
+    for name, (T, d, order) in shapes.items():
+        flags = 1 if name.endswith("naive") else 0
+        for want_grad in (0, 1):
+            for A, B in ((37, 37), (5, 9)):
+                assert lib.sigsvgd_gram_workspace_bytes(A, B, T, d, order, want_grad, flags, ctypes.byref(n)) == 0, name
+                assert n.value > 0, name
+                if name in ("quad", "band notebook", "band maze"):
+                    assert n.value >= A * B
+    # the same shapes forced onto the coverage kernel
+    for name, (T, d, order) in shapes.items():
+        assert lib.sigsvgd_gram_workspace_bytes(9, 9, T, d, order, 1, 8, ctypes.byref(n)) == 0 and n.value > 0, name
+
+
 def test_argument_errors_are_status_codes(lib):
     """bad arguments are rejected on the host before anything is launched"""
     one = ctypes.c_void_p(16)  # never dereferenced: the checks below fail first
