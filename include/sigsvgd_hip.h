@@ -92,8 +92,9 @@ extern "C" {
                                       /* together always hold the same number of pairs of the upper triangle, so every rank of   */
                                       /* the sharded step gets the same share (cyclic ownership alone: +5.4 % on the first rank)    */
 #define SIGSVGD_FLAG_FORCE_GENERIC 8u /* use the coverage kernel: fp64 end to end (every entry of K is the fp64 reference's up to */
-                                      /* the store in `dtype`, in any regime), one wavefront per pair; tests, and callers who   */
-                                      /* work with rough paths in one channel                            */
+                                      /* the store in `dtype`, in any regime) while its tables fit LDS in fp64 (forward-only      */
+                                      /* T <= ~125, with the gradient T <= ~92); one wavefront per pair; tests, and callers who   */
+                                      /* work with rough paths in one to three channels                     */
 
 /* errors */
 #define SIGSVGD_OK 0
