@@ -33,6 +33,8 @@ struct DyadArgs {
     TileMap tm;
     long long nitems;
     double inv_h;
+    unsigned char *kflag; // [A][B]: 1 where the fp32 solution of the pair cancelled (max |K_grid| > 8 max(|K|, 0.1), as in
+                          // gram_quad.hip): the launcher lets the coverage kernel solve those pairs' K again in fp64
 };
 
 namespace {
@@ -46,6 +48,11 @@ constexpr int DHN = 136;  // hand-over rows: entries 0 .. 129 are read
 __device__ __forceinline__ double d_ldany(const void *b, size_t i, int io64)
 {
     return io64 ? static_cast<const double *>(b)[i] : (double)static_cast<const float *>(b)[i];
+}
+__device__ __forceinline__ float d_max3_abs(float m, float a, float b)
+{
+    asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(m) : "v"(a), "v"(b));
+    return m;
 }
 __device__ __forceinline__ void d_stany(void *b, size_t i, double v, int io64)
 {
@@ -181,6 +188,7 @@ __global__ __launch_bounds__(DNW * 64) __attribute__((amdgpu_waves_per_eu(DNW ==
             float rc = 1.f, rdA = 1.f, rdB = 1.f, rV = 0.f;
             int rev_band = -1;
             bool kdone = false;
+            float kmax = 1.f; // largest |K| this lane has seen on the pair's grid (boundary: 1)
             // visit list, 8 bits per visit: band | half << 1 | reverse << 2 | leave K[64][.] << 3
             unsigned long long vis = 0;
             int nv = 0;
@@ -250,6 +258,11 @@ __global__ __launch_bounds__(DNW * 64) __attribute__((amdgpu_waves_per_eu(DNW ==
                     asm volatile("" ::: "memory");
                     quad_fwd_all<0, true>(fc, fuA, fuB, fV, Dsl, Ssl, wr, rows, hbf, haddr, hinc, r3, nrows + ncols);
                     asm volatile("" ::: "memory");
+                    if (!kdone) { // (the slots: K at the cells' upper left corners; fc: the row's last value so far)
+                        kmax = d_max3_abs(kmax, fc, fc);
+#pragma unroll
+                        for (int k = 0; k < 64; k += 2) kmax = d_max3_abs(kmax, Ssl[k], Ssl[k + 1]);
+                    }
                 }
                 if (b == 0 && h == 0) {
                     svc = fc;
@@ -259,9 +272,13 @@ __global__ __launch_bounds__(DNW * 64) __attribute__((amdgpu_waves_per_eu(DNW ==
                 }
                 if (!kdone && b == b_last && h == h_last) {
                     kdone = true;
+                    // a pair whose solution cancelled (rough paths in few channels: DESIGN.md section 3) is marked for the fp64 pass
+                    const float kfin = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fc), nrows - 1));
+                    const bool cancelled = __builtin_amdgcn_ballot_w64(kmax > 8.f * fmaxf(fabsf(kfin), 0.1f)) != 0;
                     if (lanep == nrows - 1) {
                         d_stany(a.K, (size_t)i * a.B + j, (double)fc, io64);
                         if (SYM && j != i) d_stany(a.K, (size_t)j * a.B + i, (double)fc, io64);
+                        a.kflag[(size_t)i * a.B + j] = cancelled ? 1 : 0;
                     }
                 }
                 if (!GRAD || !rev) continue;
@@ -438,9 +455,13 @@ inline GradGeom dyad_geometry(int A, int B, int T, int d, bool sym, int nw)
 }
 } // namespace
 
+namespace {
+inline size_t dyad_flag_bytes(int A, int B) { return (((size_t)A * B + 255) & ~(size_t)255) + generic_repair_bytes(); }
+} // namespace
+
 int dyad_workspace_bytes(int A, int B, int T, int d, int want_grad, size_t *bytes)
 {
-    *bytes = 256;
+    *bytes = dyad_flag_bytes(A, B) + 512;
     if (!want_grad) return SIGSVGD_OK;
     const GradGeom o = dyad_geometry(A, B, T, d, false, dyad_nw(A, B, false));
     size_t need = o.rseg_bytes;
@@ -448,7 +469,7 @@ int dyad_workspace_bytes(int A, int B, int T, int d, int want_grad, size_t *byte
         const GradGeom y = dyad_geometry(A, B, T, d, true, dyad_nw(A, B, true));
         if (y.rseg_bytes + y.cslab_bytes > need) need = y.rseg_bytes + y.cslab_bytes;
     }
-    *bytes = need + 512;
+    *bytes = need + dyad_flag_bytes(A, B) + 512;
     return SIGSVGD_OK;
 }
 
@@ -489,13 +510,15 @@ int dyad_launch(const GramProblem &p)
     }
     const int nw = dyad_nw(p.A, p.B, sym);
     const GradGeom g = dyad_geometry(p.A, p.B, p.T, p.d, sym, nw);
+    const size_t need = dyad_flag_bytes(p.A, p.B) + (grad ? g.rseg_bytes + g.cslab_bytes : 0) + 256;
+    if (!p.ws || p.ws_bytes < need) {
+        set_error("dyad: workspace %zu B < required %zu B", p.ws_bytes, need);
+        return SIGSVGD_E_WORKSPACE;
+    }
+    unsigned char *base = reinterpret_cast<unsigned char *>((reinterpret_cast<uintptr_t>(p.ws) + 255) & ~(uintptr_t)255);
+    a.kflag = base;
+    base += dyad_flag_bytes(p.A, p.B);
     if (grad) {
-        const size_t need = g.rseg_bytes + g.cslab_bytes + 256;
-        if (!p.ws || p.ws_bytes < need) {
-            set_error("dyad: workspace %zu B < required %zu B", p.ws_bytes, need);
-            return SIGSVGD_E_WORKSPACE;
-        }
-        unsigned char *base = reinterpret_cast<unsigned char *>((reinterpret_cast<uintptr_t>(p.ws) + 255) & ~(uintptr_t)255);
         a.rseg = reinterpret_cast<double *>(base);
         a.cslab = sym ? reinterpret_cast<float *>(base + g.rseg_bytes) : nullptr;
     }
@@ -504,6 +527,9 @@ int dyad_launch(const GramProblem &p)
         rc = p.d <= 8 ? dyad_launch_variant<8, 4>(p, a, g, grad, sym) : dyad_launch_variant<16, 4>(p, a, g, grad, sym);
     else
         rc = p.d <= 8 ? dyad_launch_variant<8, 8>(p, a, g, grad, sym) : dyad_launch_variant<16, 8>(p, a, g, grad, sym);
+    if (rc) return rc;
+    // fp64 pass of the coverage kernel over the flagged pairs (a few microseconds when there are none)
+    rc = generic_repair_launch(p, a.kflag, nullptr, sym, g.tm, nw);
     if (rc || !grad) return rc;
     return grad_reduce_launch(g, a.rseg, a.cslab, p.gradX_out, p.dtype == SIGSVGD_F64, p.A, p.B, p.T * p.d, sym, p.stream);
 }
