@@ -43,7 +43,7 @@
  *     gradient contraction, fp64 reduction over pairs; the coverage kernel (other refinements, longer
  *     paths, linear kernel, naive solver, SIGSVGD_FLAG_FORCE_GENERIC) is fp64 end to end (DESIGN.md
  *     "precision plan").  A pair whose fp32 solution
- *     cancelled -- the largest |K| on its PDE grid exceeds 4x (T <= 64) / 8x (otherwise) max(|K|, 0.1):
+ *     cancelled -- the largest |K| on its PDE grid exceeds 4x .. 8x max(|K|, 0.1):
  *     oscillating discrete solutions of rough paths in few channels -- has its K solved again in fp64
  *     inside the same call, so every entry of K_out is within 1e-5 of the fp64 reference's, relative to
  *     max(|K|, 0.1);

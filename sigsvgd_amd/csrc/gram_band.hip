@@ -30,7 +30,7 @@ struct BandArgs {
     float *cslab; // [items][T*d] (symmetric launches)
     float *wsk;   // [gridDim.x][8 waves][bands][steps][64]: forward solution of the pair in work (gradient launches)
     size_t wsk_per_wave;
-    unsigned char *kflag; // [A][B]: 1 where the fp32 solution of the pair cancelled (max |K_grid| > 8 max(|K|, 0.1), as in
+    unsigned char *kflag; // [A][B]: 1 where the fp32 solution of the pair cancelled (max |K_grid| > max(2, r max(|K|, 0.1)) with r = 4 (d <= 2) or 8, as in
                           // gram_quad.hip): the launcher lets the coverage kernel solve those pairs' K again in fp64
     int io64, A, B, T, d, n, symw;
     TileMap tm;
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(BNW * 64) __attribute__((amdgpu_waves_per_eu(BNW ==
             }
             {
                 const float kfv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int((float)kfin), (P - 1) & 63));
-                const bool cancelled = __builtin_amdgcn_ballot_w64(kmax > 8.f * fmaxf(fabsf(kfv), 0.1f)) != 0;
+                const bool cancelled = __builtin_amdgcn_ballot_w64(kmax > 2.f && kmax > (d <= 2 ? 4.f : 8.f) * fmaxf(fabsf(kfv), 0.1f)) != 0;
                 if (lanep == ((P - 1) & 63)) {
                     b_stany(a.K, (size_t)i * a.B + j, kfin, io64);
                     if (SYM && j != i) b_stany(a.K, (size_t)j * a.B + i, kfin, io64);

@@ -33,7 +33,7 @@ struct DyadArgs {
     TileMap tm;
     long long nitems;
     double inv_h;
-    unsigned char *kflag; // [A][B]: 1 where the fp32 solution of the pair cancelled (max |K_grid| > 8 max(|K|, 0.1), as in
+    unsigned char *kflag; // [A][B]: 1 where the fp32 solution of the pair cancelled (max |K_grid| > max(2, r max(|K|, 0.1)) with r = 4 (d <= 2) or 8, as in
                           // gram_quad.hip): the launcher lets the coverage kernel solve those pairs' K again in fp64
 };
 
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(DNW * 64) __attribute__((amdgpu_waves_per_eu(DNW ==
                     kdone = true;
                     // a pair whose solution cancelled (rough paths in few channels: DESIGN.md section 3) is marked for the fp64 pass
                     const float kfin = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fc), nrows - 1));
-                    const bool cancelled = __builtin_amdgcn_ballot_w64(kmax > 8.f * fmaxf(fabsf(kfin), 0.1f)) != 0;
+                    const bool cancelled = __builtin_amdgcn_ballot_w64(kmax > 2.f && kmax > (d <= 2 ? 4.f : 8.f) * fmaxf(fabsf(kfin), 0.1f)) != 0;
                     if (lanep == nrows - 1) {
                         d_stany(a.K, (size_t)i * a.B + j, (double)fc, io64);
                         if (SYM && j != i) d_stany(a.K, (size_t)j * a.B + i, (double)fc, io64);

@@ -81,10 +81,12 @@ constexpr int QNW = SIGQ_NW; // wavefronts (rows i) per workgroup
 #ifndef SIGQ_CANCEL_RATIO
 #define SIGQ_CANCEL_RATIO 8.f
 #endif
-// A pair is solved again in fp64 when max |K_grid| > QUAD_CANCEL_RATIO * max(|K[P][P]|, 0.1): the fp32 sweeps lose
-// about 5e-7 (T = 64) .. 1e-6 (T = 128) of the LARGEST value on the grid, so 8 keeps every entry within 8e-6 while the
-// pairs that merely decay from the boundary value 1 to K >= 0.125 -- common with few channels, and cheap to get right in
-// fp32 -- stay out of the coverage kernel's fp64 pass (at 4, N=256 T=96 d=3 sent enough of them there to cost 25 %).
+// A pair is solved again in fp64 when max |K_grid| > ratio * max(|K[P][P]|, 0.1) AND max |K_grid| > 2: the fp32 sweeps lose
+// about 5e-7 (T = 64) .. 2e-6 (T = 128) of the LARGEST value on the grid.  The second condition keeps the pairs out that
+// merely decay from the boundary value 1 (nothing large to cancel: right to 1e-6 in fp32).  ratio = 8, and 4 for paths in
+// one or two channels: that is where the discrete solution is ill-conditioned beyond what the maximum shows (60 of the 61
+// soak cases beyond 1e-5), while with three channels and more a ratio of 4 only sends well-resolved
+// pairs to the coverage kernel's fp64 pass (N=256, T=96, d=3: +16 % forward-only for differences of 1e-6).
 constexpr float QUAD_CANCEL_RATIO = SIGQ_CANCEL_RATIO;
 // floats of a wavefront's column-side records of one pair: 4 quadrant passes + 2 halves of point row 64, each
 // [DPAD + 1 values][64 lanes], + 4 seam-column records of DPAD + 1 values (sized for DPAD = 16)
@@ -626,7 +628,7 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                     kdone = true;
                     // a pair whose solution cancelled (see gram_fast.hip, resweep_fwd_fp64) is marked for the fp64 pass
                     const float kfin = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fc), nrows - 1));
-                    const bool cancelled = __builtin_amdgcn_ballot_w64(kmax > QUAD_CANCEL_RATIO * fmaxf(fabsf(kfin), 0.1f)) != 0;
+                    const bool cancelled = __builtin_amdgcn_ballot_w64(kmax > 2.f && kmax > (d <= 2 ? 4.f : QUAD_CANCEL_RATIO) * fmaxf(fabsf(kfin), 0.1f)) != 0;
                     if (lanep == nrows - 1) {
                         q_stany(a.K, (size_t)i * a.B + j, (double)fc, io64);
                         if (SYM && j != i) q_stany(a.K, (size_t)j * a.B + i, (double)fc, io64);
