@@ -61,6 +61,8 @@ struct FastArgs {
     TileMap tm;                   // row tiles owned by this launch, in the order of the enumeration (multi-GPU sharding)
     long long nitems;             // (owned row tile, column) items of the launch
     double inv_h;
+    unsigned char *kflag;         // [A][B]: 1 where the pair's fp32 solution cancelled: besides the fp64 re-sweep in the kernel
+                                  // (fp32 increments), the launcher lets the coverage kernel solve those pairs exactly
 #ifdef SIGSVGD_PHASE_STAMPS
     unsigned long long *stamps; // diagnostic build only: [8] shader-clock totals per phase, summed over waves
 #endif
@@ -627,9 +629,29 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
                     const float kf1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cur), 32 + P - 1));
                     kf = (lane >> 5) ? kf1 : kf;
                 }
+                // Paths in one or two channels (the 4-channel instantiations; the launcher passes a flag array for d <= 2 only):
+                // the fp64 re-sweep below runs on fp32 increments, which is not enough where the discrete solution is
+                // ill-conditioned (33 of 6,000 soak cases beyond 1e-5 on this kernel, 32 of them with d <= 2), so the pairs the
+                // other kernels' rule marks (gram_quad.hip: the grid maximum above 2 and above 4 max(|K|, 0.1)) are also
+                // flagged for the exact fp64 pass of the coverage kernel that follows the launch.  A pair that came out NaN (a
+                // NaN in its inputs) is not marked: the coverage kernel's clamped exponential would turn it into a number.
+                // Compiled into the 4-channel kernels only: in the 8-channel ones the ballot and the byte store cost the
+                // headline launch 1.7 % (same-box A/B), for one soak case.
+                bool x0 = false, x1 = false;
+                if constexpr (DPAD == 4) {
+                    if (a.kflag) {
+                        const unsigned long long xbal =
+                            __builtin_amdgcn_ballot_w64(mine && kf == kf && km > 2.f && km > 4.f * fmaxf(fabsf(kf), 0.1f));
+                        x0 = (RING == 64) ? xbal != 0 : (unsigned)xbal != 0u;
+                        x1 = (xbal >> 32) != 0;
+                    }
+                }
                 if (lrow == P - 1 && mine) { // this lane's last value is K[P, P]
                     store_any(a.K, (size_t)i * a.B + j, (double)cur, io64);
                     if (SYM && j != i) store_any(a.K, (size_t)j * a.B + i, (double)cur, io64);
+                    if constexpr (DPAD == 4) { // (two rows per wavefront: each half of the ballot is one pair)
+                        if (a.kflag) a.kflag[(size_t)i * a.B + j] = (RING == 32 && (lane >> 5)) ? x1 : x0;
+                    }
                 }
                 if (__builtin_expect(__builtin_amdgcn_ballot_w64(mine && km > 4.f * fmaxf(fabsf(kf), 0.1f)) != 0, 0)) {
                     const double k64 = resweep_fwd_fp64<RING>(Dsl, P, lrow);
@@ -1018,10 +1040,18 @@ FastGeom fast_geometry(int A, int B, int T, int d, bool sym)
 
 int sym_tile_rows_fast(int T, int d) { return grad_nw(T, d); }
 
+namespace {
+// (the flag array of the exact fp64 pass: launches with paths in one or two channels only, see the kernel)
+inline size_t fast_flag_bytes(int A, int B, int d)
+{
+    return d <= 2 ? (((size_t)A * B + 255) & ~(size_t)255) + generic_repair_bytes() : 0;
+}
+} // namespace
+
 int fast_workspace_bytes(int A, int B, int T, int d, int want_grad, unsigned flags, size_t *bytes)
 {
     (void)flags;
-    *bytes = 256;
+    *bytes = 512 + fast_flag_bytes(A, B, d);
     if (want_grad) { // the larger of the ordered and the symmetric launch (the query carries no Y_IS_X promise)
         const FastGeom o = fast_geometry(A, B, T, d, false);
         size_t need = o.rseg_bytes;
@@ -1082,6 +1112,10 @@ int launch_variant(const GramProblem &p, FastArgs &a, bool grad, bool sym)
         hipLaunchKernelGGL((gram_fast_kernel<DPAD, NW, true, false, false, RING>), grid, block, 0, p.stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "launch gram_fast_kernel");
+    if (a.kflag) { // exact fp64 pass of the coverage kernel over the flagged pairs (a few microseconds when there are none)
+        const int rc = generic_repair_launch(p, a.kflag, nullptr, sym, a.tm, NWR);
+        if (rc) return rc;
+    }
 #ifdef SIGSVGD_PHASE_STAMPS
     {
         unsigned long long h[8];
@@ -1117,12 +1151,14 @@ int dispatch_variant(const GramProblem &p, FastArgs &a, bool grad, bool sym)
 int run_grad(const GramProblem &p, FastArgs &a, bool sym, void *out, int out64)
 {
     const FastGeom g = fast_geometry(p.A, p.B, p.T, p.d, sym, a.tm);
-    const size_t need = g.rseg_bytes + g.cslab_bytes + 256;
+    const size_t need = fast_flag_bytes(p.A, p.B, p.d) + g.rseg_bytes + g.cslab_bytes + 256;
     if (!p.ws || p.ws_bytes < need) {
         set_error("fast: workspace %zu B < required %zu B", p.ws_bytes, need);
         return SIGSVGD_E_WORKSPACE;
     }
     unsigned char *base = reinterpret_cast<unsigned char *>((reinterpret_cast<uintptr_t>(p.ws) + 255) & ~(uintptr_t)255);
+    a.kflag = p.d <= 2 ? base : nullptr;
+    base += fast_flag_bytes(p.A, p.B, p.d);
     a.rseg = reinterpret_cast<double *>(base);
     a.cslab = sym ? reinterpret_cast<float *>(base + g.rseg_bytes) : nullptr;
     int rc = dispatch_variant(p, a, true, sym);
@@ -1138,6 +1174,7 @@ void fill_args(const GramProblem &p, FastArgs &a)
     a.tm = make_tilemap(1, 0, 1, false); a.nitems = 0; // (off / stride / fold are what launch_variant reads: a full launch)
     a.rseg = nullptr;
     a.cslab = nullptr;
+    a.kflag = nullptr;
 }
 } // namespace
 
@@ -1151,7 +1188,16 @@ int fast_launch(const GramProblem &p)
         set_error("sym backward needs A == B");
         return SIGSVGD_E_BADARG;
     }
-    if (!grad) return dispatch_variant(p, a, false, sym);
+    if (!grad) {
+        if (p.d <= 2) {
+            if (!p.ws || p.ws_bytes < fast_flag_bytes(p.A, p.B, p.d) + 256) {
+                set_error("fast: workspace %zu B < required %zu B", p.ws_bytes, fast_flag_bytes(p.A, p.B, p.d) + 256);
+                return SIGSVGD_E_WORKSPACE;
+            }
+            a.kflag = reinterpret_cast<unsigned char *>((reinterpret_cast<uintptr_t>(p.ws) + 255) & ~(uintptr_t)255);
+        }
+        return dispatch_variant(p, a, false, sym);
+    }
     return run_grad(p, a, sym, p.gradX_out, p.dtype == SIGSVGD_F64);
 }
 

@@ -55,6 +55,9 @@ def test_workspace_query_is_host_only(lib):
     assert lo <= n.value <= lo + 1024 * 8 * 448 * 8 + 8192  # (the workgroup count depends on the device: <= 1024 here)
     # forward only: nothing is accumulated
     assert lib.sigsvgd_gram_workspace_bytes(1024, 1024, 64, 7, 0, 0, 0, ctypes.byref(n)) == 0 and 0 < n.value <= 4096
+    # paths in one or two channels: one byte per pair more, the flags of the pairs the coverage kernel solves again in fp64
+    assert lib.sigsvgd_gram_workspace_bytes(1024, 1024, 64, 2, 0, 0, 0, ctypes.byref(n)) == 0
+    assert 1024 * 1024 <= n.value <= 1024 * 1024 + 4096
     # generic path (dyadic refinement): partial slabs + per-workgroup forward-solution scratch
     assert lib.sigsvgd_gram_workspace_bytes(16, 16, 20, 2, 2, 1, 0, ctypes.byref(n)) == 0 and n.value > 0
     # does not fit in LDS -> UNSUPPORTED with a message
@@ -75,7 +78,7 @@ def test_workspace_query_covers_every_pair_kernel(lib):
             for A, B in ((37, 37), (5, 9)):
                 assert lib.sigsvgd_gram_workspace_bytes(A, B, T, d, order, want_grad, flags, ctypes.byref(n)) == 0, name
                 assert n.value > 0, name
-                if name in ("quad", "band notebook", "band maze"):
+                if not name.startswith("coverage") and not name.startswith("fast"):
                     assert n.value >= A * B
     # the same shapes forced onto the coverage kernel
     for name, (T, d, order) in shapes.items():
