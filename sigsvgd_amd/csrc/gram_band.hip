@@ -279,7 +279,7 @@ __global__ __launch_bounds__(BNW * 64) __attribute__((amdgpu_waves_per_eu(BNW ==
             }
             {
                 const float kfv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int((float)kfin), (P - 1) & 63));
-                const bool cancelled = __builtin_amdgcn_ballot_w64(kfv == kfv && kmax > 2.f && kmax > (d <= 2 ? 4.f : 8.f) * fmaxf(fabsf(kfv), 0.1f)) != 0;
+                const bool cancelled = __builtin_amdgcn_ballot_w64(kfv == kfv && kmax > (d == 1 ? 1.5f : 2.f) && kmax > (d == 1 ? 2.f : d == 2 ? 4.f : 8.f) * fmaxf(fabsf(kfv), 0.1f)) != 0;
                 if (lanep == ((P - 1) & 63)) {
                     b_stany(a.K, (size_t)i * a.B + j, kfin, io64);
                     if (SYM && j != i) b_stany(a.K, (size_t)j * a.B + i, kfin, io64);

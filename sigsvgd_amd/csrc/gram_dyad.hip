@@ -274,7 +274,7 @@ __global__ __launch_bounds__(DNW * 64) __attribute__((amdgpu_waves_per_eu(DNW ==
                     kdone = true;
                     // a pair whose solution cancelled (rough paths in few channels: DESIGN.md section 3) is marked for the fp64 pass
                     const float kfin = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fc), nrows - 1));
-                    const bool cancelled = __builtin_amdgcn_ballot_w64(kfin == kfin && kmax > 2.f && kmax > (d <= 2 ? 4.f : 8.f) * fmaxf(fabsf(kfin), 0.1f)) != 0;
+                    const bool cancelled = __builtin_amdgcn_ballot_w64(kfin == kfin && kmax > (d == 1 ? 1.5f : 2.f) && kmax > (d == 1 ? 2.f : d == 2 ? 4.f : 8.f) * fmaxf(fabsf(kfin), 0.1f)) != 0;
                     if (lanep == nrows - 1) {
                         d_stany(a.K, (size_t)i * a.B + j, (double)fc, io64);
                         if (SYM && j != i) d_stany(a.K, (size_t)j * a.B + i, (double)fc, io64);

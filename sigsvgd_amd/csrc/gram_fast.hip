@@ -641,7 +641,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
                 if constexpr (DPAD == 4) {
                     if (a.kflag) {
                         const unsigned long long xbal =
-                            __builtin_amdgcn_ballot_w64(mine && kf == kf && km > 2.f && km > 4.f * fmaxf(fabsf(kf), 0.1f));
+                            __builtin_amdgcn_ballot_w64(mine && kf == kf && km > (d == 1 ? 1.5f : 2.f) && km > (d == 1 ? 2.f : 4.f) * fmaxf(fabsf(kf), 0.1f));
                         x0 = (RING == 64) ? xbal != 0 : (unsigned)xbal != 0u;
                         x1 = (xbal >> 32) != 0;
                     }

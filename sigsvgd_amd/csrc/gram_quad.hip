@@ -628,7 +628,7 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                     kdone = true;
                     // a pair whose solution cancelled (see gram_fast.hip, resweep_fwd_fp64) is marked for the fp64 pass
                     const float kfin = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fc), nrows - 1));
-                    const bool cancelled = __builtin_amdgcn_ballot_w64(kfin == kfin && kmax > 2.f && kmax > (d <= 2 ? 4.f : QUAD_CANCEL_RATIO) * fmaxf(fabsf(kfin), 0.1f)) != 0;
+                    const bool cancelled = __builtin_amdgcn_ballot_w64(kfin == kfin && kmax > (d == 1 ? 1.5f : 2.f) && kmax > (d == 1 ? 2.f : d == 2 ? 4.f : QUAD_CANCEL_RATIO) * fmaxf(fabsf(kfin), 0.1f)) != 0;
                     if (lanep == nrows - 1) {
                         q_stany(a.K, (size_t)i * a.B + j, (double)fc, io64);
                         if (SYM && j != i) q_stany(a.K, (size_t)j * a.B + i, (double)fc, io64);
