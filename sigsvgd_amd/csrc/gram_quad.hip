@@ -83,10 +83,11 @@ constexpr int QNW = SIGQ_NW; // wavefronts (rows i) per workgroup
 #endif
 // A pair is solved again in fp64 when max |K_grid| > ratio * max(|K[P][P]|, 0.1) AND max |K_grid| > 2: the fp32 sweeps lose
 // about 5e-7 (T = 64) .. 2e-6 (T = 128) of the LARGEST value on the grid.  The second condition keeps the pairs out that
-// merely decay from the boundary value 1 (nothing large to cancel: right to 1e-6 in fp32).  ratio = 8, and 4 for paths in
-// one or two channels: that is where the discrete solution is ill-conditioned beyond what the maximum shows (60 of the 61
-// soak cases beyond 1e-5), while with three channels and more a ratio of 4 only sends well-resolved
-// pairs to the coverage kernel's fp64 pass (N=256, T=96, d=3: +16 % forward-only for differences of 1e-6).
+// merely decay from the boundary value 1 (nothing large to cancel: right to 1e-6 in fp32).  ratio = 8; 4 for paths in
+// two channels and 2 (grid maximum above 1.5) in one: that is where the discrete solution is ill-conditioned beyond what
+// the maximum shows (60 of the 61 soak cases beyond 1e-5), while with three channels and more a ratio
+// of 4 only sends well-resolved pairs to the coverage kernel's fp64 pass (N=256, T=96, d=3: +16 % forward-only for
+// differences of 1e-6).
 constexpr float QUAD_CANCEL_RATIO = SIGQ_CANCEL_RATIO;
 // floats of a wavefront's column-side records of one pair: 4 quadrant passes + 2 halves of point row 64, each
 // [DPAD + 1 values][64 lanes], + 4 seam-column records of DPAD + 1 values (sized for DPAD = 16)
