@@ -17,9 +17,9 @@ int hip_fail(hipError_t e, const char *what);
 // exp(a) = 2^k * P(r), k = rint(a*log2e), r = a - k*ln2 (two-word ln2), P = degree-11 Taylor/Horner
 // on |r| <= ln2/2.  Relative error < 3e-16 * few; enough for the 4-corner cancellation in the
 // kernel increments (needs ~1e-10).  One v_rndne_f64 + v_cvt_i32_f64 + v_ldexp_f64 + 14 FMA/MUL.
-__device__ __forceinline__ double exp64(double a)
+__device__ __forceinline__ double exp64(double a0)
 {
-    a = fmin(fmax(a, -1000.0), 700.0);
+    double a = fmin(fmax(a0, -1000.0), 700.0); // (fmax / fmin drop a NaN: it is put back at the end)
     const double kf = __builtin_rint(a * 1.4426950408889634074);
     double r = __builtin_fma(kf, -6.93147180369123816490e-01, a);
     r = __builtin_fma(kf, -1.90821492927058770002e-10, r);
@@ -35,7 +35,8 @@ __device__ __forceinline__ double exp64(double a)
     p = __builtin_fma(p, r, 0.5);
     p = __builtin_fma(p, r, 1.0);
     p = __builtin_fma(p, r, 1.0);
-    return ldexp(p, (int)kf);
+    const double e = ldexp(p, (int)kf);
+    return (a0 != a0) ? a0 : e; // a NaN in a path poisons its own row / column of K, as in the reference
 }
 
 // 2^t for the register-resident kernel: t arrives already scaled by log2(e) (the scale is folded into

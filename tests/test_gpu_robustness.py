@@ -87,19 +87,25 @@ def test_degenerate_paths(gpu, T, d):
     assert _relK(K4.cpu().numpy(), Kref) < TOL and _rel(g4.cpu().numpy(), gref) < TOL
 
 
-def test_non_finite_inputs_propagate_without_hanging(gpu):
-    """a NaN in one trajectory poisons its own row/column only; the launch completes"""
+@pytest.mark.parametrize("T,d,n,generic", [(64, 7, 0, False), (32, 2, 0, False), (100, 5, 0, False), (20, 2, 2, False),
+                                           (10, 2, 4, False), (64, 7, 0, True), (10, 2, 4, True)])
+def test_non_finite_inputs_propagate_without_hanging(gpu, T, d, n, generic):
+    """a NaN in one trajectory poisons its own row/column only; the launch completes -- on every pair kernel (the fp64 pass
+    over flagged pairs must not turn a NaN pair into a number: NaN pairs are not flagged, and the coverage kernel's
+    exponential hands a NaN through)"""
     from sigsvgd_amd import ops
 
-    X = _paths(9, 64, 7, 5, 0.05)
-    X[3, 10, 2] = np.nan
+    X = _paths(9, T, d, 5, 0.05)
+    X[3, min(10, T - 2), d - 1] = np.nan
     Xg = torch.as_tensor(X, device=gpu)
-    K, g = ops.gram_fwd_bwd(Xg, Xg, 1.0, y_is_x=True)
+    K, g = ops.gram_fwd_bwd(Xg, Xg, 1.0, n, y_is_x=True, force_generic=generic)
+    Kf = ops.gram_fwd(Xg, Xg.clone(), 1.0, n, force_generic=generic)
     torch.cuda.synchronize()
-    bad = torch.isnan(K)
-    assert bad[3].all() and bad[:, 3].all()
-    ok = [i for i in range(9) if i != 3]
-    assert torch.isfinite(K[ok][:, ok]).all()
+    for Kx in (K, Kf):
+        bad = torch.isnan(Kx)
+        assert bad[3].all() and bad[:, 3].all()
+        ok = [i for i in range(9) if i != 3]
+        assert torch.isfinite(Kx[ok][:, ok]).all()
 
 
 def test_rough_long_paths_are_solved(gpu):
