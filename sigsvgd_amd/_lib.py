@@ -25,7 +25,7 @@ STATIC_RBF, STATIC_LINEAR = 0, 1
 FLAG_NAIVE_SOLVER, FLAG_SYM, FLAG_Y_IS_X, FLAG_FORCE_GENERIC, FLAG_WS_CLEAN, FLAG_STORED_FORWARD = 1, 2, 4, 8, 16, 32
 FLAG_FOLD_TILES = 64
 VEC_GAUSSIAN, VEC_IMQ, VEC_UNIT = 0, 1, 2
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 EXPORTS = [
     "sigsvgd_abi_version",
@@ -141,7 +141,7 @@ def load():
     L.sigsvgd_last_error.restype = ctypes.c_char_p
     L.sigsvgd_last_error.argtypes = []
     L.sigsvgd_gram_workspace_bytes.restype = ci
-    L.sigsvgd_gram_workspace_bytes.argtypes = [ci, ci, ci, ci, ci, ci, cu, ctypes.POINTER(ctypes.c_size_t)]
+    L.sigsvgd_gram_workspace_bytes.argtypes = [ci, ci, ci, ci, ci, ci, ci, cu, ctypes.POINTER(ctypes.c_size_t)]
     L.sigsvgd_gram_fwd.restype = ci
     L.sigsvgd_gram_fwd.argtypes = [vp, vp, ci, ci, ci, ci, ci, cd, ci, ci, cu, vp, vp, ctypes.c_size_t, vp]
     L.sigsvgd_gram_fwd_bwd.restype = ci

@@ -140,23 +140,28 @@ int sigsvgd_abi_version(void) { return SIGSVGD_ABI_VERSION; }
 
 const char *sigsvgd_last_error(void) { return g_err; }
 
-int sigsvgd_gram_workspace_bytes(int A, int B, int T, int d, int dyadic_order, int want_grad, unsigned flags,
-                                 size_t *bytes)
+int sigsvgd_gram_workspace_bytes(int A, int B, int T, int d, int dyadic_order, int static_kind, int want_grad,
+                                 unsigned flags, size_t *bytes)
 {
     if (!bytes) {
         set_error("bytes == NULL");
         return SIGSVGD_E_BADARG;
     }
-    // size for whichever kernel dispatch() would pick; the static kind does not change the size
-    if (!(flags & SIGSVGD_FLAG_FORCE_GENERIC) && fast_supported(A, B, T, d, dyadic_order, SIGSVGD_STATIC_RBF, flags))
+    if (static_kind != SIGSVGD_STATIC_RBF && static_kind != SIGSVGD_STATIC_LINEAR) {
+        set_error("bad static kernel kind %d", static_kind);
+        return SIGSVGD_E_BADARG;
+    }
+    // size for the kernel dispatch() picks: the same predicates on the same arguments
+    const bool forced = (flags & SIGSVGD_FLAG_FORCE_GENERIC) != 0;
+    if (!forced && fast_supported(A, B, T, d, dyadic_order, static_kind, flags))
         return fast_workspace_bytes(A, B, T, d, want_grad, flags, bytes);
-    if (!(flags & SIGSVGD_FLAG_FORCE_GENERIC) && quad_supported(A, B, T, d, dyadic_order, SIGSVGD_STATIC_RBF, flags))
+    if (!forced && quad_supported(A, B, T, d, dyadic_order, static_kind, flags))
         return quad_workspace_bytes(A, B, T, d, want_grad, bytes);
-    if (!(flags & SIGSVGD_FLAG_FORCE_GENERIC) && dyad_supported(A, B, T, d, dyadic_order, SIGSVGD_STATIC_RBF, flags))
+    if (!forced && dyad_supported(A, B, T, d, dyadic_order, static_kind, flags))
         return dyad_workspace_bytes(A, B, T, d, want_grad, bytes);
-    if (!(flags & SIGSVGD_FLAG_FORCE_GENERIC) && band_supported(A, B, T, d, dyadic_order, SIGSVGD_STATIC_RBF, flags))
+    if (!forced && band_supported(A, B, T, d, dyadic_order, static_kind, flags))
         return band_workspace_bytes(A, B, T, d, dyadic_order, want_grad, bytes);
-    return generic_workspace_bytes(A, B, T, d, dyadic_order, want_grad, bytes);
+    return generic_workspace_bytes(A, B, T, d, dyadic_order, want_grad, forced, bytes);
 }
 
 int sigsvgd_gram_fwd(const void *X, const void *Y, int A, int B, int T, int d, int dtype, double inv_h,

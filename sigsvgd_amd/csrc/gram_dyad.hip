@@ -256,7 +256,7 @@ __global__ __launch_bounds__(DNW * 64) __attribute__((amdgpu_waves_per_eu(DNW ==
                     for (int k = 0; k < 64; ++k) Ssl[k] = 0.f;
                     const float hbf = topb[lv + 2];
                     asm volatile("" ::: "memory");
-                    quad_fwd_all<0, true>(fc, fuA, fuB, fV, Dsl, Ssl, wr, rows, hbf, haddr, hinc, r3, nrows + ncols);
+                    { float sd_unused = 0.f; quad_fwd_all<0, true>(fc, fuA, fuB, fV, Dsl, Ssl, wr, rows, hbf, haddr, hinc, r3, nrows + ncols, sd_unused); }
                     asm volatile("" ::: "memory");
                     if (!kdone) { // (the slots: K at the cells' upper left corners; fc: the row's last value so far)
                         kmax = d_max3_abs(kmax, fc, fc);

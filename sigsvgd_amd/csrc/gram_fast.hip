@@ -61,8 +61,8 @@ struct FastArgs {
     TileMap tm;                   // row tiles owned by this launch, in the order of the enumeration (multi-GPU sharding)
     long long nitems;             // (owned row tile, column) items of the launch
     double inv_h;
-    unsigned char *kflag;         // [A][B]: 1 where the pair's fp32 solution cancelled: besides the fp64 re-sweep in the kernel
-                                  // (fp32 increments), the launcher lets the coverage kernel solve those pairs exactly
+    unsigned char *kflag;         // [A][B] (d <= 3 only): 1 where the pair's fp32 solution cancelled or K is ill-conditioned in
+                                  // the increments: the launcher lets the coverage kernel solve those pairs exactly (fp64)
 #ifdef SIGSVGD_PHASE_STAMPS
     unsigned long long *stamps; // diagnostic build only: [8] shader-clock totals per phase, summed over waves
 #endif
@@ -222,6 +222,9 @@ __constant__ const SweepMasks32 SWEEP_MASK32 = SweepMasks32();
     "v_add_f32 %[cur], %[" UP "], %[V]\n\t" KSL
 #define SIG_FWD_KSL(DIAG, K) "v_mov_b32 %[" K "], %[" DIAG "]\n\t"
 #define SIG_FWD_NOKSL "v_max_f32 %[km], |%[cur]|, %[km]\n\t" // (forward-only launches: the largest |K| of the grid, in the hazard slot)
+// few-channel forward-only launches also sum |K[l][q] * gamma[l][q]| over the cells: the forward half of the condition
+// estimate sum |S * D| / |K| that decides whether the pair goes to the exact fp64 pass (see the kernel, "conditioning")
+#define SIG_FWD_NOKSL_SD(DIAG, G) "v_max_f32 %[km], |%[cur]|, %[km]\n\tv_fma_f32 %[sd], |%[" DIAG "]|, |%[" G "]|, %[sd]\n\t"
 #define SIG_REV_STEP(DN, DDIAG, G, K, M)                                                      \
     "s_mov_b64 exec, -1\n\t"                                                                  \
     "v_mov_b32_dpp %[" DN "], %[cur] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"               \
@@ -236,13 +239,25 @@ __constant__ const SweepMasks32 SWEEP_MASK32 = SweepMasks32();
 
 // steps sigma0 .. sigma0+7 of the forward sweep (sigma0 even): g, ksl point at slots sigma0 & 63 ..; mk at the
 // windows of sigma0 ..
-template <bool STORE>
+// MODE 0: K_fwd into the slots (gradient launches); 1: forward only, row maximum; 2: forward only, row maximum and the
+// sum of |K00 * gamma| (few-channel launches)
+template <int MODE>
 __device__ __forceinline__ void sweep_fwd8(float &cur, float &upA, float &upB, float &V, const float *g, float *ksl,
-                                           const unsigned long long *mk, const float r3, float &km)
+                                           const unsigned long long *mk, const float r3, float &km, float &sd)
 {
     float t, y;
     const unsigned long long m0 = mk[0], m1 = mk[1], m2 = mk[2], m3 = mk[3], m4 = mk[4], m5 = mk[5], m6 = mk[6], m7 = mk[7];
-    if (STORE)
+    if constexpr (MODE == 2)
+        asm volatile(SIG_FWD_STEP("upA", "upB", "g0", SIG_FWD_NOKSL_SD("upB", "g0"), "m0") SIG_FWD_STEP("upB", "upA", "g1", SIG_FWD_NOKSL_SD("upA", "g1"), "m1")
+                     SIG_FWD_STEP("upA", "upB", "g2", SIG_FWD_NOKSL_SD("upB", "g2"), "m2") SIG_FWD_STEP("upB", "upA", "g3", SIG_FWD_NOKSL_SD("upA", "g3"), "m3")
+                     SIG_FWD_STEP("upA", "upB", "g4", SIG_FWD_NOKSL_SD("upB", "g4"), "m4") SIG_FWD_STEP("upB", "upA", "g5", SIG_FWD_NOKSL_SD("upA", "g5"), "m5")
+                     SIG_FWD_STEP("upA", "upB", "g6", SIG_FWD_NOKSL_SD("upB", "g6"), "m6") SIG_FWD_STEP("upB", "upA", "g7", SIG_FWD_NOKSL_SD("upA", "g7"), "m7")
+                     "s_mov_b64 exec, -1\n\t"
+                     : [cur] "+v"(cur), [upA] "+v"(upA), [upB] "+v"(upB), [V] "+v"(V), [t] "=&v"(t), [y] "=&v"(y), [km] "+v"(km), [sd] "+v"(sd)
+                     : [g0] "v"(g[0]), [g1] "v"(g[1]), [g2] "v"(g[2]), [g3] "v"(g[3]), [g4] "v"(g[4]), [g5] "v"(g[5]),
+                       [g6] "v"(g[6]), [g7] "v"(g[7]), [r3] "s"(r3), [m0] "s"(m0), [m1] "s"(m1), [m2] "s"(m2),
+                       [m3] "s"(m3), [m4] "s"(m4), [m5] "s"(m5), [m6] "s"(m6), [m7] "s"(m7));
+    else if constexpr (MODE == 0)
         asm volatile(SIG_FWD_STEP("upA", "upB", "g0", SIG_FWD_KSL("upB", "k0"), "m0")
                      SIG_FWD_STEP("upB", "upA", "g1", SIG_FWD_KSL("upA", "k1"), "m1")
                      SIG_FWD_STEP("upA", "upB", "g2", SIG_FWD_KSL("upB", "k2"), "m2")
@@ -329,6 +344,19 @@ __device__ __forceinline__ double resweep_fwd_fp64(const float (&Dsl)[RING], int
         }
     }
     return cur;
+}
+// Sum over the lanes in DPP adds (no LDS round trip).  Lane 31 ends with the total of lanes 0 .. 31; lane 63 with the
+// total of ALL 64 lanes if `whole`, else of lanes 32 .. 63 (two pairs per wavefront).
+template <bool WHOLE>
+__device__ __forceinline__ float wave_sum_dpp(float v)
+{
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xF, 0xF, true)); // row_shr:1
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112, 0xF, 0xF, true)); // row_shr:2
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xF, 0xF, true)); // row_shr:4
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x118, 0xF, 0xF, true)); // row_shr:8 (lane 15 of a row: its total)
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, true)); // row_bcast:15 into rows 1, 3
+    if (WHOLE) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xC, 0xF, true)); // row_bcast:31 into rows 2, 3
+    return v;
 }
 __device__ __forceinline__ float max3_abs(float m, float a, float b)
 {
@@ -589,6 +617,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
 
             SIG_STAMP(1)
             SIG_PRIO(2)
+            float kf_keep = 0.f;                   // K[P][P] of this lane's pair and the cancellation verdicts of phase 2, for the
+            bool x0_keep = false, x1_keep = false; // conditioning check after the reverse sweep (4-channel gradient kernels)
             // ---- phase 2: forward sweep, anti-diagonal sigma = 0 .. 2P-2, in fp32 DIFFERENCE FORM ----------
             // With gamma = g / sqrt(12) the second-order stencil reads
             //     K11 - K01 = (K10 - K00) + F,   F = gamma * (sqrt(3) * t + gamma * (t + K00)),  t = K10 + K01,
@@ -603,7 +633,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
                 // the diagonal neighbour K[l][q] of a step is the upper neighbour of the step before, whether or
                 // not this lane was active then (a lane's value is 1.0 until its row starts and frozen after it
                 // ends), so it needs no copy.
-                float cur = 1.f, upA = 1.f, upB = 1.f, V = 0.f, km = 1.f;
+                float cur = 1.f, upA = 1.f, upB = 1.f, V = 0.f, km = 1.f, sd = 0.f;
                 const int smax = 2 * P - 2;
                 if (GRAD) {
 #pragma unroll
@@ -616,7 +646,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
                     const unsigned long long *mk = (RING == 64 ? SWEEP_MASK.m[P] : SWEEP_MASK32.m[P]) + rnd * 64; // EXEC windows
 #pragma unroll
                     for (int k0 = 0; k0 < 64; k0 += 8) // Ksl[k] <- K[l, q]
-                        sweep_fwd8<GRAD>(cur, upA, upB, V, &Dsl[k0 & RM], &Ksl[k0 & RM], mk + k0, r3, km);
+                        sweep_fwd8<GRAD ? 0 : (DPAD == 4 ? 2 : 1)>(cur, upA, upB, V, &Dsl[k0 & RM], &Ksl[k0 & RM], mk + k0, r3, km, sd);
                 }
                 // largest |K| on this lane's row against the pair's result: cancellation -> fp64 (resweep_fwd_fp64 above)
                 if (GRAD) {
@@ -629,19 +659,40 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
                     const float kf1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cur), 32 + P - 1));
                     kf = (lane >> 5) ? kf1 : kf;
                 }
-                // Paths in one or two channels (the 4-channel instantiations; the launcher passes a flag array for d <= 2 only):
+                // Paths in one to three channels (the 4-channel instantiations; the launcher passes a flag array for d <= 3 only):
                 // the fp64 re-sweep below runs on fp32 increments, which is not enough where the discrete solution is
-                // ill-conditioned (33 of 6,000 soak cases beyond 1e-5 on this kernel, 32 of them with d <= 2), so the pairs the
-                // other kernels' rule marks (gram_quad.hip: the grid maximum above 2 and above 4 max(|K|, 0.1)) are also
-                // flagged for the exact fp64 pass of the coverage kernel that follows the launch.  A pair that came out NaN (a
-                // NaN in its inputs) is not marked: the coverage kernel's clamped exponential would turn it into a number.
-                // Compiled into the 4-channel kernels only: in the 8-channel ones the ballot and the byte store cost the
-                // headline launch 1.7 % (same-box A/B), for one soak case.
+                // ill-conditioned, so such pairs are flagged for the EXACT fp64 pass of the coverage kernel that follows the
+                // launch (fp64 static kernel, increments and sweeps: 6e-8).  Two rules, either one flags the pair:
+                //   * cancellation of magnitudes (round 3): the grid maximum above 2 and above 4 max(|K|, 0.1) (1.5 / 2 in one
+                //     channel) -- the fp32 sweeps resolve ~1e-6 of the largest value on the grid;
+                //   * CONDITIONING (round 4): K[P][P] as a function of the increments has the first-order condition number
+                //     c1 = sum |S * D| / |K| (S = K_fwd * U is dK/dD up to the stencil's second-order terms), and the fp32
+                //     STORAGE of the increments (6e-8 each) costs K up to 2.7e-8 c1 whatever the precision of the sweeps
+                //     (measured over 5,000 pairs of 25 roughness regimes, scripts/dev/cond_study.py: error <= 2.7e-8 c1, every
+                //     pair beyond 3e-6 has c1 > 230; smooth paths -- the bench inputs at d <= 3 -- stay below 100 at T <= 128).
+                //     Gradient launches have S in the slots after the reverse sweep and flag c1 > 150 there (below, "conditioning");
+                //     forward-only launches have no U and use the bound  sum |K_fwd * D| * max(grid maximum, 1) / |K| > 300
+                //     (>= c1 up to 15 % in every pair of the study, within a factor 7 of it for three channels; no pair beyond
+                //     2.5e-6 stays below it).
+                // A pair that came out NaN (a NaN in its inputs) is not marked: the coverage kernel's clamped exponential would
+                // turn it into a number.  Compiled into the 4-channel kernels only: in the 8-channel ones the ballot and the byte
+                // store cost the headline launch 1.7 % (same-box A/B), and no pair of >= 4 channels needs it (worst entry 9e-7 in
+                // the roughest regimes of the study).
                 bool x0 = false, x1 = false;
                 if constexpr (DPAD == 4) {
                     if (a.kflag) {
-                        const unsigned long long xbal =
-                            __builtin_amdgcn_ballot_w64(mine && kf == kf && km > (d == 1 ? 1.5f : 2.f) && km > (d == 1 ? 2.f : 4.f) * fmaxf(fabsf(kf), 0.1f));
+                        const float kden = fmaxf(fabsf(kf), 0.1f);
+                        bool fl = km > (d == 1 ? 1.5f : 2.f) && km > (d == 1 ? 2.f : 4.f) * kden;
+                        if constexpr (!GRAD) { // sum over the pair's lanes of sum_q |K[l][q] gamma[l][q]|, times sqrt(12): in units of D
+                            const float wsum = wave_sum_dpp<RING == 64>(sd);
+                            float sds = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wsum), 63));
+                            if (RING == 32) {
+                                const float s0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wsum), 31));
+                                sds = (lane >> 5) ? sds : s0;
+                            }
+                            fl = fl || sds * 3.46410161513775459f * fmaxf(km, 1.f) > 300.f * kden;
+                        }
+                        const unsigned long long xbal = __builtin_amdgcn_ballot_w64(mine && kf == kf && fl);
                         x0 = (RING == 64) ? xbal != 0 : (unsigned)xbal != 0u;
                         x1 = (xbal >> 32) != 0;
                     }
@@ -649,10 +700,13 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
                 if (lrow == P - 1 && mine) { // this lane's last value is K[P, P]
                     store_any(a.K, (size_t)i * a.B + j, (double)cur, io64);
                     if (SYM && j != i) store_any(a.K, (size_t)j * a.B + i, (double)cur, io64);
-                    if constexpr (DPAD == 4) { // (two rows per wavefront: each half of the ballot is one pair)
+                    if constexpr (DPAD == 4 && !GRAD) { // (two rows per wavefront: each half of the ballot is one pair)
                         if (a.kflag) a.kflag[(size_t)i * a.B + j] = (RING == 32 && (lane >> 5)) ? x1 : x0;
                     }
                 }
+                kf_keep = kf;
+                x0_keep = x0;
+                x1_keep = x1;
                 if (__builtin_expect(__builtin_amdgcn_ballot_w64(mine && km > 4.f * fmaxf(fabsf(kf), 0.1f)) != 0, 0)) {
                     const double k64 = resweep_fwd_fp64<RING>(Dsl, P, lrow);
                     if (lrow == P - 1 && mine) { // (same lane, same addresses as the first store: the later one stands)
@@ -764,6 +818,25 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
                     for (int k0 = 56; k0 >= 0; k0 -= 8) sweep_rev8(cur, downA, downB, V, &Dsl[k0 & RM], &Ksl[k0 & RM], mk + k0, r3);
                 }
 
+                // ---- conditioning (4-channel kernels with a flag array, i.e. d <= 3): c1 = sum |S * D| / max(|K|, 0.1) ------
+                // The slots hold S = K_fwd * U (0 where there is no cell) and gamma = D / sqrt(12): 64 multiply-adds per lane, a
+                // wave sum, one byte per pair (see phase 2 for the rule and its measurement).  C3 (d = 3): +1.2 % instructions.
+                if constexpr (DPAD == 4) {
+                    if (a.kflag) {
+                        float cs = 0.f;
+#pragma unroll
+                        for (int k = 0; k < RING; ++k) cs = __builtin_fmaf(fabsf(Ksl[k]), fabsf(Dsl[k]), cs);
+                        const float wsum = wave_sum_dpp<RING == 64>(cs);
+                        float c1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wsum), 63));
+                        if (RING == 32) {
+                            const float c10 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wsum), 31));
+                            c1 = (lane >> 5) ? c1 : c10;
+                        }
+                        const bool ill = kf_keep == kf_keep && c1 * 3.46410161513775459f > 150.f * fmaxf(fabsf(kf_keep), 0.1f);
+                        if (lrow == P - 1 && mine)
+                            a.kflag[(size_t)i * a.B + j] = (((RING == 32 && (lane >> 5)) ? x1_keep : x0_keep) || ill) ? 1 : 0;
+                    }
+                }
                 SIG_STAMP(3)
                 SIG_PRIO(0)
                 // ---- phase 4: 4-corner scatter R and both contractions, one column per lane and iteration ----
@@ -1041,10 +1114,10 @@ FastGeom fast_geometry(int A, int B, int T, int d, bool sym)
 int sym_tile_rows_fast(int T, int d) { return grad_nw(T, d); }
 
 namespace {
-// (the flag array of the exact fp64 pass: launches with paths in one or two channels only, see the kernel)
+// (the flag array of the exact fp64 pass: launches with paths in one to three channels only, see the kernel)
 inline size_t fast_flag_bytes(int A, int B, int d)
 {
-    return d <= 2 ? (((size_t)A * B + 255) & ~(size_t)255) + generic_repair_bytes() : 0;
+    return d <= 3 ? (((size_t)A * B + 255) & ~(size_t)255) + generic_repair_bytes() : 0;
 }
 } // namespace
 
@@ -1157,7 +1230,7 @@ int run_grad(const GramProblem &p, FastArgs &a, bool sym, void *out, int out64)
         return SIGSVGD_E_WORKSPACE;
     }
     unsigned char *base = reinterpret_cast<unsigned char *>((reinterpret_cast<uintptr_t>(p.ws) + 255) & ~(uintptr_t)255);
-    a.kflag = p.d <= 2 ? base : nullptr;
+    a.kflag = p.d <= 3 ? base : nullptr;
     base += fast_flag_bytes(p.A, p.B, p.d);
     a.rseg = reinterpret_cast<double *>(base);
     a.cslab = sym ? reinterpret_cast<float *>(base + g.rseg_bytes) : nullptr;
@@ -1189,7 +1262,7 @@ int fast_launch(const GramProblem &p)
         return SIGSVGD_E_BADARG;
     }
     if (!grad) {
-        if (p.d <= 2) {
+        if (p.d <= 3) {
             if (!p.ws || p.ws_bytes < fast_flag_bytes(p.A, p.B, p.d) + 256) {
                 set_error("fast: workspace %zu B < required %zu B", p.ws_bytes, fast_flag_bytes(p.A, p.B, p.d) + 256);
                 return SIGSVGD_E_WORKSPACE;

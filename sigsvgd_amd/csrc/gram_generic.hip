@@ -46,7 +46,7 @@ struct GenericArgs {
     unsigned long long *next_item; // work counter (zeroed by the launcher): items are pulled, not assigned, because
                                    // with yx their cost varies from nothing to JC pairs
     int A, B, T, d, dp, n, r, P, Tm, TmS, nbands, nsteps, JC, nchunks, kind, naive, sym, want_grad;
-    int big; // long paths (dyadic order 0 only): S kept in fp32 (one write per entry), no LDS gradient accumulator
+    int big; // long paths (dyadic order 0 only): fp64 increments per band, S in the launch's scratch, no LDS gradient accumulator
     // fp64 pass over the pairs a fp32-sweep kernel flagged (generic_repair_launch; forward only): the pairs with
     // flags[i * B + j] != 0 among the rows of the tiles `tm` owns (tile_rows rows each), j >= i with yx
     const unsigned char *flags;
@@ -65,15 +65,22 @@ __host__ __device__ inline size_t generic_lds_bytes(int T, int d, int n, int wan
     const int dp = (d % 2 == 0) ? d + 1 : d;
     const int Tm = T - 1, TmS = Tm | 1, P = (1 << n) * Tm;
     size_t dbl = (size_t)2 * T * dp + 2 * T + (P + 2) + 64; // (+64: per-lane dump cells of the sweeps' boundary stores)
+    if (big) // long paths (dyadic order 0): fp64 increments of ONE band of 64 rows + the static-kernel row beyond it; S lives in
+        return (dbl + (size_t)kWave * TmS + T) * sizeof(double); // the launch's scratch in global memory
     size_t flt = (size_t)Tm * TmS;
-    if (want_grad && !big) dbl += (size_t)Tm * Tm + (size_t)T * dp; // S fp64 + gradient accumulator
-    if (want_grad && big) flt += (size_t)Tm * Tm;                   // S fp32 only
+    if (want_grad) dbl += (size_t)Tm * Tm + (size_t)T * dp; // S fp64 + gradient accumulator
     if (dd) dbl += (size_t)Tm * TmS, flt -= (size_t)Tm * TmS; // increments kept in fp64 (see DT below)
     return dbl * sizeof(double) + flt * sizeof(float);
 }
 
 // NAIVE / GRAD / BIG are compile-time: tested per sweep step, each of them was a taken branch on the one wave's
 // dependent chain.
+// BIG (round 4): paths too long for the whole-grid tables (dyadic order 0).  The increments are formed PER BAND of 64 rows, in
+// fp64, right before the band is swept (forwards and again backwards: the static kernel is evaluated twice), and S = K_fwd * U
+// goes to the launch's scratch in the [step][lane] order of the stored forward solution (coalesced 256-B rows, fp32: each entry
+// is written once).  Per-pair LDS: 64 (T-1) + 2 T d doubles -- T = 128, d = 16 takes 104 KB -- so this layout is fp64 end to
+// end for every shape of the quadrant kernel (T <= 128) with and without the gradient; rounds 2-3 kept the whole table in
+// fp32 there and the exact pass inherited 3e-5 from its rounding (soak case: T = 100, d = 2, gradient, forced coverage kernel).
 // DT: storage type of the increment table.  float (rounds 1-2): 6e-8 per increment, invisible while K grows along the
 // grid -- but where the discrete solution oscillates (rough paths in one or two channels) K[P][P] is
 // a small remainder of much larger values and inherits ~3e-7 .. 3e-6 (T = 64 .. 128) of their ratio to it from the rounded
@@ -97,14 +104,50 @@ __global__ __launch_bounds__(64) void gram_generic_kernel(GenericArgs a)
     double *dump = rowbuf + (P + 2); // [64]: where the lanes that have nothing to hand over store
     double *Sm = dump + kWave;
     double *acc = Sm + ((GRAD && !big) ? (size_t)Tm * Tm : 0);
-    DT *Dm = reinterpret_cast<DT *>(acc + ((GRAD && !big) ? (size_t)T * dp : 0));
-    float *Sm32 = reinterpret_cast<float *>(Dm + (size_t)Tm * TmS); // big mode: S in fp32 (dyadic order 0: each entry written once)
+    DT *Dm = reinterpret_cast<DT *>(acc + ((GRAD && !big) ? (size_t)T * dp : 0)); // big: rows of the band in work only
+    double *gnext = reinterpret_cast<double *>(Dm + (size_t)kWave * TmS);         // big: static-kernel row beyond the band [T]
 
     const IO *X = static_cast<const IO *>(a.X);
     const IO *Y = static_cast<const IO *>(a.Y);
     const IO *GO = static_cast<const IO *>(a.grad_out);
     IO *Kout = static_cast<IO *>(a.K_out);
     float *wsk = a.wsk + (size_t)blockIdx.x * a.wsk_per_block;
+    float *wss = wsk + (size_t)a.nbands * a.nsteps * kWave; // big: S in the order of the stored forward solution
+    // S[aa][bb] of the pair in work (big mode: row aa = band aa / 64, lane aa % 64, filed under step lane + bb)
+    auto Sat = [&](int aa, int bb) -> double {
+        if (big) return (double)wss[((size_t)(aa >> 6) * a.nsteps + (aa & 63) + bb) * kWave + (aa & 63)];
+        return Sm[aa * Tm + bb];
+    };
+    // big: increments of the cell rows a0 .. a0 + nrows - 1 (one band), fp64, from static-kernel rows a0 .. a0 + nrows
+    auto band_increments = [&](int a0, int nrows) {
+        __syncthreads();
+        for (int q = lane; q < T; q += kWave) { // the row beyond the band, one column per lane
+            double dot = 0.0;
+            const int pr = a0 + nrows; // <= T - 1
+            for (int c = 0; c < d; ++c) dot = __builtin_fma(xs[pr * dp + c], ys[q * dp + c], dot);
+            gnext[q] = rbf ? exp64((2.0 * dot - xn[pr] - yn[q]) * a.inv_h) : dot;
+        }
+        __syncthreads();
+        const int p = a0 + lane;
+        const bool valid = lane < nrows;
+        double g_prev = 0.0, gn_prev = 0.0;
+        for (int q = 0; q < T; ++q) {
+            double gq = 0.0;
+            if (valid) {
+                double dot = 0.0;
+                for (int c = 0; c < d; ++c) dot = __builtin_fma(xs[p * dp + c], ys[q * dp + c], dot);
+                gq = rbf ? exp64((2.0 * dot - xn[p] - yn[q]) * a.inv_h) : dot;
+            }
+            const double rd = gq - g_prev;
+            g_prev = gq;
+            const double gn = gnext[q];
+            double rdn = shfl_down_f64(rd);
+            rdn = (lane == nrows - 1) ? gn - gn_prev : rdn;
+            gn_prev = gn;
+            if (q >= 1 && valid) Dm[lane * TmS + (q - 1)] = (DT)(rdn - rd);
+        }
+        __syncthreads();
+    };
 
 #ifdef SIGSVGD_PHASE_STAMPS
     unsigned long long gph_[6] = {0, 0, 0, 0, 0, 0}, gtl_ = __builtin_amdgcn_s_memtime();
@@ -186,7 +229,7 @@ __global__ __launch_bounds__(64) void gram_generic_kernel(GenericArgs a)
 
             SIG_GSTAMP(0)
             // ---- phase 1: static kernel rows -> increments D (fp64 arithmetic, stored as DT) ----
-            for (int rb = 0; rb < Tm; rb += kWave - 1) {
+            for (int rb = 0; rb < (big ? 0 : Tm); rb += kWave - 1) { // (big: per band, below)
                 const int p = rb + lane;
                 const bool valid = p < T;
                 double g_prev = 0.0;
@@ -216,7 +259,8 @@ __global__ __launch_bounds__(64) void gram_generic_kernel(GenericArgs a)
                 const int p = kb * kWave + lane;
                 const bool rowvalid = p < P;
                 const bool first = kb == 0;
-                const DT *Drow = Dm + (size_t)(min(p, P - 1) >> n) * TmS;
+                if (big) band_increments(kb * kWave, min(kWave, P - kb * kWave));
+                const DT *Drow = Dm + (size_t)(big ? min(lane, P - 1 - kb * kWave) : (min(p, P - 1) >> n)) * TmS;
                 float *wp = wsk + (size_t)kb * a.nsteps * kWave + lane;
                 double cur = 1.0, upprev = 1.0;
                 int q = -lane;
@@ -262,7 +306,9 @@ __global__ __launch_bounds__(64) void gram_generic_kernel(GenericArgs a)
                 const bool rowvalid = p < P;
                 const int L = min(kWave, P - kb * kWave);
                 const int arow = min(p, P - 1) >> n;
-                const DT *Drow = Dm + (size_t)arow * TmS;
+                if (big && kb != a.nbands - 1) band_increments(kb * kWave, L); // (last band: the forward sweep's table is still there)
+                const DT *Drow = Dm + (size_t)(big ? min(lane, L - 1) : arow) * TmS;
+                float *wsrow = wss + (size_t)kb * a.nsteps * kWave + lane;
                 const bool lastband = kb == a.nbands - 1;
                 const bool hands_over = lane == 0 && kb > 0;
                 double cur = 1.0, dprev = 1.0, sb = 0.0;
@@ -293,8 +339,10 @@ __global__ __launch_bounds__(64) void gram_generic_kernel(GenericArgs a)
                         double down_in = shfl_down_f64(cur);
                         down_in = (lane == L - 1) ? rb : down_in;
                         const double g = (double)gf * a.inv_r2;
-                        if (big) {
-                            if (active) Sm32[arow * Tm + q] = (float)(kf * dprev); // r == 1: the block is this cell
+                        if (big) { // r == 1: the block is this cell; filed where K_fwd[p][q] is (row R of the band, this lane)
+                            const float sst = active ? (float)(kf * dprev) : 0.f;
+                            // (the padding steps past the last anti-diagonal, R < 0, go to a spare row behind the table)
+                            asm volatile("global_store_dword %0, %1, off" ::"v"(R >= 0 ? wsrow + (size_t)R * kWave : wss + (size_t)a.nbands * a.nsteps * kWave + lane), "v"(sst));
                         } else {
                             sb = active ? __builtin_fma(kf, dprev, sb) : sb;
                             if (active && (q & (r - 1)) == 0) {
@@ -311,6 +359,7 @@ __global__ __launch_bounds__(64) void gram_generic_kernel(GenericArgs a)
                     }
                 }
             }
+            if (big) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // S is in L2 before the assembly reads it
             __syncthreads();
 
             SIG_GSTAMP(3)
@@ -338,7 +387,6 @@ __global__ __launch_bounds__(64) void gram_generic_kernel(GenericArgs a)
                     double s0 = 0.0;
                     for (int nn = nn0; nn < nn1; ++nn) {
                         double R = 0.0;
-                        auto Sat = [&](int aa, int bb) { return big ? (double)Sm32[aa * Tm + bb] : Sm[aa * Tm + bb]; };
                         if (m >= 1 && nn >= 1) R += Sat(m - 1, nn - 1);
                         if (m < Tm && nn < Tm) R += Sat(m, nn);
                         if (m >= 1 && nn < Tm) R -= Sat(m - 1, nn);
@@ -384,7 +432,6 @@ __global__ __launch_bounds__(64) void gram_generic_kernel(GenericArgs a)
                 } else if (a.sym) {
                     wc = 2.0;
                 }
-                auto Sat = [&](int aa, int bb) { return big ? (double)Sm32[aa * Tm + bb] : Sm[aa * Tm + bb]; };
                 for (int nn = lane; nn < T; nn += kWave) {
                     for (int c0 = 0; c0 < d; c0 += 16) {
                         double accv[16];
@@ -485,22 +532,22 @@ int make_plan(int A, int B, int T, int d, int n, int want_grad, GenericPlan &pl,
     pl.nbands = (pl.P + kWave - 1) / kWave;
     pl.nsteps = pl.P + kWave - 1;
     pl.big = 0;
+    pl.dd = 0;
     pl.lds = generic_lds_bytes(T, d, n, want_grad, 0);
-    if (pl.lds > 160 * 1024 && want_grad && n == 0) { // long paths: compact layout (S fp32, no LDS accumulator)
+    // increments in fp64: `precise` (force_generic, the fp64 pass over flagged pairs) whenever the whole-grid table fits 160 KB;
+    // otherwise only where it costs no occupancy (<= 20 KB per pair: every shape of the reference's own calls)
+    const size_t l2 = generic_lds_bytes(T, d, n, want_grad, 0, 1);
+    if (l2 <= (precise ? (size_t)160 * 1024 : (size_t)20 * 1024)) {
+        pl.dd = 1;
+        pl.lds = l2;
+    } else if (n == 0 && (precise || pl.lds > 160 * 1024)) { // long paths: per-band fp64 increments (fp64 end to end)
         pl.big = 1;
+        pl.dd = 1;
         pl.lds = generic_lds_bytes(T, d, n, want_grad, 1);
     }
     if (pl.lds > 160 * 1024) {
         set_error("generic: per-pair state needs %zu B of LDS (> 160 KiB): T=%d d=%d n=%d", pl.lds, T, d, n);
         return SIGSVGD_E_UNSUPPORTED;
-    }
-    pl.dd = 0;
-    if (!pl.big) {
-        const size_t l2 = generic_lds_bytes(T, d, n, want_grad, 0, 1);
-        if (l2 <= (precise ? (size_t)160 * 1024 : (size_t)20 * 1024)) {
-            pl.dd = 1;
-            pl.lds = l2;
-        }
     }
     // j-chunk: enough work items to fill the chip, few enough partial slabs
     int JC = 32;
@@ -514,7 +561,8 @@ int make_plan(int A, int B, int T, int d, int n, int want_grad, GenericPlan &pl,
     pl.grid = grid;
     pl.partial_bytes = want_grad ? (size_t)A * pl.nchunks * T * d * sizeof(double) : 0;
     pl.col_bytes = (want_grad && yx) ? (((size_t)A * B * T * d * sizeof(double) + 255) & ~(size_t)255) : 0; // symmetric solve only
-    pl.wsk_per_block = want_grad ? (size_t)pl.nbands * pl.nsteps * kWave : 0;
+    // forward solution in [band][step][lane] order; long paths: S behind it in the same order + one spare row
+    pl.wsk_per_block = want_grad ? (size_t)pl.nbands * pl.nsteps * kWave * (pl.big ? 2 : 1) + (pl.big ? kWave : 0) : 0;
     pl.wsk_bytes = pl.wsk_per_block * sizeof(float) * grid;
     return SIGSVGD_OK;
 }
@@ -524,16 +572,16 @@ namespace {
 inline size_t plan_bytes(const GenericPlan &pl) { return 512 + pl.partial_bytes + pl.col_bytes + pl.wsk_bytes; }
 }
 
-int generic_workspace_bytes(int A, int B, int T, int d, int n, int want_grad, size_t *bytes)
+int generic_workspace_bytes(int A, int B, int T, int d, int n, int want_grad, bool precise, size_t *bytes)
 {
-    // the query carries no flags: size for whichever of the ordered / symmetric plans needs more (the symmetric
+    // the query carries no Y_IS_X promise: size for whichever of the ordered / symmetric plans needs more (the symmetric
     // one uses shorter column chunks, i.e. more partial slabs)
     GenericPlan pl;
-    int rc = make_plan(A, B, T, d, n, want_grad, pl, false);
+    int rc = make_plan(A, B, T, d, n, want_grad, pl, false, precise);
     if (rc) return rc;
     *bytes = plan_bytes(pl);
     if (generic_solves_unordered(A, B, T, d, want_grad, SIGSVGD_FLAG_Y_IS_X)) {
-        rc = make_plan(A, B, T, d, n, want_grad, pl, true);
+        rc = make_plan(A, B, T, d, n, want_grad, pl, true, precise);
         if (rc) return rc;
         if (plan_bytes(pl) > *bytes) *bytes = plan_bytes(pl);
     }
@@ -559,11 +607,10 @@ hipError_t generic_launch_one(const GenericPlan &pl, hipStream_t stream, const G
 template <typename IO, bool NAIVE, typename DT>
 hipError_t generic_dispatch2(bool grad, bool big, const GenericPlan &pl, hipStream_t stream, const GenericArgs &a)
 {
-    if (!grad) return generic_launch_one<IO, NAIVE, false, false, DT>(pl, stream, a);
-    if constexpr (sizeof(DT) == 8) // (the compact long-path layout keeps fp32 increments: make_plan)
-        return generic_launch_one<IO, NAIVE, true, false, DT>(pl, stream, a);
-    else
-        return big ? generic_launch_one<IO, NAIVE, true, true, DT>(pl, stream, a) : generic_launch_one<IO, NAIVE, true, false, DT>(pl, stream, a);
+    if constexpr (sizeof(DT) == 8) { // (the long-path layout is fp64 only: make_plan)
+        if (big) return grad ? generic_launch_one<IO, NAIVE, true, true, DT>(pl, stream, a) : generic_launch_one<IO, NAIVE, false, true, DT>(pl, stream, a);
+    }
+    return grad ? generic_launch_one<IO, NAIVE, true, false, DT>(pl, stream, a) : generic_launch_one<IO, NAIVE, false, false, DT>(pl, stream, a);
 }
 template <typename IO>
 hipError_t generic_dispatch1(bool naive, bool grad, bool big, const GenericPlan &pl, hipStream_t stream, const GenericArgs &a)
@@ -687,13 +734,13 @@ int generic_repair_launch(const GramProblem &p, const unsigned char *flags, void
     a.inv_r2 = 1.0 / ((double)pl.r * (double)pl.r);
     // one item per row: its B flags are scanned 64 per load, and a row without a flag costs one pass over them
     a.JC = p.B; a.nchunks = 1;
-    a.total_items = p.A; a.wsk_per_block = 0; a.big = 0;
+    a.total_items = p.A; a.wsk_per_block = 0; a.big = pl.big;
     if ((long long)pl.grid > a.total_items) pl.grid = (int)a.total_items;
     a.flags = flags; a.tm = tm; a.tile_rows = tile_rows;
 #ifdef SIGSVGD_PHASE_STAMPS
     a.stamps = nullptr;
 #endif
-    hipError_t e = generic_dispatch(p.dtype == SIGSVGD_F64, false, false, false, pl, p.stream, a);
+    hipError_t e = generic_dispatch(p.dtype == SIGSVGD_F64, false, false, pl.big != 0, pl, p.stream, a);
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(generic, fp64 pass)");
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "launch gram_generic_kernel (fp64 pass)");

@@ -218,7 +218,10 @@ __device__ __forceinline__ double qexp2_p7(double t, const QExp7 &k)
 // accumulator instead (a separate instantiation: its code costs the common one 40 spilled registers)
 // EARLY: paths of <= 112 points (second band / half of <= 47 cells): the sweeps skip the steps beyond a quadrant's last
 // anti-diagonal (T=100, d=7: 2.51 -> 2.40 ms symmetric); longer paths keep the unconditional 128-step statements
-template <int DPAD, bool GRAD, bool SYM, bool ROWG = false, bool EARLY = false>
+// FEW (forward-only launches of paths in <= 3 channels): the forward steps also accumulate sum |K_fwd * D|, the bound on the
+// condition number that sends ill-conditioned pairs to the exact fp64 pass (gram_fast.hip, "conditioning"; gradient launches
+// take the condition number itself from the S slots after each reverse sweep, a uniform branch on d)
+template <int DPAD, bool GRAD, bool SYM, bool ROWG = false, bool EARLY = false, bool FEW = false>
 __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void gram_quad_kernel(QuadArgs a)
 {
     constexpr int NT = QNW * 64;
@@ -439,6 +442,9 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
             int rev_band = -1;
             bool kdone = false;
             float kmax = 1.f; // largest |K| this lane has seen on the pair's grid (boundary: 1)
+            float cnd = 0.f;  // this lane's share of sum |S * gamma| (gradient launches, d <= 3) / sum |K_fwd * gamma| (FEW)
+            float kfin_keep = 0.f;
+            bool canc_keep = false;
 
             // visit list, 8 bits per visit: band | half << 1 | reverse << 2 | leave K[64][.] << 3 | increments << 4 (0 compute,
             // 1 compute and keep in the launch's scratch, 2 take from there) | scratch slot << 6
@@ -605,7 +611,7 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                     // in LATER visits only, so one compiler barrier around the sweep is enough.
                     const float hbf = topb[lv + 2]; // lane l: the value lane 0 takes after step l
                     asm volatile("" ::: "memory");
-                    quad_fwd_all<0, EARLY>(fc, fuA, fuB, fV, Dsl, Ssl, wr, rows, hbf, haddr, hinc, r3, nrows + ncols);
+                    quad_fwd_all<0, EARLY, FEW ? 1 : 0>(fc, fuA, fuB, fV, Dsl, Ssl, wr, rows, hbf, haddr, hinc, r3, nrows + ncols, cnd);
                     asm volatile("" ::: "memory");
                     if (!kdone) { // (the slots: K at the cells' upper left corners; fc: the row's last value so far)
                         kmax = q_max3_abs(kmax, fc, fc);
@@ -629,12 +635,20 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                     kdone = true;
                     // a pair whose solution cancelled (see gram_fast.hip, resweep_fwd_fp64) is marked for the fp64 pass
                     const float kfin = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fc), nrows - 1));
-                    const bool cancelled = __builtin_amdgcn_ballot_w64(kfin == kfin && kmax > (d == 1 ? 1.5f : 2.f) && kmax > (d == 1 ? 2.f : d == 2 ? 4.f : QUAD_CANCEL_RATIO) * fmaxf(fabsf(kfin), 0.1f)) != 0;
+                    const float kden = fmaxf(fabsf(kfin), 0.1f);
+                    bool fl = kmax > (d == 1 ? 1.5f : 2.f) && kmax > (d == 1 ? 2.f : d == 2 ? 4.f : QUAD_CANCEL_RATIO) * kden;
+                    if constexpr (FEW) { // conditioning bound of a forward-only launch: sum |K_fwd D| max(grid maximum, 1) > 300 max(|K|, 0.1)
+                        const float sds = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q_wave_sum63(cnd)), 63));
+                        fl = fl || sds * 3.46410161513775459f * fmaxf(kmax, 1.f) > 300.f * kden;
+                    }
+                    const bool cancelled = __builtin_amdgcn_ballot_w64(kfin == kfin && fl) != 0;
                     if (lanep == nrows - 1) {
                         q_stany(a.K, (size_t)i * a.B + j, (double)fc, io64);
                         if (SYM && j != i) q_stany(a.K, (size_t)j * a.B + i, (double)fc, io64);
-                        if (a.kflag) a.kflag[(size_t)i * a.B + j] = cancelled ? 1 : 0;
+                        if (!GRAD && a.kflag) a.kflag[(size_t)i * a.B + j] = cancelled ? 1 : 0; // (gradient launches: after the last reverse sweep)
                     }
+                    kfin_keep = kfin;
+                    canc_keep = cancelled;
                 }
                 if (!GRAD || !rev) continue;
 
@@ -668,6 +682,13 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                     asm volatile("" ::: "memory");
                     quad_rev_all<124, EARLY>(rc, rdA, rdB, rV, Dsl, Ssl, wr, rows, hbr, bmr, haddr, hinc, r3, nrows + ncols);
                     asm volatile("" ::: "memory");
+                }
+                // conditioning, paths in <= 3 channels: this quadrant's share of sum |S * gamma| (slots without a cell hold S = 0)
+                if (DPAD == 8 && d <= 3) {
+                    float cs = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 64; ++k) cs = __builtin_fmaf(fabsf(Ssl[k]), fabsf(Dsl[k]), cs);
+                    cnd += cs;
                 }
                 SIG_QSTAMP(3)
                 // ---- seam rows for the hand-over pass: S[63][.] (band 0, lane 63), S[64][.] (band 1, lane 0) ------
@@ -806,6 +827,16 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
             } // quadrant visits
 
             SIG_QSTAMP(0)
+            if (GRAD && a.kflag) {
+                // the pair's verdict for the exact fp64 pass: cancellation of magnitudes (forward sweep) or, in <= 3 channels,
+                // the condition number c1 = sum |S D| / max(|K|, 0.1) > 150 (gram_fast.hip, "conditioning")
+                bool ill = false;
+                if (DPAD == 8 && d <= 3) {
+                    const float c1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q_wave_sum63(cnd)), 63));
+                    ill = kfin_keep == kfin_keep && c1 * 3.46410161513775459f > 150.f * fmaxf(fabsf(kfin_keep), 0.1f);
+                }
+                if (lanep == 0) a.kflag[(size_t)i * a.B + j] = (canc_keep || ill) ? 1 : 0;
+            }
             if (GRAD) {
                 // ---- seam: point row 64.  R[64][n] = (S[63][n-1] - S[63][n]) - (S[64][n-1] - S[64][n]), formed from both
                 // bands' rows before the contraction; lanes take columns n = lane and lane + 64.
@@ -1002,6 +1033,8 @@ int quad_launch_variant(const GramProblem &p, QuadArgs &a, bool grad, bool sym)
     const bool rowg = HAS_ROWG && grad && p.d > 14;
     const bool early = p.T <= 112;
 #define SIGQ_LAUNCH(G, S, R, E) hipLaunchKernelGGL((gram_quad_kernel<DPAD, G, S, R, E>), grid, block, 0, p.stream, a)
+#define SIGQ_LAUNCH_FEW(S, E) hipLaunchKernelGGL((gram_quad_kernel<8, false, S, false, E, true>), grid, block, 0, p.stream, a)
+    const bool few = DPAD == 8 && !grad && p.d <= 3;
     if (grad && sym && rowg)
         SIGQ_LAUNCH(true, true, HAS_ROWG, false);
     else if (grad && rowg)
@@ -1010,11 +1043,16 @@ int quad_launch_variant(const GramProblem &p, QuadArgs &a, bool grad, bool sym)
         { if (early) SIGQ_LAUNCH(true, true, false, true); else SIGQ_LAUNCH(true, true, false, false); }
     else if (grad)
         { if (early) SIGQ_LAUNCH(true, false, false, true); else SIGQ_LAUNCH(true, false, false, false); }
+    else if (few && sym)
+        { if (early) SIGQ_LAUNCH_FEW(true, true); else SIGQ_LAUNCH_FEW(true, false); }
+    else if (few)
+        { if (early) SIGQ_LAUNCH_FEW(false, true); else SIGQ_LAUNCH_FEW(false, false); }
     else if (sym)
         { if (early) SIGQ_LAUNCH(false, true, false, true); else SIGQ_LAUNCH(false, true, false, false); }
     else
         { if (early) SIGQ_LAUNCH(false, false, false, true); else SIGQ_LAUNCH(false, false, false, false); }
 #undef SIGQ_LAUNCH
+#undef SIGQ_LAUNCH_FEW
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "launch gram_quad_kernel");
 #ifdef SIGSVGD_PHASE_STAMPS

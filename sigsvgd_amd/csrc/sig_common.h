@@ -169,7 +169,7 @@ struct GramProblem {
 };
 
 // generic (any T, n, d that fits LDS) -- gram_generic.hip
-int generic_workspace_bytes(int A, int B, int T, int d, int n, int want_grad, size_t *bytes);
+int generic_workspace_bytes(int A, int B, int T, int d, int n, int want_grad, bool precise, size_t *bytes); // precise: FORCE_GENERIC
 int generic_launch(const GramProblem &p);
 
 // fixed-order reduction of the gradient partial sums shared by the register-resident and the quadrant kernel -- gram_fast.hip

@@ -100,7 +100,7 @@ def gram_fwd(X, Y, inv_h: float, dyadic_order: int = 0, static_kind: int = _lib.
     B = Yc.shape[0]
     flags = _flags(naive, False, bool(y_is_x) and A == B, force_generic, stored_forward)
     nbytes = ctypes.c_size_t(0)
-    _lib.check(L.sigsvgd_gram_workspace_bytes(A, B, T, d, dyadic_order, 0, flags, ctypes.byref(nbytes)),
+    _lib.check(L.sigsvgd_gram_workspace_bytes(A, B, T, d, dyadic_order, int(static_kind), 0, flags, ctypes.byref(nbytes)),
                "gram_workspace_bytes")
     ws, wsn = _workspace(dev, nbytes.value)
     K = torch.empty((A, B), dtype=Xc.dtype, device=dev)
@@ -136,7 +136,7 @@ def gram_fwd_bwd(X, Y, inv_h: float, dyadic_order: int = 0, static_kind: int = _
         go = grad_out.detach().to(Xc.dtype).contiguous()
     flags = _flags(naive, sym, y_is_x, force_generic, stored_forward)
     nbytes = ctypes.c_size_t(0)
-    _lib.check(L.sigsvgd_gram_workspace_bytes(A, B, T, d, dyadic_order, 1, flags, ctypes.byref(nbytes)),
+    _lib.check(L.sigsvgd_gram_workspace_bytes(A, B, T, d, dyadic_order, int(static_kind), 1, flags, ctypes.byref(nbytes)),
                "gram_workspace_bytes")
     ws, wsn = _workspace(dev, nbytes.value)
     K = torch.empty((A, B), dtype=Xc.dtype, device=dev)
@@ -279,7 +279,7 @@ def gram_sym_partial(X, inv_h: float, tile_offset: int, tile_stride: int, static
         gp = torch.empty((N, T, d), dtype=torch.float64, device=dev)  # fully overwritten by the library
     flags = _flags(False, sym, True, False) | (_lib.FLAG_FOLD_TILES if fold else 0)
     nbytes = ctypes.c_size_t(0)
-    _lib.check(L.sigsvgd_gram_workspace_bytes(N, N, T, d, 0, 1, flags, ctypes.byref(nbytes)), "gram_workspace_bytes")
+    _lib.check(L.sigsvgd_gram_workspace_bytes(N, N, T, d, 0, int(static_kind), 1, flags, ctypes.byref(nbytes)), "gram_workspace_bytes")
     ws, wsn = _workspace(dev, nbytes.value)
     with torch.cuda.device(dev):
         rc = L.sigsvgd_gram_sym_partial(Xc.data_ptr(), N, T, d, _io_dtype(Xc), float(inv_h), int(static_kind),

@@ -49,21 +49,30 @@ def test_workspace_query_is_host_only(lib):
     n = ctypes.c_size_t(123)
     # register-resident path (n=0, T<=64), sized for the symmetric launch: one fp32 row of T*d per (8-row tile, column) item
     # of the upper triangle + one fp64 block of 8*T*d per (workgroup, tile) segment (at most tiles + workgroups of them)
-    assert lib.sigsvgd_gram_workspace_bytes(1024, 1024, 64, 7, 0, 1, 0, ctypes.byref(n)) == 0
+    assert lib.sigsvgd_gram_workspace_bytes(1024, 1024, 64, 7, 0, 0, 1, 0, ctypes.byref(n)) == 0
     items = sum(1024 - 8 * k for k in range(128))
     lo = items * 448 * 4 + 128 * 8 * 448 * 8
     assert lo <= n.value <= lo + 1024 * 8 * 448 * 8 + 8192  # (the workgroup count depends on the device: <= 1024 here)
     # forward only: nothing is accumulated
-    assert lib.sigsvgd_gram_workspace_bytes(1024, 1024, 64, 7, 0, 0, 0, ctypes.byref(n)) == 0 and 0 < n.value <= 4096
-    # paths in one or two channels: one byte per pair more, the flags of the pairs the coverage kernel solves again in fp64
-    assert lib.sigsvgd_gram_workspace_bytes(1024, 1024, 64, 2, 0, 0, 0, ctypes.byref(n)) == 0
-    assert 1024 * 1024 <= n.value <= 1024 * 1024 + 4096
+    assert lib.sigsvgd_gram_workspace_bytes(1024, 1024, 64, 7, 0, 0, 0, 0, ctypes.byref(n)) == 0 and 0 < n.value <= 4096
+    # paths in one to three channels: one byte per pair more, the flags of the pairs the coverage kernel solves again in fp64
+    for d in (1, 2, 3):
+        assert lib.sigsvgd_gram_workspace_bytes(1024, 1024, 64, d, 0, 0, 0, 0, ctypes.byref(n)) == 0
+        assert 1024 * 1024 <= n.value <= 1024 * 1024 + 4096
+    # the static kernel decides the solver (ABI 9): the linear kernel runs every shape on the coverage kernel, whose scratch
+    # is sized differently (ABI 8 sized a refined 9 x 7 launch at 70,912 B for a kernel that needs 5.8 MB)
+    m = ctypes.c_size_t(0)
+    assert lib.sigsvgd_gram_workspace_bytes(9, 7, 30, 3, 2, 0, 1, 0, ctypes.byref(n)) == 0
+    assert lib.sigsvgd_gram_workspace_bytes(9, 7, 30, 3, 2, 1, 1, 0, ctypes.byref(m)) == 0
+    assert lib.sigsvgd_gram_workspace_bytes(9, 7, 30, 3, 2, 0, 1, 8, ctypes.byref(n)) == 0  # (forced coverage kernel, RBF)
+    assert m.value >= 1 << 20 and m.value == n.value
+    assert lib.sigsvgd_gram_workspace_bytes(9, 7, 30, 3, 2, 5, 1, 0, ctypes.byref(m)) == -1  # unknown static kernel
     # generic path (dyadic refinement): partial slabs + per-workgroup forward-solution scratch
-    assert lib.sigsvgd_gram_workspace_bytes(16, 16, 20, 2, 2, 1, 0, ctypes.byref(n)) == 0 and n.value > 0
+    assert lib.sigsvgd_gram_workspace_bytes(16, 16, 20, 2, 2, 0, 1, 0, ctypes.byref(n)) == 0 and n.value > 0
     # does not fit in LDS -> UNSUPPORTED with a message
-    assert lib.sigsvgd_gram_workspace_bytes(4, 4, 400, 3, 0, 1, 0, ctypes.byref(n)) == -2
+    assert lib.sigsvgd_gram_workspace_bytes(4, 4, 400, 3, 0, 0, 1, 0, ctypes.byref(n)) == -2
     assert b"LDS" in lib.sigsvgd_last_error()
-    assert lib.sigsvgd_gram_workspace_bytes(4, 4, 10, 3, 0, 1, 0, None) == -1
+    assert lib.sigsvgd_gram_workspace_bytes(4, 4, 10, 3, 0, 0, 1, 0, None) == -1
 
 
 def test_workspace_query_covers_every_pair_kernel(lib):
@@ -76,13 +85,13 @@ def test_workspace_query_covers_every_pair_kernel(lib):
         flags = 1 if name.endswith("naive") else 0
         for want_grad in (0, 1):
             for A, B in ((37, 37), (5, 9)):
-                assert lib.sigsvgd_gram_workspace_bytes(A, B, T, d, order, want_grad, flags, ctypes.byref(n)) == 0, name
+                assert lib.sigsvgd_gram_workspace_bytes(A, B, T, d, order, 0, want_grad, flags, ctypes.byref(n)) == 0, name
                 assert n.value > 0, name
                 if not name.startswith("coverage") and not name.startswith("fast"):
                     assert n.value >= A * B
     # the same shapes forced onto the coverage kernel
     for name, (T, d, order) in shapes.items():
-        assert lib.sigsvgd_gram_workspace_bytes(9, 9, T, d, order, 1, 8, ctypes.byref(n)) == 0 and n.value > 0, name
+        assert lib.sigsvgd_gram_workspace_bytes(9, 9, T, d, order, 0, 1, 8, ctypes.byref(n)) == 0 and n.value > 0, name
 
 
 def test_argument_errors_are_status_codes(lib):
