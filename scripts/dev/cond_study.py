@@ -46,8 +46,7 @@ def soak_cases(wanted, seed=7):
         Y = X if A == B and rng.random() < 0.5 else np.cumsum(scale * rng.standard_normal((B, T, d)), axis=1).astype(np.float32)
         yx = Y is X
         rng.uniform(0.5, 1.5, (A, B))
-        if T <= 100 and rng.random() < 0.3:
-            pass
+        rng.random()  # (the forced-coverage-kernel draw)
         if yx and n == 0 and 3 <= T <= 128 and rng.random() < 0.5:
             rng.integers(1, 6)
             rng.random()

@@ -30,7 +30,7 @@ struct BandArgs {
     float *cslab; // [items][T*d] (symmetric launches)
     float *wsk;   // [gridDim.x][8 waves][bands][steps][64]: forward solution of the pair in work (gradient launches)
     size_t wsk_per_wave;
-    unsigned char *kflag; // [A][B]: 1 where the fp32 solution of the pair cancelled (max |K_grid| > max(2, r max(|K|, 0.1)) with r = 4 (d <= 2) or 8, as in
+    unsigned char *kflag; // [A][B]: 1 where the fp32 solution of the pair cancelled (max |K_grid| > r max(|K|, 0.1), r = 2 / 4 / 8) or is ill-conditioned (d <= 3), as in
                           // gram_quad.hip): the launcher lets the coverage kernel solve those pairs' K again in fp64
     int io64, A, B, T, d, n, symw;
     TileMap tm;
@@ -215,6 +215,8 @@ __global__ __launch_bounds__(BNW * 64) __attribute__((amdgpu_waves_per_eu(BNW ==
             // ---- forward sweep, band by band -------------------------------------------------------------------------
             double kfin = 1.0;
             float kmax = 1.f; // largest |K| this lane has seen on the pair's grid
+            float kfin_keep = 0.f;
+            bool canc_keep = false;
 #pragma unroll 1
             for (int kb = 0; kb < nb; ++kb) {
                 const int p = 64 * kb + lanep;
@@ -279,12 +281,17 @@ __global__ __launch_bounds__(BNW * 64) __attribute__((amdgpu_waves_per_eu(BNW ==
             }
             {
                 const float kfv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int((float)kfin), (P - 1) & 63));
-                const bool cancelled = __builtin_amdgcn_ballot_w64(kfv == kfv && kmax > (d == 1 ? 1.5f : 2.f) && kmax > (d == 1 ? 2.f : d == 2 ? 4.f : 8.f) * fmaxf(fabsf(kfv), 0.1f)) != 0;
+                // (round 4: no floor "grid maximum > 2" any more -- on a refined grid the full-magnitude add drifts by up to 6e-8 per
+                //  row of the largest value, the boundary value 1 included, so a pair that merely decays to K = 0.15 is as exposed as
+                //  one that oscillates (gram_dyad.hip, soak case 504); without the two-float add the ratio is at most 4)
+                const bool cancelled = __builtin_amdgcn_ballot_w64(kfv == kfv && kmax > (d == 1 ? 2.f : (d == 2 || !COMP) ? 4.f : 8.f) * fmaxf(fabsf(kfv), 0.1f)) != 0;
                 if (lanep == ((P - 1) & 63)) {
                     b_stany(a.K, (size_t)i * a.B + j, kfin, io64);
                     if (SYM && j != i) b_stany(a.K, (size_t)j * a.B + i, kfin, io64);
-                    a.kflag[(size_t)i * a.B + j] = cancelled ? 1 : 0;
+                    if (!GRAD) a.kflag[(size_t)i * a.B + j] = cancelled ? 1 : 0; // (gradient launches: with the condition number, below)
                 }
+                kfin_keep = kfv;
+                canc_keep = cancelled;
             }
 
             if (GRAD) {
@@ -355,6 +362,19 @@ __global__ __launch_bounds__(BNW * 64) __attribute__((amdgpu_waves_per_eu(BNW ==
                     __builtin_amdgcn_s_waitcnt(0xc07f);
                 }
 
+                // the pair's verdict for the exact fp64 pass: the grid maximum (above) or, in <= 3 channels, the condition number of
+                // K in the stored coarse increments, c1 = sqrt(12) sum |Sc * Dc| / max(|K|, 0.1) > 150 (gram_dyad.hip, gram_fast.hip)
+                {
+                    bool ill = false;
+                    if (d <= 3) {
+                        float cs = 0.f;
+                        for (int e = lanep; e < Tm * Tm; e += 64) cs = __builtin_fmaf(fabsf((float)wl.Sc[e]), fabsf(wl.Dc[e]), cs);
+#pragma unroll
+                        for (int off = 1; off < 64; off <<= 1) cs += __shfl_xor(cs, off, 64);
+                        ill = kfin_keep == kfin_keep && cs * 3.46410161513775459f > 150.f * fmaxf(fabsf(kfin_keep), 0.1f);
+                    }
+                    if (lanep == 0) a.kflag[(size_t)i * a.B + j] = (canc_keep || ill) ? 1 : 0;
+                }
                 // ---- coarse gradient: R = 4-corner scatter of S_coarse / r^2, RBF derivative, both contractions ----------
                 const float ns32 = (float)(-inv_h * 1.4426950408889634074);
                 auto Sat = [&](int aa, int bb) -> float {

@@ -61,9 +61,23 @@ __device__ __forceinline__ void d_stany(void *b, size_t i, double v, int io64)
     else
         static_cast<float *>(b)[i] = (float)v;
 }
+// sum over the 64 lanes in six DPP adds; the total ends up in lane 63
+__device__ __forceinline__ float d_wave_sum63(float v)
+{
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xF, 0xF, true)); // row_shr:1
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112, 0xF, 0xF, true)); // row_shr:2
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xF, 0xF, true)); // row_shr:4
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x118, 0xF, 0xF, true)); // row_shr:8
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, true)); // row_bcast:15 into rows 1, 3
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xC, 0xF, true)); // row_bcast:31 into rows 2, 3
+    return v;
+}
 } // namespace
 
-template <int DPAD, bool GRAD, bool SYM, int DNW>
+// FEW (forward-only launches of paths in <= 3 channels, 8-channel layout): the forward steps also accumulate sum |K_fwd * D|,
+// the bound on the condition number of gram_fast.hip ("conditioning"); gradient launches take the condition number itself
+// from the coarse tables (sum |S_coarse D_coarse|, one pass over (T-1)^2 entries per pair)
+template <int DPAD, bool GRAD, bool SYM, int DNW, bool FEW = false>
 __global__ __launch_bounds__(DNW * 64) __attribute__((amdgpu_waves_per_eu(DNW == 8 ? 2 : 1, 2))) void gram_dyad_kernel(DyadArgs a)
 {
     constexpr int NT = DNW * 64;
@@ -189,6 +203,9 @@ __global__ __launch_bounds__(DNW * 64) __attribute__((amdgpu_waves_per_eu(DNW ==
             int rev_band = -1;
             bool kdone = false;
             float kmax = 1.f; // largest |K| this lane has seen on the pair's grid (boundary: 1)
+            float cnd = 0.f;  // FEW: this lane's share of sum |K_fwd * gamma|
+            float kfin_keep = 0.f;
+            bool canc_keep = false;
             // visit list, 8 bits per visit: band | half << 1 | reverse << 2 | leave K[64][.] << 3
             unsigned long long vis = 0;
             int nv = 0;
@@ -256,7 +273,7 @@ __global__ __launch_bounds__(DNW * 64) __attribute__((amdgpu_waves_per_eu(DNW ==
                     for (int k = 0; k < 64; ++k) Ssl[k] = 0.f;
                     const float hbf = topb[lv + 2];
                     asm volatile("" ::: "memory");
-                    { float sd_unused = 0.f; quad_fwd_all<0, true>(fc, fuA, fuB, fV, Dsl, Ssl, wr, rows, hbf, haddr, hinc, r3, nrows + ncols, sd_unused); }
+                    quad_fwd_all<0, true, FEW ? 1 : 0>(fc, fuA, fuB, fV, Dsl, Ssl, wr, rows, hbf, haddr, hinc, r3, nrows + ncols, cnd);
                     asm volatile("" ::: "memory");
                     if (!kdone) { // (the slots: K at the cells' upper left corners; fc: the row's last value so far)
                         kmax = d_max3_abs(kmax, fc, fc);
@@ -274,12 +291,27 @@ __global__ __launch_bounds__(DNW * 64) __attribute__((amdgpu_waves_per_eu(DNW ==
                     kdone = true;
                     // a pair whose solution cancelled (rough paths in few channels: DESIGN.md section 3) is marked for the fp64 pass
                     const float kfin = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fc), nrows - 1));
-                    const bool cancelled = __builtin_amdgcn_ballot_w64(kfin == kfin && kmax > (d == 1 ? 1.5f : 2.f) && kmax > (d == 1 ? 2.f : d == 2 ? 4.f : 8.f) * fmaxf(fabsf(kfin), 0.1f)) != 0;
+                    // Refined grids: the one full-magnitude add per cell rounds with the same sign row after row where the
+                    // increments of neighbouring cells are (nearly) identical, i.e. the fp32 sweeps lose up to ~6e-8 per ROW of the
+                    // largest value on the grid -- 5e-6 over 128 rows at dyadic order >= 5, where whole blocks of cells share one
+                    // increment (round 3's sweep: 5.7e-6 on smooth paths with K ~ 1).  A pair that merely decays from the boundary
+                    // value 1 to K = 0.18 therefore came out 1.7e-5 off (soak of round 4, case 504: T = 3, order 6, d = 2): at order
+                    // >= 5 every pair whose grid maximum exceeds 1.5 max(|K|, 0.1) goes to the fp64 pass, and below that order the
+                    // round-3 ratios apply WITHOUT the floor "grid maximum > 2" (the boundary value alone is a maximum of 1).
+                    const float kden = fmaxf(fabsf(kfin), 0.1f);
+                    bool fl = kmax > (n >= 5 ? 1.5f : (d == 1 ? 2.f : d == 2 ? 4.f : 8.f)) * kden;
+                    if constexpr (FEW) { // conditioning bound of a forward-only launch (gram_fast.hip); sqrt(12) gamma = the fine increment
+                        const float sds = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d_wave_sum63(cnd)), 63));
+                        fl = fl || sds * 3.46410161513775459f * fmaxf(kmax, 1.f) > 300.f * kden;
+                    }
+                    const bool cancelled = __builtin_amdgcn_ballot_w64(kfin == kfin && fl) != 0;
                     if (lanep == nrows - 1) {
                         d_stany(a.K, (size_t)i * a.B + j, (double)fc, io64);
                         if (SYM && j != i) d_stany(a.K, (size_t)j * a.B + i, (double)fc, io64);
-                        a.kflag[(size_t)i * a.B + j] = cancelled ? 1 : 0;
+                        if (!GRAD) a.kflag[(size_t)i * a.B + j] = cancelled ? 1 : 0; // (gradient launches: with the condition number, below)
                     }
+                    kfin_keep = kfin;
+                    canc_keep = cancelled;
                 }
                 if (!GRAD || !rev) continue;
 
@@ -335,6 +367,19 @@ __global__ __launch_bounds__(DNW * 64) __attribute__((amdgpu_waves_per_eu(DNW ==
                 // ---- coarse gradient: R = 4-corner scatter of S_coarse / r^2, RBF derivative, both contractions ----------
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_s_waitcnt(0xc07f);
+                // the pair's verdict for the exact fp64 pass: the grid maximum (above) or, in <= 3 channels, the condition number
+                // of K in the STORED increments -- one fp32 value per coarse cell, shared by its r^2 fine cells, so
+                // dK/dD_coarse = the block sum of S: c1 = sqrt(12) sum |Sc * Dc| / max(|K|, 0.1) > 150 (gram_fast.hip, "conditioning")
+                {
+                    bool ill = false;
+                    if (d <= 3) {
+                        float cs = 0.f;
+                        for (int e = lanep; e < Tm * Tm; e += 64) cs = __builtin_fmaf(fabsf((float)wl.Sc[e]), fabsf(wl.Dc[e]), cs);
+                        const float c1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d_wave_sum63(cs)), 63));
+                        ill = kfin_keep == kfin_keep && c1 * 3.46410161513775459f > 150.f * fmaxf(fabsf(kfin_keep), 0.1f);
+                    }
+                    if (lanep == 0) a.kflag[(size_t)i * a.B + j] = (canc_keep || ill) ? 1 : 0;
+                }
                 const float ns32 = (float)(-inv_h * 1.4426950408889634074);
                 auto Sat = [&](int aa, int bb) -> float {
                     return (aa >= 0 && aa < Tm && bb >= 0 && bb < Tm) ? (float)(wl.Sc[aa * Tm + bb] * inv_r2) : 0.f;
@@ -485,6 +530,10 @@ int dyad_launch_variant(const GramProblem &p, DyadArgs &a, const GradGeom &g, bo
         hipLaunchKernelGGL((gram_dyad_kernel<DPAD, true, true, DNW>), grid, block, 0, p.stream, a);
     else if (grad)
         hipLaunchKernelGGL((gram_dyad_kernel<DPAD, true, false, DNW>), grid, block, 0, p.stream, a);
+    else if (DPAD == 8 && p.d <= 3 && sym)
+        hipLaunchKernelGGL((gram_dyad_kernel<8, false, true, DNW, true>), grid, block, 0, p.stream, a);
+    else if (DPAD == 8 && p.d <= 3)
+        hipLaunchKernelGGL((gram_dyad_kernel<8, false, false, DNW, true>), grid, block, 0, p.stream, a);
     else if (sym)
         hipLaunchKernelGGL((gram_dyad_kernel<DPAD, false, true, DNW>), grid, block, 0, p.stream, a);
     else

@@ -663,8 +663,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
                 // the fp64 re-sweep below runs on fp32 increments, which is not enough where the discrete solution is
                 // ill-conditioned, so such pairs are flagged for the EXACT fp64 pass of the coverage kernel that follows the
                 // launch (fp64 static kernel, increments and sweeps: 6e-8).  Two rules, either one flags the pair:
-                //   * cancellation of magnitudes (round 3): the grid maximum above 2 and above 4 max(|K|, 0.1) (1.5 / 2 in one
-                //     channel) -- the fp32 sweeps resolve ~1e-6 of the largest value on the grid;
+                //   * cancellation of magnitudes (round 3): the grid maximum above 4 max(|K|, 0.1) (2 in one channel) -- the fp32
+                //     sweeps resolve ~1e-6 of the largest value on the grid, the boundary value 1 included;
                 //   * CONDITIONING (round 4): K[P][P] as a function of the increments has the first-order condition number
                 //     c1 = sum |S * D| / |K| (S = K_fwd * U is dK/dD up to the stencil's second-order terms), and the fp32
                 //     STORAGE of the increments (6e-8 each) costs K up to 2.7e-8 c1 whatever the precision of the sweeps
@@ -682,7 +682,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
                 if constexpr (DPAD == 4) {
                     if (a.kflag) {
                         const float kden = fmaxf(fabsf(kf), 0.1f);
-                        bool fl = km > (d == 1 ? 1.5f : 2.f) && km > (d == 1 ? 2.f : 4.f) * kden;
+                        bool fl = km > (d == 1 ? 2.f : 4.f) * kden;
                         if constexpr (!GRAD) { // sum over the pair's lanes of sum_q |K[l][q] gamma[l][q]|, times sqrt(12): in units of D
                             const float wsum = wave_sum_dpp<RING == 64>(sd);
                             float sds = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wsum), 63));

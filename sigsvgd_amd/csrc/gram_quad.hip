@@ -81,13 +81,11 @@ constexpr int QNW = SIGQ_NW; // wavefronts (rows i) per workgroup
 #ifndef SIGQ_CANCEL_RATIO
 #define SIGQ_CANCEL_RATIO 8.f
 #endif
-// A pair is solved again in fp64 when max |K_grid| > ratio * max(|K[P][P]|, 0.1) AND max |K_grid| > 2: the fp32 sweeps lose
-// about 5e-7 (T = 64) .. 2e-6 (T = 128) of the LARGEST value on the grid.  The second condition keeps the pairs out that
-// merely decay from the boundary value 1 (nothing large to cancel: right to 1e-6 in fp32).  ratio = 8; 4 for paths in
-// two channels and 2 (grid maximum above 1.5) in one: that is where the discrete solution is ill-conditioned beyond what
-// the maximum shows (60 of the 61 soak cases beyond 1e-5), while with three channels and more a ratio
-// of 4 only sends well-resolved pairs to the coverage kernel's fp64 pass (N=256, T=96, d=3: +16 % forward-only for
-// differences of 1e-6).
+// A pair is solved again in fp64 when max |K_grid| > ratio * max(|K[P][P]|, 0.1): the fp32 sweeps lose about 5e-7 (T = 64) ..
+// 2e-6 (T = 128) of the LARGEST value on the grid (the boundary value 1 included: round 3 also asked for a grid maximum above
+// 2, which left pairs that decay to K < 0.125 unchecked).  ratio = 8; 4 for paths in two channels and 2 in one.  Paths in <= 3
+// channels are also checked for their CONDITIONING in the increments (sum |S D| / |K|, gram_fast.hip): that, not the grid
+// maximum, is what the 9 soak cases of round 3 beyond 1e-5 had in common.
 constexpr float QUAD_CANCEL_RATIO = SIGQ_CANCEL_RATIO;
 // floats of a wavefront's column-side records of one pair: 4 quadrant passes + 2 halves of point row 64, each
 // [DPAD + 1 values][64 lanes], + 4 seam-column records of DPAD + 1 values (sized for DPAD = 16)
@@ -636,7 +634,9 @@ __global__ __launch_bounds__(QNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
                     // a pair whose solution cancelled (see gram_fast.hip, resweep_fwd_fp64) is marked for the fp64 pass
                     const float kfin = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fc), nrows - 1));
                     const float kden = fmaxf(fabsf(kfin), 0.1f);
-                    bool fl = kmax > (d == 1 ? 1.5f : 2.f) && kmax > (d == 1 ? 2.f : d == 2 ? 4.f : QUAD_CANCEL_RATIO) * kden;
+                    // (round 4: without the floor "grid maximum > 2" -- a pair that decays from the boundary value 1 to K < 1 / ratio
+                    //  loses the same ~2e-6 of the LARGEST value on its grid as one that oscillates)
+                    bool fl = kmax > (d == 1 ? 2.f : d == 2 ? 4.f : QUAD_CANCEL_RATIO) * kden;
                     if constexpr (FEW) { // conditioning bound of a forward-only launch: sum |K_fwd D| max(grid maximum, 1) > 300 max(|K|, 0.1)
                         const float sds = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q_wave_sum63(cnd)), 63));
                         fl = fl || sds * 3.46410161513775459f * fmaxf(kmax, 1.f) > 300.f * kden;

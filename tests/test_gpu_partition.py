@@ -98,9 +98,9 @@ def test_partial_shares_sum_to_full(gpu, N, stride, T, fold):
 
 
 def test_paths_beyond_128_points(gpu):
-    """T > 128 (dyadic order 0) is the coverage kernel's: with the gradient up to T = 136 in its compact layout (S in
-    fp32, gradient accumulated in place; the per-pair state has to fit 160 KB of LDS), forward-only beyond; longer
-    gradient launches are refused loudly."""
+    """T > 128 (dyadic order 0) is the coverage kernel's: its long-path layout (fp64 increments per band of 64 rows, S in the
+    launch's scratch; round 4) takes paths while 64 (T-1) + 2 T d doubles fit 160 KB of LDS -- T = 190 with the gradient,
+    which round 3 refused --, longer ones are refused loudly."""
     from sigsvgd_amd import ops
 
     A, B, h, d = 5, 4, 1.2, 2
@@ -115,8 +115,14 @@ def test_paths_beyond_128_points(gpu):
     assert _relK(Ks.cpu().numpy(), Ksr) < TOL and _rel(gs.cpu().numpy(), gsr) < TOL
 
     X2, Y2 = _paths(3, 190, d, 43, scale=0.03), _paths(4, 190, d, 44, scale=0.03)
-    Kref2, _ = C.gram_fwd_bwd(X2, Y2, h, 0, want_grad=False)
-    K2 = ops.gram_fwd(torch.as_tensor(X2, device=gpu), torch.as_tensor(Y2, device=gpu), 1.0 / h)
+    Kref2, gref2 = C.gram_fwd_bwd(X2, Y2, h, 0)
+    X2g, Y2g = torch.as_tensor(X2, device=gpu), torch.as_tensor(Y2, device=gpu)
+    K2 = ops.gram_fwd(X2g, Y2g, 1.0 / h)
     assert _relK(K2.cpu().numpy(), Kref2) < TOL
+    K3, g3 = ops.gram_fwd_bwd(X2g, Y2g, 1.0 / h)
+    assert _relK(K3.cpu().numpy(), Kref2) < TOL and _rel(g3.cpu().numpy(), gref2) < TOL
+    X4 = torch.as_tensor(_paths(3, 300, d, 45, scale=0.03), device=gpu)
     with pytest.raises(RuntimeError, match="LDS"):
-        ops.gram_fwd_bwd(torch.as_tensor(X2, device=gpu), torch.as_tensor(Y2, device=gpu), 1.0 / h)
+        ops.gram_fwd_bwd(X4, X4.clone(), 1.0 / h)
+    with pytest.raises(RuntimeError, match="LDS"):
+        ops.gram_fwd(X4, X4.clone(), 1.0 / h)
