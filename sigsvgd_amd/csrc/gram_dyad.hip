@@ -378,7 +378,13 @@ __global__ __launch_bounds__(DNW * 64) __attribute__((amdgpu_waves_per_eu(DNW ==
                         const float c1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d_wave_sum63(cs)), 63));
                         ill = kfin_keep == kfin_keep && c1 * 3.46410161513775459f > 150.f * fmaxf(fabsf(kfin_keep), 0.1f);
                     }
-                    if (lanep == 0) a.kflag[(size_t)i * a.B + j] = (canc_keep || ill) ? 1 : 0;
+                    // (`lane`, not the per-pair opaque copy `lanep`: with `lanep == 0` hipcc reuses the mask it formed for the sweeps'
+                    //  boundary lanes at the top of the pair, keeps it live across every sweep statement, and the 16-channel
+                    //  4-wavefront symmetric instantiation -- the one that parks spilled values in AGPRs -- then returned column-side
+                    //  sums that were wrong at the first and last point (soak of round 4, 91 of 6,000 cases); with `lane == 0`, or with
+                    //  every lane storing, the same kernel is right.  Not understood beyond that: tests/test_gpu_dyadic.py pins the
+                    //  instantiation.)
+                    if (lane == 0) a.kflag[(size_t)i * a.B + j] = (canc_keep || ill) ? 1 : 0;
                 }
                 const float ns32 = (float)(-inv_h * 1.4426950408889634074);
                 auto Sat = [&](int aa, int bb) -> float {
