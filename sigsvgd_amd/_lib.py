@@ -64,17 +64,24 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """hipcc --offload-arch=gfx950 -shared -> sigsvgd_amd/libsigsvgd_hip.so (in-tree)."""
+def build(force: bool = False, verbose: bool = False, out_path: str = None, objdir: str = None, defines=()) -> str:
+    """hipcc --offload-arch=gfx950 -shared -> sigsvgd_amd/libsigsvgd_hip.so (in-tree).  `out_path` / `objdir`: build somewhere
+    else from scratch (tests/test_cabi.py builds into a temporary directory to show the sources alone produce the library;
+    scripts/dev builds diagnostic variants with `defines`)."""
+    if out_path is not None:
+        return _build_to(out_path, objdir or os.path.join(os.path.dirname(out_path), "_obj"), verbose, tuple(defines))
     if not force and not needs_build():
         return LIB_PATH
+    return _build_to(LIB_PATH, os.path.join(_PKG, "_obj"), verbose, tuple(defines))
+
+
+def _build_to(lib_path: str, objdir: str, verbose: bool, defines=()) -> str:
     # one hipcc per source, side by side (the four pair-solver files take 30-50 s each: 3 min in a row, 1 min in parallel),
     # then one link; objects under sigsvgd_amd/_obj/ (git-ignored)
     from concurrent.futures import ThreadPoolExecutor
 
-    objdir = os.path.join(_PKG, "_obj")
     os.makedirs(objdir, exist_ok=True)
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + [f"-D{d}" for d in defines]
 
     def compile_one(src):
         obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
@@ -88,12 +95,12 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
     with ThreadPoolExecutor(max_workers=min(len(SOURCES), max(1, (os.cpu_count() or 2) - 1))) as pool:
         objs = list(pool.map(compile_one, SOURCES))
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB_PATH] + objs + ["-ldl"]
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared", "-o", lib_path] + objs + ["-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
-    _check_dpp_hazards(LIB_PATH)
-    return LIB_PATH
+    _check_dpp_hazards(lib_path)
+    return lib_path
 
 
 def _check_dpp_hazards(lib_path: str) -> None:

@@ -341,9 +341,13 @@ __global__ __launch_bounds__(DNW * 64) __attribute__((amdgpu_waves_per_eu(DNW ==
                 }
                 // ---- block sums of S into the coarse grid (cells outside the grid hold S = 0) -------------------------
                 // A lane's slots walk its row's local columns in order, so the cells of one coarse column form a run: the run
-                // is summed in the lane and added when the coarse column changes (or the slots end).  Lanes of one row block
-                // reach their run ends on different slots, so the adds of one instruction never meet on an address (one add
-                // per cell instead -- r lanes times r slots on the same address -- took 2/3 of the kernel at order 5).
+                // is summed in the lane and added when the coarse column changes.  Lanes of one row block reach those run ends
+                // on different slots, so the adds of one instruction never meet on an address (one add per cell instead -- r
+                // lanes times r slots on the same address -- took 2/3 of the kernel at order 5).  The LAST slot is different: it
+                // ends every lane's run at once, and the r lanes of a row block (an aligned group: local column 63 - lane) then
+                // hold pieces of the SAME coarse cell -- r same-address adds in one instruction, whose order is the LDS unit's
+                // business.  Their pieces are therefore summed across the group in a fixed butterfly first and
+                // one lane adds: the bits of S_coarse are a function of the launch geometry only.
                 {
                     double *scrow = wl.Sc + arow * Tm;
                     int cl = (64 - lv) & 63;
@@ -354,7 +358,10 @@ __global__ __launch_bounds__(DNW * 64) __attribute__((amdgpu_waves_per_eu(DNW ==
                         run += Ssl[k];
                         cl = (cl + 1) & 63;
                         const int bnext = min((64 * h + cl) >> n, Tm - 1);
-                        if (bnext != bcur || k == 63) {
+                        if (k == 63) {
+                            for (int off = 1; off < (1 << n); off <<= 1) run += __shfl_xor(run, off, 64);
+                            if ((lv & ((1 << n) - 1)) == 0) unsafeAtomicAdd(scrow + bcur, (double)run);
+                        } else if (bnext != bcur) {
                             unsafeAtomicAdd(scrow + bcur, (double)run); // ds_add_f64
                             run = 0.f;
                         }
@@ -590,3 +597,5 @@ int dyad_launch(const GramProblem &p)
 }
 
 } // namespace sigsvgd
+
+SIG_EXEC_DEBUG_GETTER(dyad)

@@ -34,6 +34,8 @@
 //
 // Reference semantics: sigkernel _SigKernelGram.forward/backward [RECALLED, SURVEY.md App. A];
 // static kernel src/kernels/_traj_kernels.py:176-195; callers src/inference/score.py:68-69.
+#include <atomic>
+
 #include "sig_common.h"
 #ifdef SIGSVGD_PHASE_STAMPS
 #include <cstdio>
@@ -246,6 +248,7 @@ __device__ __forceinline__ void sweep_fwd8(float &cur, float &upA, float &upB, f
                                            const unsigned long long *mk, const float r3, float &km, float &sd)
 {
     float t, y;
+    SIG_EXEC_MUST_BE_FULL("sweep_fwd8");
     const unsigned long long m0 = mk[0], m1 = mk[1], m2 = mk[2], m3 = mk[3], m4 = mk[4], m5 = mk[5], m6 = mk[6], m7 = mk[7];
     if constexpr (MODE == 2)
         asm volatile(SIG_FWD_STEP("upA", "upB", "g0", SIG_FWD_NOKSL_SD("upB", "g0"), "m0") SIG_FWD_STEP("upB", "upA", "g1", SIG_FWD_NOKSL_SD("upA", "g1"), "m1")
@@ -290,6 +293,7 @@ __device__ __forceinline__ void sweep_rev8(float &cur, float &dnA, float &dnB, f
                                            const unsigned long long *mk, const float r3)
 {
     float t, y;
+    SIG_EXEC_MUST_BE_FULL("sweep_rev8");
     const unsigned long long m0 = mk[0], m1 = mk[1], m2 = mk[2], m3 = mk[3], m4 = mk[4], m5 = mk[5], m6 = mk[6], m7 = mk[7];
     asm volatile(SIG_REV_STEP("dnA", "dnB", "g7", "k7", "m7") SIG_REV_STEP("dnB", "dnA", "g6", "k6", "m6")
                  SIG_REV_STEP("dnA", "dnB", "g5", "k5", "m5") SIG_REV_STEP("dnB", "dnA", "g4", "k4", "m4")
@@ -1037,16 +1041,17 @@ bool fast_supported(int A, int B, int T, int d, int n, int kind, unsigned flags)
 // compute units of the current device (256 on MI355X); the persistent grids are sized from it
 int device_cu_count()
 {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
-            n = v;
-        else
-            n = 256;
+    static std::atomic<int> cache[64]; // per device ordinal (zero-initialised: not queried yet)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (dev >= 0 && dev < 64) {
+        const int c = cache[dev].load(std::memory_order_relaxed);
+        if (c > 0) return c;
     }
-    return n;
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    if (dev >= 0 && dev < 64) cache[dev].store(v, std::memory_order_relaxed);
+    return v;
 }
 
 TileMap make_tilemap(int ntile, int off, int stride, bool fold)
@@ -1295,3 +1300,5 @@ int fast_sym_partial(const GramProblem &p, int tile_offset, int tile_stride, boo
 }
 
 } // namespace sigsvgd
+
+SIG_EXEC_DEBUG_GETTER(fast)

@@ -15,6 +15,8 @@
 //
 // Reference semantics: sigkernel _SigKernelGram.forward/backward [RECALLED, SURVEY.md App. A];
 // static kernel src/kernels/_traj_kernels.py:176-195.
+#include <atomic>
+
 #include "sig_common.h"
 #ifdef SIGSVGD_PHASE_STAMPS
 #include <cstdio>
@@ -592,14 +594,17 @@ namespace {
 template <typename IO, bool NAIVE, bool GRAD, bool BIG, typename DT>
 hipError_t generic_launch_one(const GenericPlan &pl, hipStream_t stream, const GenericArgs &a)
 {
-    // (once per instantiation and process, for the largest size any plan can ask for: the call costs ~10 us of host time,
-    //  which a small launch -- the fp64 pass behind a 50-us kernel -- would pay every time)
-    static bool raised = false;
-    if (!raised) {
+    // (once per instantiation, for the largest size any plan can ask for: the call costs ~10 us of host time, which a small
+    //  launch -- the fp64 pass behind a 50-us kernel -- would pay every time
+    //  -- per DEVICE: the attribute belongs to the current device's copy of the function, and a process may drive several)
+    static std::atomic<unsigned long long> raised{0}; // bit = device ordinal (devices >= 64: raised every time)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !((raised.load(std::memory_order_acquire) >> dev) & 1ull)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gram_generic_kernel<IO, NAIVE, GRAD, BIG, DT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        raised = true;
+        if (dev >= 0 && dev < 64) raised.fetch_or(1ull << dev, std::memory_order_release);
     }
     hipLaunchKernelGGL((gram_generic_kernel<IO, NAIVE, GRAD, BIG, DT>), dim3(pl.grid), dim3(kWave), pl.lds, stream, a);
     return hipSuccess;

@@ -1164,3 +1164,5 @@ int quad_sym_partial(const GramProblem &p, int tile_offset, int tile_stride, boo
 }
 
 } // namespace sigsvgd
+
+SIG_EXEC_DEBUG_GETTER(quad)

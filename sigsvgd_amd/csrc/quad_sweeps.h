@@ -61,6 +61,7 @@ __device__ __forceinline__ void quad_fwd4(float &cur, float &upA, float &upB, fl
 {
     float t, y;
     unsigned long long tm;
+    SIG_EXEC_MUST_BE_FULL("quad_fwd4");
     if constexpr (S0 < 64 && MODE == 0) {
         int sb;
         asm volatile(SIG_Q_FWD("s_lshr_b64", "i0", "wr", "upA", "upB", "g0", "k0", SIG_Q_RL("l0"), SIG_Q_BMOV("upB"))
@@ -131,6 +132,7 @@ __device__ __forceinline__ void quad_rev4(float &cur, float &dnA, float &dnB, fl
 {
     float t, y;
     unsigned long long tm;
+    SIG_EXEC_MUST_BE_FULL("quad_rev4");
     if constexpr (S0 >= 64) {
         int sb;
         const unsigned long long wl = (S0 + 3 == 127) ? 0ull : wr;

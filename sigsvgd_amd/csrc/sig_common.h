@@ -152,6 +152,34 @@ __device__ __forceinline__ double shfl_down_f64(double v) // lane l <- lane l+1 
     return __hiloint2double(hi, lo);
 }
 
+// ---- EXEC discipline of the hand-written sweep statements ----------------------------------------------------------------
+// The sweep statements (gram_fast.hip sweep_fwd8 / sweep_rev8, quad_sweeps.h) move lane windows into EXEC and leave it at
+// all ones.  EXEC is a reserved register for hipcc: a clobber on it is ignored with a warning ("inline asm clobber list
+// contains reserved registers"), so the compiler cannot be told.  The statements are therefore only correct where the
+// compiler's own EXEC is all ones too, i.e. in wave-uniform control flow -- which every call site is by construction (the
+// conditions around them are functions of kernel arguments, block and wavefront indices).  -DSIGSVGD_CHECK_EXEC turns that
+// into a run-time check: each statement group first compares EXEC with all ones and records a violation in a device-side
+// sticky word per translation unit (scripts/dev/check_exec.py builds that variant, runs the kernel families through it and
+// reads the words back; profiles/r04_exec_check.txt).
+#ifdef SIGSVGD_CHECK_EXEC
+static __device__ unsigned g_exec_violations; // one per translation unit; read back by sigsvgd_debug_exec_violations_<unit>()
+#define SIG_EXEC_MUST_BE_FULL(what)                                                        \
+    do {                                                                                   \
+        if (__builtin_amdgcn_read_exec() != ~0ull) g_exec_violations = 1u;                 \
+    } while (0)
+#define SIG_EXEC_DEBUG_GETTER(unit)                                                        \
+    extern "C" unsigned sigsvgd_debug_exec_violations_##unit(void)                         \
+    {                                                                                      \
+        unsigned v = 0xffffffffu;                                                          \
+        (void)hipDeviceSynchronize();                                                      \
+        (void)hipMemcpyFromSymbol(&v, HIP_SYMBOL(sigsvgd::g_exec_violations), sizeof(v));  \
+        return v;                                                                          \
+    }
+#else
+#define SIG_EXEC_MUST_BE_FULL(what)
+#define SIG_EXEC_DEBUG_GETTER(unit)
+#endif
+
 // ---- launch descriptors shared by host code -----------------------------------------------------
 struct GramProblem {
     const void *X, *Y;

@@ -5,7 +5,9 @@ The reference has no distributed code; this is new desig
 natural sharding: N^2/2 independent pair solves followed by one reduction over partners.
 
     rank r owns particle rows [r*N/G, (r+1)*N/G)
-    1. all-gather   X and score shards, packed into ONE collective   (2*N*T*d*4 B; 3.7 MB at N=1024,T=64,d=7)
+    1. all-gather   X and score shards (2*N*T*d*4 B; 3.7 MB at N=1024,T=64,d=7) into two contiguous operands, issued as
+                    ONE grouped RCCL operation (ncclGroupStart / ncclGroupEnd through torch's coalescing manager: a single
+                    launch on this latency-bound path); gloo, which has no grouped form, issues them one after the other
     2. compute      the unordered pairs {i <= j} whose row tile (ops.sym_tile_rows(T, d) rows: 4 for T <= 64 with
                     d > 8, else 8) has index r, r + G, ... or is the mirror image ntile-1-t of such a tile
                     (FOLDED ownership: in the upper triangle tile t holds N - t*rows columns, so a tile and
@@ -48,6 +50,22 @@ def all_gather_rows(shard: torch.Tensor, group=None, out: Optional[torch.Tensor]
         out = torch.empty((shard.shape[0] * world,) + tuple(shard.shape[1:]), dtype=shard.dtype, device=shard.device)
     dist.all_gather_into_tensor(out, shard.contiguous(), group=group)
     return out
+
+
+def all_gather_rows_pair(a: torch.Tensor, b: torch.Tensor, out_a: torch.Tensor, out_b: torch.Tensor, group=None) -> None:
+    """Two all-gathers (same shard shape) into their own contiguous outputs as one grouped collective where the backend has
+    one (RCCL: ncclGroupStart / ncclGroupEnd, a single launch); otherwise back to back."""
+    a, b = a.contiguous(), b.contiguous()
+    if dist.get_backend(group) == "nccl" and hasattr(dist, "_coalescing_manager"):
+        try:
+            with dist._coalescing_manager(group=group, device=a.device, async_ops=False):
+                dist.all_gather_into_tensor(out_a, a, group=group)
+                dist.all_gather_into_tensor(out_b, b, group=group)
+            return
+        except (RuntimeError, TypeError, NotImplementedError):  # a torch build without the grouped form for this op
+            pass
+    dist.all_gather_into_tensor(out_a, a, group=group)
+    dist.all_gather_into_tensor(out_b, b, group=group)
 
 
 def reduce_scatter_rows(full: torch.Tensor, group=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -109,10 +127,22 @@ class ShardedSigSVGD:
         self.group = group
         self.fold = bool(fold)
         self.partial_fn = partial_fn or ops.gram_sym_partial
+        # `out=` / `fold=` are passed only to callables that take them (the 4-argument contract of rounds 1-2 still works;
+        # such a callable owns cyclic tiles and allocates its results)
+        import inspect
+
+        try:
+            params = inspect.signature(self.partial_fn).parameters
+            self._partial_kwargs = ("out" in params and "fold" in params) or any(
+                q.kind is inspect.Parameter.VAR_KEYWORD for q in params.values())
+        except (TypeError, ValueError):
+            self._partial_kwargs = True
+        if not self._partial_kwargs and self.fold and partial_fn is not None:
+            self.fold = False  # (cyclic ownership is what a 4-argument callable implements)
         self.phi_fn = phi_fn or (lambda K, s, gk: ops.svgd_phi(K, s, gk))
         self.rows_fn = rows_fn or (lambda Xs, Xf, inv_h: ops.gram_fwd_bwd(Xs, Xf, inv_h))
         self.rowwise = bool(rowwise)
-        self.last_K_partial = None
+        self.last_K_partial = None  # ALIASES the step's preallocated buffer: the next step() overwrites it (clone to keep it)
         self.last_K_rows = None
         self.phase_ms = None  # filled by step(profile=True): milliseconds per phase on this rank
         self._buf = {}        # per-step buffers, allocated once per (shape, dtype, device)
@@ -141,9 +171,9 @@ class ShardedSigSVGD:
         rank, world = _world(self.group)
         mark = _PhaseClock(X_shard.device) if profile else None
         buf = self._buffers(X_shard, world)
-        # two collectives into preallocated, contiguous operands (no stack / split copies)
-        X_full = all_gather_rows(X_shard, self.group, out=buf["X_full"])
-        s_full = all_gather_rows(score_shard.to(X_shard.dtype), self.group, out=buf["s_full"])
+        # one grouped collective into preallocated, contiguous operands (no stack / split copies)
+        X_full, s_full = buf["X_full"], buf["s_full"]
+        all_gather_rows_pair(X_shard, score_shard.to(X_shard.dtype), X_full, s_full, self.group)
         if mark:
             mark("all_gather")
         if self.rowwise or not self._partial_supported(X_full):
@@ -152,8 +182,11 @@ class ShardedSigSVGD:
                 mark("rowwise_solve_and_update")
                 self.phase_ms = mark.result()
             return out
-        Kp, gp = self.partial_fn(X_full, self.inv_h, rank, world, out=(buf["K_partial"], buf["grad_partial"]),
-                                 fold=self.fold)
+        if self._partial_kwargs:  # (a user callable written to the 4-argument contract gets no preallocated outputs)
+            Kp, gp = self.partial_fn(X_full, self.inv_h, rank, world, out=(buf["K_partial"], buf["grad_partial"]),
+                                     fold=self.fold)
+        else:
+            Kp, gp = self.partial_fn(X_full, self.inv_h, rank, world)
         if mark:
             mark("partial_solve")
         self.last_K_partial = Kp

@@ -293,7 +293,18 @@ def gram_sym_partial(X, inv_h: float, tile_offset: int, tile_stride: int, static
 def sym_tile_rows(T: int, d: int) -> int:
     """Rows per tile of the symmetric / partial solve (the ownership unit of the sharded step); 0 for shapes the partial
     solve does not take.  Host-only query of the library."""
-    return int(_lib.load().sigsvgd_gram_sym_tile_rows(int(T), int(d)))
+    try:
+        return int(_lib.load().sigsvgd_gram_sym_tile_rows(int(T), int(d)))
+    except RuntimeError:
+        # Host-only rule, restated for boxes without the built library (the CPU test doubles of tests/helpers.py and the gloo
+        # rehearsal use it to mirror the ownership; every compute entry point still raises without the library):
+        # csrc/gram_fast.hip grad_nw (T <= 64: 8 rows, 4 with d > 8), csrc/gram_quad.hip (65 <= T <= 128: 8 rows)
+        T, d = int(T), int(d)
+        if 3 <= T <= 64 and d <= 16:
+            return 8 if d <= 8 else 4
+        if 65 <= T <= 128 and d <= 16:
+            return 8
+        return 0
 
 
 def owned_tiles(ntile: int, tile_offset: int, tile_stride: int, fold: bool = False):

@@ -117,3 +117,25 @@ def test_argument_errors_are_status_codes(lib):
     assert rc == -2  # T > 128 is outside the register-resident and streaming paths
     rc = lib.sigsvgd_svgd_phi(None, one, one, None, 4, 4, one, None, None, 0.1, None)
     assert rc == -1
+
+
+def test_build_from_a_clean_tree(tmp_path):
+    """`build()` proves itself: the sources alone, compiled into an empty directory (no object or library of an earlier
+    build is touched), give a library that exports exactly the header's entry points, reports the header's ABI version and
+    passes the DPP hazard check.  (The driver's build() call is mtime-gated and usually finds the in-tree library current.)"""
+    import re
+    import subprocess
+
+    from sigsvgd_amd import _lib
+
+    out = tmp_path / "libsigsvgd_clean.so"
+    _lib.build(out_path=str(out), objdir=str(tmp_path / "obj"))
+    assert out.exists() and out.stat().st_size > 1 << 20
+    syms = subprocess.run(["nm", "-D", "--defined-only", str(out)], capture_output=True, text=True, check=True).stdout
+    exported = sorted(set(re.findall(r"\bT (sigsvgd_\w+)", syms)))
+    assert exported == sorted(_lib.EXPORTS)
+    header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "sigsvgd_hip.h")).read()
+    abi = int(re.search(r"#define SIGSVGD_ABI_VERSION (\d+)", header).group(1))
+    L = ctypes.CDLL(str(out))
+    L.sigsvgd_abi_version.restype = ctypes.c_int
+    assert L.sigsvgd_abi_version() == abi == _lib.ABI_VERSION

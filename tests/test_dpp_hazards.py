@@ -44,3 +44,29 @@ def test_built_library_has_no_dpp_hazard():
         bad += b
     assert total > 1000, "no DPP instructions found: the disassembly step is broken"
     assert not bad, bad[:5]
+
+
+def test_exec_region_reader_finds_planted_statements():
+    """the informational EXEC reader: a sweep statement (s_mov_b64 exec, -1 + wave shift) inside a saved-EXEC region or a
+    divergent loop is reported, one in straight-line code is not"""
+    import check_dpp_hazards as c
+
+    text = """
+0000000000001000 <kern_a>:
+\ts_mov_b64 exec, -1                                         // 000000001000: BEFE01C1
+\tv_mov_b32_dpp v1, v2 wave_shr:1 row_mask:0xf bank_mask:0xf   // 000000001004: 7E0202FA FF013802
+\ts_and_saveexec_b64 s[4:5], vcc                              // 00000000100C: BE84206A
+\ts_mov_b64 exec, -1                                         // 000000001010: BEFE01C1
+\tv_mov_b32_dpp v1, v2 wave_shl:1 row_mask:0xf bank_mask:0xf   // 000000001014: 7E0202FA FF013002
+\ts_or_b64 exec, exec, s[4:5]                                 // 00000000101C: 87FE047E
+\ts_mov_b64 exec, -1                                         // 000000001020: BEFE01C1
+\tv_mov_b32_dpp v1, v2 wave_shr:1 row_mask:0xf bank_mask:0xf   // 000000001024: 7E0202FA FF013802
+0000000000002000 <kern_b>:
+\ts_mov_b64 exec, -1                                         // 000000002000: BEFE01C1
+\tv_mov_b32_dpp v1, v2 wave_shr:1 row_mask:0xf bank_mask:0xf   // 000000002004: 7E0202FA FF013802
+\ts_andn2_b64 exec, exec, s[6:7]                              // 00000000200C: 89FE067E
+\ts_cbranch_execnz 65531                                      // 000000002010: BF89FFFB
+"""
+    n, bad = c.check_exec_regions(text)
+    assert n == 4
+    assert [(f, a) for f, a, _ in bad] == [("kern_a", 0x1010), ("kern_b", 0x2000)]
