@@ -57,8 +57,8 @@
  *     below 5e-6 of it in every regime measured).  SIGSVGD_FLAG_FORCE_GENERIC returns 6e-8 anywhere.
  *   - results are bit-reproducible: every reduction over pairs runs in an order fixed by the launch
  *     geometry (no floating-point atomics), so two calls on the same inputs return the same bits.
- *     One exception: sigsvgd_vec_kernel_fused joins its column splits with fp32 atomics (dK_out may
- *     differ in the last bits between calls); sigsvgd_vec_sqdist + sigsvgd_vec_kernel are reproducible.
+ *     sigsvgd_vec_kernel_fused is reproducible when it is given its workspace (sigsvgd_vec_fused_workspace_bytes);
+ *     without one its column splits meet in fp32 atomics and the last bits of dK_out may differ between calls.
  */
 #ifndef SIGSVGD_HIP_H
 #define SIGSVGD_HIP_H
@@ -206,10 +206,15 @@ int sigsvgd_vec_kernel(const void *sq, const void *XM, const void *YM, const voi
 /* The same in ONE launch when the bandwidth is known in advance (no sq[A,B] round trip through HBM; both
  * GEMM-shaped sums on the fp32 matrix cores).  X, Y [.,D]; XM, YM = X M, Y M or both NULL (M = I); K_out / dK_out
  * nullable (not both).  fp32 and D <= 512 only (else SIGSVGD_E_UNSUPPORTED: use the two calls above).  Operands
- * are centred on the first row of Y (differences are unchanged); dK_out is zeroed by the call. */
+ * are centred on the first row of Y (differences are unchanged); dK_out is fully overwritten. */
 int sigsvgd_vec_kernel_fused(const void *X, const void *Y, const void *XM, const void *YM, const void *grad_out, int A,
                              int B, int D, int dtype, int kind, double inv_h2, double grad_scale, void *K_out,
-                             void *dK_out, void *stream);
+                             void *dK_out, void *workspace, size_t workspace_bytes, void *stream);
+/* Scratch for the reproducible route of sigsvgd_vec_kernel_fused (ABI 9): the launch splits the columns over the grid, and
+ * with a workspace of this size every split stores its partial dK in a block of its own, added in split order by a second
+ * small launch -- bits that depend on the launch geometry only.  workspace = NULL keeps the one-launch route whose splits
+ * meet in fp32 atomics (last bits of dK_out may differ between calls).  0 bytes: a single split, nothing to join. */
+int sigsvgd_vec_fused_workspace_bytes(int A, int B, int D, size_t *bytes);
 
 /* ---- trajectory cost in front of the path -----------------------------------------------
  * The reference's planning cost, examples/script_planning_obstacle_field.py:113-126, with its analytic gradient:

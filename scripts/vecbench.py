@@ -54,6 +54,8 @@ for N, D in [(1024, 448), (4096, 64), (4096, 448), (512, 14)]:
     Kr, dKr = ref_gaussian(X.double(), X.double(), h) if N * N * D * 8 < 40e9 else (None, None)
     err = float((dK.double() - dKr).abs().max() / dKr.abs().max()) if dKr is not None else float("nan")
     t_fused = timeit(lambda: ops.vec_kernel_fused(X, X, _lib.VEC_GAUSSIAN, 1 / h**2, -1 / h**2))
+    t_fused_atomic = timeit(lambda: ops.vec_kernel_fused(X, X, _lib.VEC_GAUSSIAN, 1 / h**2, -1 / h**2, reproducible=False))
+    print(f"N={N} D={D}: fused, reproducible route (per-split partials + join) {t_fused*1e3:.1f} us; one launch with atomics {t_fused_atomic*1e3:.1f} us")
     Kf, dKf = ops.vec_kernel_fused(X, X, _lib.VEC_GAUSSIAN, 1 / h**2, -1 / h**2)
     errf = float((dKf.double() - dKr).abs().max() / dKr.abs().max()) if dKr is not None else float((dKf - dK).abs().max() / dK.abs().max())
     byf = 4 * (2 * N * D + N * N + N * D)      # fused: read X twice, write K, write dK

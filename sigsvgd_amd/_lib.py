@@ -41,6 +41,7 @@ EXPORTS = [
     "sigsvgd_vec_sqdist",
     "sigsvgd_vec_kernel",
     "sigsvgd_vec_kernel_fused",
+    "sigsvgd_vec_fused_workspace_bytes",
     "sigsvgd_signature",
     "sigsvgd_signature_backward",
     "sigsvgd_obstacle_cost",
@@ -168,7 +169,9 @@ def load():
     L.sigsvgd_vec_kernel.restype = ci
     L.sigsvgd_vec_kernel.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, cd, cd, vp, vp, vp]
     L.sigsvgd_vec_kernel_fused.restype = ci
-    L.sigsvgd_vec_kernel_fused.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, cd, cd, vp, vp, vp]
+    L.sigsvgd_vec_kernel_fused.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, cd, cd, vp, vp, vp, ctypes.c_size_t, vp]
+    L.sigsvgd_vec_fused_workspace_bytes.restype = ci
+    L.sigsvgd_vec_fused_workspace_bytes.argtypes = [ci, ci, ci, ctypes.POINTER(ctypes.c_size_t)]
     L.sigsvgd_obstacle_cost.restype = ci
     L.sigsvgd_obstacle_cost.argtypes = [vp, ci, ci, ci, vp, vp, vp, ci, vp, vp, vp, ci, cf, cf, vp, vp, vp, vp]
     L.sigsvgd_signature.restype = ci

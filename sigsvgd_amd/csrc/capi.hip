@@ -35,7 +35,8 @@ int vec_kgrad_launch(const void *sq, const void *XM, const void *YM, const void 
                      int kind, double inv_h2, double grad_scale, void *K, void *dK, hipStream_t stream);
 bool vec_fused_supported(int D, int dtype);
 int vec_fused_launch(const void *X, const void *Y, const void *XM, const void *YM, const void *go, int A, int B, int D,
-                     int kind, double inv_h2, double grad_scale, void *K, void *dK, hipStream_t stream);
+                     int kind, double inv_h2, double grad_scale, void *K, void *dK, void *ws, size_t ws_bytes, hipStream_t stream);
+size_t vec_fused_workspace_bytes(int A, int B, int D);
 long long signature_channels(int C, int depth);
 int obstacle_cost_launch(const float *x, int N, int Kx, int d, const float *start, const float *target, const float *basis,
                          int Tt, const float *logw, const float *mean, const float *stdv, int M, float w_obst, float w_len,
@@ -268,9 +269,19 @@ int sigsvgd_vec_sqdist(const void *X, const void *Y, const void *XM, const void 
     return vec_sqdist_launch(X, Y, XM, YM, A, B, D, dtype, sq_out, static_cast<hipStream_t>(stream));
 }
 
+int sigsvgd_vec_fused_workspace_bytes(int A, int B, int D, size_t *bytes)
+{
+    if (!bytes || A < 1 || B < 1 || D < 1) {
+        set_error("vec_fused_workspace_bytes: bad arguments A=%d B=%d D=%d", A, B, D);
+        return SIGSVGD_E_BADARG;
+    }
+    *bytes = vec_fused_workspace_bytes(A, B, D);
+    return SIGSVGD_OK;
+}
+
 int sigsvgd_vec_kernel_fused(const void *X, const void *Y, const void *XM, const void *YM, const void *grad_out, int A,
                              int B, int D, int dtype, int kind, double inv_h2, double grad_scale, void *K_out,
-                             void *dK_out, void *stream)
+                             void *dK_out, void *workspace, size_t workspace_bytes, void *stream)
 {
     if (!X || !Y || (!K_out && !dK_out) || (XM == nullptr) != (YM == nullptr)) {
         set_error("vec_kernel_fused: null pointer argument (XM and YM must both be given or both be NULL)");
@@ -290,7 +301,7 @@ int sigsvgd_vec_kernel_fused(const void *X, const void *Y, const void *XM, const
         return SIGSVGD_E_UNSUPPORTED;
     }
     Range range("sigsvgd_vec_kernel_fused");
-    return vec_fused_launch(X, Y, XM, YM, grad_out, A, B, D, kind, inv_h2, grad_scale, K_out, dK_out,
+    return vec_fused_launch(X, Y, XM, YM, grad_out, A, B, D, kind, inv_h2, grad_scale, K_out, dK_out, workspace, workspace_bytes,
                             static_cast<hipStream_t>(stream));
 }
 

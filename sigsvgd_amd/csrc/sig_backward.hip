@@ -14,6 +14,15 @@
 //   * adjoint of the exponential:   dD[a]   = sum_m (1/m!) sum_{r=1..m} sum_{v: v_r = a} dE_m[v] prod_{s != r} D[v_s]
 //   * D_t = x_t - x_{t-1}:          dX[t]   = dD_t - dD_{t+1}.
 // Every sum has one owner thread and a fixed order: no atomics, reproducible bits.
+//
+// Round 4: the index arithmetic is TABULATED once per workgroup, as the forward kernel does.  Round 3 decoded every element of
+// every level at every point -- two integer divisions by runtime powers of C per Horner step, a while loop and more divisions
+// per work unit of the exponential's adjoint, fp64 divisions by (k - r + 1) and m! -- and a point cost ~20,000 cycles whatever
+// the signature's size: 0.56 ms for 1024 paths x 64 points x 2 channels at depth 3 against 25 us forwards.  Now a table in LDS
+// holds, for element e of level k and Horner step r, the offset of the prefix (a_1 .. a_r) and the letter a_r (the monomial
+// pass reads the same table), the reciprocals are multiplied, and each thread decodes its work units of the exponential's
+// adjoint once, before the point loop.  Signatures whose table does not fit next to the six working copies keep the decoding
+// per point (TAB = false).
 #include "sig_common.h"
 
 namespace sigsvgd {
@@ -26,41 +35,98 @@ struct SigLevels {
     int off[SB_MAX_DEPTH + 2]; // offset of level k (1-based) in the concatenated signature; off[depth + 1] = total
 };
 
-template <typename T>
+constexpr int SB_UNITS = 4; // work units of the exponential's adjoint a thread can keep decoded (C depth (depth + 1) / 2 <= 4 threads)
+
+template <typename T, bool TAB>
 __global__ __launch_bounds__(256) void signature_bwd_kernel(const T *__restrict__ X, const T *__restrict__ gsig, int L, int C,
                                                             int depth, int basepoint, int sigdim, T *__restrict__ gX)
 {
     extern __shared__ double sb_lds[];
     double *S = sb_lds, *Sn = S + sigdim, *G = Sn + sigdim, *Gn = G + sigdim, *A0 = Gn + sigdim, *A1 = A0 + sigdim;
     double *inc = A1 + sigdim, *gnext = inc + C, *parts = gnext + C; // parts: [C][depth (depth + 1) / 2]
+    // TAB: tab[(r - 1) * sigdim + off[k] + e] = offset of the prefix (a_1 .. a_r) of element e of level k in the concatenated
+    // signature, letter a_r in the low byte (r = 1 .. k)
+    int *tab = reinterpret_cast<int *>(parts + (size_t)C * depth * (depth + 1) / 2);
     const int tid = threadIdx.x, nt = blockDim.x;
     const T *x = X + (size_t)blockIdx.x * L * C;
     T *gx = gX + (size_t)blockIdx.x * L * C;
     const int U = depth * (depth + 1) / 2;
 
-    SigLevels lv;
-    lv.pw[0] = 1;
-    lv.off[1] = 0;
-    for (int k = 1; k <= depth; ++k) {
-        lv.pw[k] = lv.pw[k - 1] * C;
-        lv.off[k + 1] = lv.off[k] + lv.pw[k];
+    // (in LDS: as private arrays indexed by run-time levels they lived in scratch memory, one scratch load per use)
+    __shared__ SigLevels lv;
+    __shared__ double rcp[SB_MAX_DEPTH + 1]; // 1 / n
+    if (tid == 0) {
+        lv.pw[0] = 1;
+        lv.off[0] = 0;
+        lv.off[1] = 0;
+        for (int k = 1; k <= depth; ++k) {
+            lv.pw[k] = lv.pw[k - 1] * C;
+            lv.off[k + 1] = lv.off[k] + lv.pw[k];
+        }
+        rcp[0] = 1.0;
+        for (int n = 1; n <= SB_MAX_DEPTH; ++n) rcp[n] = 1.0 / (double)n;
     }
+    __syncthreads();
     auto load_inc = [&](int t, double sign) { // D_t = x_t - x_{t-1} (x_{-1} = 0: the base point)
         if (tid < C)
             inc[tid] = sign * ((double)x[(size_t)t * C + tid] - (t > 0 ? (double)x[(size_t)(t - 1) * C + tid] : 0.0));
     };
     // dst = src (x) exp(inc): element (a_1 .. a_k) in Horner form, h_r = src_r[a_1..a_r] + h_{r-1} inc[a_r] / (k - r + 1)
+    if (TAB) {
+        for (int k = 1; k <= depth; ++k)
+            for (int e = tid; e < lv.pw[k]; e += nt)
+                for (int r = 1; r <= k; ++r) {
+                    const int pr = e / lv.pw[k - r];
+                    tab[(r - 1) * sigdim + lv.off[k] + e] = ((lv.off[r] + pr) << 8) | (pr % C);
+                }
+    }
     auto chen = [&](const double *src, double *dst) {
         for (int k = 1; k <= depth; ++k)
             for (int e = tid; e < lv.pw[k]; e += nt) {
                 double h = 1.0;
-                for (int r = 1; r <= k; ++r) {
-                    const int pr = e / lv.pw[k - r];
-                    h = src[lv.off[r] + pr] + h * inc[pr % C] / (double)(k - r + 1);
+                if (TAB) {
+                    const int *tp = tab + lv.off[k] + e;
+                    for (int r = 1; r <= k; ++r) {
+                        const int code = tp[(r - 1) * sigdim];
+                        h = __builtin_fma(h * inc[code & 255], rcp[k - r + 1], src[code >> 8]);
+                    }
+                } else {
+                    for (int r = 1; r <= k; ++r) {
+                        const int pr = e / lv.pw[k - r];
+                        h = __builtin_fma(h * inc[pr % C], rcp[k - r + 1], src[lv.off[r] + pr]);
+                    }
                 }
                 dst[lv.off[k] + e] = h;
             }
     };
+    // work units (a, m, r) of the exponential's adjoint, decoded once (TAB: C U <= SB_UNITS * threads)
+    int un_a[SB_UNITS], un_m[SB_UNITS], un_r[SB_UNITS], un_phi[SB_UNITS], un_plo[SB_UNITS];
+    double un_f[SB_UNITS];
+    auto decode_unit = [&](int u, int &a, int &m, int &r, int &phi, int &plo, double &rf) {
+        a = u / U;
+        int q = u % U;
+        m = 1;
+        while (q >= m) { // unit q of the triangle -> (m, r)
+            q -= m;
+            ++m;
+        }
+        r = q + 1;
+        phi = 0;
+        plo = 0; // offsets of P_{r-1} and P_{m-r}
+        for (int k = 0; k < r - 1; ++k) phi += lv.pw[k];
+        for (int k = 0; k < m - r; ++k) plo += lv.pw[k];
+        double fm = 1.0;
+        for (int k = 2; k <= m; ++k) fm *= (double)k;
+        rf = 1.0 / fm;
+    };
+    if (TAB) {
+#pragma unroll
+        for (int i = 0; i < SB_UNITS; ++i) {
+            const int u = tid + i * nt;
+            un_a[i] = un_m[i] = un_r[i] = 1, un_phi[i] = un_plo[i] = 0, un_f[i] = 0.0;
+            if (u < C * U) decode_unit(u, un_a[i], un_m[i], un_r[i], un_phi[i], un_plo[i], un_f[i]);
+        }
+    }
 
     // ---- forward: the signature of the whole path ----------------------------------------------------------------
     for (int e = tid; e < sigdim; e += nt) {
@@ -93,17 +159,18 @@ __global__ __launch_bounds__(256) void signature_bwd_kernel(const T *__restrict_
         }
         __syncthreads();
         // adjoint of the left factor: m rounds of contracting the last letter with D
-        double fact = 1.0;
+        double fact = 1.0, rfact = 1.0;
         double *a0 = A0, *a1 = A1;
         for (int m = 1; m < depth; ++m) {
             fact *= (double)m;
+            rfact = 1.0 / fact; // (uniform, once per round)
             for (int j = 1; j <= depth - m; ++j)
                 for (int w = tid; w < lv.pw[j]; w += nt) {
                     const double *src = a0 + lv.off[j + 1] + (size_t)w * C;
                     double s = 0.0;
                     for (int a = 0; a < C; ++a) s = __builtin_fma(src[a], inc[a], s);
                     a1[lv.off[j] + w] = s;
-                    Gn[lv.off[j] + w] += s / fact;
+                    Gn[lv.off[j] + w] += s * rfact;
                 }
             __syncthreads();
             double *tmp = a0;
@@ -128,25 +195,21 @@ __global__ __launch_bounds__(256) void signature_bwd_kernel(const T *__restrict_
             int poff = 0; // offset of P_{k-1}
             for (int k = 1; k < depth; ++k) {
                 const int noff = poff + lv.pw[k - 1];
-                for (int e = tid; e < lv.pw[k]; e += nt) a1[noff + e] = a1[poff + e / C] * inc[e % C];
+                for (int e = tid; e < lv.pw[k]; e += nt) {
+                    if (TAB) { // prefix (a_1 .. a_{k-1}) and last letter of element e of level k: row k - 2 (offset) / k - 1 (letter)
+                        const int last = tab[(k - 1) * sigdim + lv.off[k] + e] & 255;
+                        const int pre = k > 1 ? (tab[(k - 2) * sigdim + lv.off[k] + e] >> 8) - lv.off[k - 1] : 0;
+                        a1[noff + e] = a1[poff + pre] * inc[last];
+                    } else {
+                        a1[noff + e] = a1[poff + e / C] * inc[e % C];
+                    }
+                }
                 __syncthreads();
                 poff = noff;
             }
         }
         // adjoint of the exponential: work unit (a, m, r) sums over the words with letter a at position r
-        for (int u = tid; u < C * U; u += nt) {
-            const int a = u / U;
-            int q = u % U, m = 1;
-            while (q >= m) { // unit q of the triangle -> (m, r)
-                q -= m;
-                ++m;
-            }
-            const int r = q + 1;
-            int phi = 0, plo = 0; // offsets of P_{r-1} and P_{m-r}
-            for (int k = 0; k < r - 1; ++k) phi += lv.pw[k];
-            for (int k = 0; k < m - r; ++k) plo += lv.pw[k];
-            double fm = 1.0;
-            for (int k = 2; k <= m; ++k) fm *= (double)k;
+        auto unit_sum = [&](int a, int m, int r, int phi, int plo, double rf) {
             const double *de = a0 + lv.off[m];
             double s = 0.0;
             for (int hi = 0; hi < lv.pw[r - 1]; ++hi) {
@@ -156,7 +219,21 @@ __global__ __launch_bounds__(256) void signature_bwd_kernel(const T *__restrict_
                 for (int lo = 0; lo < lv.pw[m - r]; ++lo) sl = __builtin_fma(row[lo], a1[plo + lo], sl);
                 s = __builtin_fma(ph, sl, s);
             }
-            parts[u] = s / fm;
+            return s * rf;
+        };
+        if (TAB) {
+#pragma unroll
+            for (int i = 0; i < SB_UNITS; ++i) {
+                const int u = tid + i * nt;
+                if (u < C * U) parts[u] = unit_sum(un_a[i], un_m[i], un_r[i], un_phi[i], un_plo[i], un_f[i]);
+            }
+        } else {
+            for (int u = tid; u < C * U; u += nt) {
+                int a, m, r, phi, plo;
+                double rf;
+                decode_unit(u, a, m, r, phi, plo, rf);
+                parts[u] = unit_sum(a, m, r, phi, plo, rf);
+            }
         }
         __syncthreads();
         if (tid < C) {
@@ -185,10 +262,10 @@ int signature_bwd_launch(const void *X, const void *gsig, int N, int L, int C, i
         set_error("signature_backward: depth %d > %d or C=%d > 255", depth, SB_MAX_DEPTH, C);
         return SIGSVGD_E_UNSUPPORTED;
     }
-    const size_t lds = ((size_t)6 * sigdim + 2 * (size_t)C + (size_t)C * depth * (depth + 1) / 2) * sizeof(double);
-    if (sigdim < 0 || lds > 150 * 1024) {
+    const size_t lds0 = ((size_t)6 * sigdim + 2 * (size_t)C + (size_t)C * depth * (depth + 1) / 2) * sizeof(double);
+    if (sigdim < 0 || lds0 > 150 * 1024) {
         set_error("signature_backward: %lld channels (C=%d, depth=%d) need %zu B of LDS, more than the 150 KB this kernel uses",
-                  sigdim, C, depth, lds);
+                  sigdim, C, depth, lds0);
         return SIGSVGD_E_UNSUPPORTED;
     }
     if (!basepoint && L < 2) { // no increment at all: the signature is constant
@@ -196,24 +273,30 @@ int signature_bwd_launch(const void *X, const void *gsig, int N, int L, int C, i
         return e0 == hipSuccess ? SIGSVGD_OK : hip_fail(e0, "hipMemsetAsync(signature_backward)");
     }
     const int threads = sigdim <= 64 ? 64 : (sigdim <= 128 ? 128 : 256);
-    hipError_t e;
+    // the index table: depth rows of sigdim ints behind the working copies; offsets must fit 23 bits next to the letter byte
+    const size_t ldst = lds0 + (size_t)depth * sigdim * sizeof(int);
+    const bool tab = ldst <= 150 * 1024 && sigdim < (1 << 23) && C * depth * (depth + 1) / 2 <= SB_UNITS * threads;
+    const size_t lds = tab ? ldst : lds0;
+    hipError_t e = hipSuccess;
+    auto launch = [&](auto kern, auto *Xp, auto *gp, auto *op) {
+        if (lds > 64 * 1024) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return;
+        }
+        hipLaunchKernelGGL(kern, dim3(N), dim3(threads), lds, stream, Xp, gp, L, C, depth, basepoint, (int)sigdim, op);
+    };
     if (dtype == SIGSVGD_F64) {
-        if (lds > 64 * 1024) {
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&signature_bwd_kernel<double>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(signature_bwd_kernel)");
-        }
-        hipLaunchKernelGGL((signature_bwd_kernel<double>), dim3(N), dim3(threads), lds, stream, static_cast<const double *>(X),
-                           static_cast<const double *>(gsig), L, C, depth, basepoint, (int)sigdim, static_cast<double *>(gX));
+        auto *Xp = static_cast<const double *>(X), *gp = static_cast<const double *>(gsig);
+        auto *op = static_cast<double *>(gX);
+        if (tab) launch(&signature_bwd_kernel<double, true>, Xp, gp, op);
+        else launch(&signature_bwd_kernel<double, false>, Xp, gp, op);
     } else {
-        if (lds > 64 * 1024) {
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&signature_bwd_kernel<float>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(signature_bwd_kernel)");
-        }
-        hipLaunchKernelGGL((signature_bwd_kernel<float>), dim3(N), dim3(threads), lds, stream, static_cast<const float *>(X),
-                           static_cast<const float *>(gsig), L, C, depth, basepoint, (int)sigdim, static_cast<float *>(gX));
+        auto *Xp = static_cast<const float *>(X), *gp = static_cast<const float *>(gsig);
+        auto *op = static_cast<float *>(gX);
+        if (tab) launch(&signature_bwd_kernel<float, true>, Xp, gp, op);
+        else launch(&signature_bwd_kernel<float, false>, Xp, gp, op);
     }
+    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(signature_bwd_kernel)");
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "launch signature_bwd_kernel");
     return SIGSVGD_OK;

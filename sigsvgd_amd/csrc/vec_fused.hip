@@ -14,7 +14,8 @@
 // |x|^2 + |y|^2 - 2 x.y loses bits relative to the spread of the particles, not to their distance from the origin
 // (the reference uses the uncentred expansion for the unscaled kernels, math.py:69-86).  a_i, b_j are accumulated
 // from the staged tiles.  The columns are split over blockIdx.x (partial O and wsum are added with fp32 atomics into
-// the zeroed dK), so a launch has (A/64) x splits workgroups.  fp32 only, D <= 512.
+// the zeroed dK -- or, given a workspace, write them to per-split blocks that vec_join_kernel adds in split order: reproducible
+// bits), so a launch has (A/64) x splits workgroups.  fp32 only, D <= 512.
 #include "sig_common.h"
 
 namespace sigsvgd {
@@ -52,7 +53,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                                                         const float *__restrict__ XM, const float *__restrict__ YM,
                                                         const float *__restrict__ go, int A, int B, int D, int kind,
                                                         float half_inv_h2, float grad_scale, int tiles_per_split,
-                                                        float *__restrict__ Kout, float *__restrict__ dK)
+                                                        float *__restrict__ Kout, float *__restrict__ dK,
+                                                        float *__restrict__ part)
 {
     __shared__ __align__(16) float xs[FM * FKS], ys[FN * FKS];             // XM~ / Y~ stage  [row][k]
     __shared__ __align__(16) float xs2[METRIC ? FM * FKS : 4], ys2[METRIC ? FN * FKS : 4]; // X~ / YM~ stage
@@ -241,25 +243,58 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const int gi = row0 + 16 * wave + 4 * rk + r;
                 if (gi < A) {
                     const float xm = XMm[(size_t)gi * D + c] - cym;
-                    unsafeAtomicAdd(&dK[(size_t)gi * D + c], grad_scale * (xm * wsum[r] - O[n][r]));
+                    const float v = grad_scale * (xm * wsum[r] - O[n][r]);
+                    // reproducible route: this column split's partial sum goes to its own [A][D] block of the workspace (every
+                    // element of the block has exactly one writer) and vec_join_kernel adds the blocks in split order; without a
+                    // workspace the splits meet in fp32 atomics on the zeroed output (last bits depend on their order)
+                    if (part) part[((size_t)blockIdx.x * A + gi) * D + c] = v;
+                    else unsafeAtomicAdd(&dK[(size_t)gi * D + c], v);
                 }
             }
         }
     }
 }
 
-template <int NT>
-int fused_launch_nt(const float *X, const float *Y, const float *XM, const float *YM, const float *go, int A, int B, int D,
-                    int kind, float half_inv_h2, float grad_scale, float *K, float *dK, hipStream_t stream)
+// dK[e] = sum over the column splits of part[s][e], in split order (fixed: reproducible bits)
+__global__ __launch_bounds__(256) void vec_join_kernel(const float *__restrict__ part, int splits, size_t n, float *__restrict__ dK)
+{
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += part[(size_t)k * n + e];
+    dK[e] = s;
+}
+
+// column splits of a launch: enough workgroups for two per compute unit
+inline void fused_splits(int A, int B, bool grad, int &splits, int &per)
 {
     const int ntile = (B + FN - 1) / FN, rows = (A + FM - 1) / FM;
-    // enough workgroups for two per compute unit; the column splits add their partial sums with atomics
-    int splits = dK ? (512 + rows - 1) / rows : ntile;
+    splits = grad ? (512 + rows - 1) / rows : ntile;
     if (splits > ntile) splits = ntile;
     if (splits < 1) splits = 1;
-    const int per = (ntile + splits - 1) / splits;
+    per = (ntile + splits - 1) / splits;
     splits = (ntile + per - 1) / per;
-    if (dK) {
+}
+
+template <int NT>
+int fused_launch_nt(const float *X, const float *Y, const float *XM, const float *YM, const float *go, int A, int B, int D,
+                    int kind, float half_inv_h2, float grad_scale, float *K, float *dK, float *ws, size_t ws_bytes,
+                    hipStream_t stream)
+{
+    const int rows = (A + FM - 1) / FM;
+    int splits, per;
+    fused_splits(A, B, dK != nullptr, splits, per);
+    // the reproducible route needs one [A][D] block per split (none with a single split: it writes dK itself)
+    float *part = nullptr;
+    if (dK && splits == 1) {
+        part = dK;
+    } else if (dK && ws) {
+        if (ws_bytes < (size_t)splits * A * D * sizeof(float)) {
+            set_error("vec_kernel_fused: workspace %zu B < required %zu B", ws_bytes, (size_t)splits * A * D * sizeof(float));
+            return SIGSVGD_E_WORKSPACE;
+        }
+        part = ws;
+    } else if (dK) {
         hipError_t e = hipMemsetAsync(dK, 0, (size_t)A * D * sizeof(float), stream);
         if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(dK)");
     }
@@ -268,7 +303,7 @@ int fused_launch_nt(const float *X, const float *Y, const float *XM, const float
     const bool vec4 = (D % 4) == 0 && al(X) && al(Y) && al(XM) && al(YM);
 #define SIG_VF_LAUNCH(M, V)                                                                                           \
     hipLaunchKernelGGL((vec_fused_kernel<NT, M, V>), grid, block, 0, stream, X, Y, XM, YM, go, A, B, D, kind, half_inv_h2, \
-                       grad_scale, per, K, dK)
+                       grad_scale, per, K, dK, part)
     if (XM && vec4)
         SIG_VF_LAUNCH(true, true);
     else if (XM)
@@ -280,24 +315,38 @@ int fused_launch_nt(const float *X, const float *Y, const float *XM, const float
 #undef SIG_VF_LAUNCH
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "launch vec_fused_kernel");
+    if (part && part != dK) {
+        const size_t n = (size_t)A * D;
+        hipLaunchKernelGGL(vec_join_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, part, splits, n, dK);
+        e = hipGetLastError();
+        if (e != hipSuccess) return hip_fail(e, "launch vec_join_kernel");
+    }
     return SIGSVGD_OK;
 }
 } // namespace
 
+size_t vec_fused_workspace_bytes(int A, int B, int D)
+{
+    int splits, per;
+    fused_splits(A, B, true, splits, per);
+    return splits > 1 ? (size_t)splits * A * D * sizeof(float) : 0;
+}
+
 bool vec_fused_supported(int D, int dtype) { return dtype == SIGSVGD_F32 && D >= 1 && D <= 512; }
 
 int vec_fused_launch(const void *X, const void *Y, const void *XM, const void *YM, const void *go, int A, int B, int D,
-                     int kind, double inv_h2, double grad_scale, void *K, void *dK, hipStream_t stream)
+                     int kind, double inv_h2, double grad_scale, void *K, void *dK, void *ws, size_t ws_bytes, hipStream_t stream)
 {
+    float *w = static_cast<float *>(ws);
     const float *x = static_cast<const float *>(X), *y = static_cast<const float *>(Y);
     const float *xm = static_cast<const float *>(XM), *ym = static_cast<const float *>(YM);
     const float *g = static_cast<const float *>(go);
     float *k = static_cast<float *>(K), *dk = static_cast<float *>(dK);
     const float hh = (float)(0.5 * inv_h2), gs = (float)grad_scale;
-    if (D <= 64) return fused_launch_nt<4>(x, y, xm, ym, g, A, B, D, kind, hh, gs, k, dk, stream);
-    if (D <= 128) return fused_launch_nt<8>(x, y, xm, ym, g, A, B, D, kind, hh, gs, k, dk, stream);
-    if (D <= 256) return fused_launch_nt<16>(x, y, xm, ym, g, A, B, D, kind, hh, gs, k, dk, stream);
-    return fused_launch_nt<32>(x, y, xm, ym, g, A, B, D, kind, hh, gs, k, dk, stream);
+    if (D <= 64) return fused_launch_nt<4>(x, y, xm, ym, g, A, B, D, kind, hh, gs, k, dk, w, ws_bytes, stream);
+    if (D <= 128) return fused_launch_nt<8>(x, y, xm, ym, g, A, B, D, kind, hh, gs, k, dk, w, ws_bytes, stream);
+    if (D <= 256) return fused_launch_nt<16>(x, y, xm, ym, g, A, B, D, kind, hh, gs, k, dk, w, ws_bytes, stream);
+    return fused_launch_nt<32>(x, y, xm, ym, g, A, B, D, kind, hh, gs, k, dk, w, ws_bytes, stream);
 }
 
 } // namespace sigsvgd

@@ -392,10 +392,12 @@ def vec_fused_supported(X: torch.Tensor) -> bool:
 
 
 def vec_kernel_fused(X, Y, kind: int, inv_h2: float, grad_scale: float, XM=None, YM=None, grad_out=None,
-                     want_K: bool = True, want_grad: bool = True):
+                     want_K: bool = True, want_grad: bool = True, reproducible: bool = True):
     """(K[A,B] or None, dK[A,D] or None) for a GIVEN bandwidth in one launch (`sigsvgd_vec_kernel_fused`): the
     distance never goes to HBM and both GEMM-shaped sums run on the fp32 matrix cores.  XM / YM = X M / Y M for the
-    scaled kernels (both or neither)."""
+    scaled kernels (both or neither).  reproducible (default): the column splits of the launch store their partial sums
+    in a workspace and a second small launch adds them in a fixed order -- two calls return the same bits; False: one
+    launch, the splits meet in fp32 atomics."""
     L = _lib.load()
     dev = _require_gpu(X, Y, XM, YM, grad_out)
     Xc, Yc = _prep_vec(X, torch.float32), _prep_vec(Y, torch.float32)
@@ -417,9 +419,14 @@ def vec_kernel_fused(X, Y, kind: int, inv_h2: float, grad_scale: float, XM=None,
     K = torch.empty((A, B), dtype=torch.float32, device=dev) if want_K else None
     dK = torch.empty((A, D), dtype=torch.float32, device=dev) if want_grad else None
     p = lambda t: t.data_ptr() if t is not None else None
+    ws, wsn = None, 0
+    if want_grad and reproducible:  # per-split partial sums joined in a fixed order (the header's reproducible route)
+        nbytes = ctypes.c_size_t(0)
+        _lib.check(L.sigsvgd_vec_fused_workspace_bytes(A, B, D, ctypes.byref(nbytes)), "vec_fused_workspace_bytes")
+        ws, wsn = _workspace(dev, nbytes.value)
     with torch.cuda.device(dev):
         rc = L.sigsvgd_vec_kernel_fused(Xc.data_ptr(), Yc.data_ptr(), p(XMc), p(YMc), p(go), A, B, D, _lib.F32, int(kind),
-                                        float(inv_h2), float(grad_scale), p(K), p(dK), _stream_ptr(dev))
+                                        float(inv_h2), float(grad_scale), p(K), p(dK), p(ws), wsn, _stream_ptr(dev))
     _lib.check(rc, "vec_kernel_fused")
     return K, dK
 

@@ -75,6 +75,16 @@ def test_workspace_query_is_host_only(lib):
     assert lib.sigsvgd_gram_workspace_bytes(4, 4, 10, 3, 0, 0, 1, 0, None) == -1
 
 
+def test_vec_fused_workspace_query(lib):
+    """ABI 9: scratch of the reproducible route of the fused vector kernel = one [A][D] fp32 block per column split"""
+    n = ctypes.c_size_t(0)
+    assert lib.sigsvgd_vec_fused_workspace_bytes(1024, 1024, 448, ctypes.byref(n)) == 0
+    assert n.value > 0 and n.value % (1024 * 448 * 4) == 0 and n.value // (1024 * 448 * 4) <= 16  # (16 column tiles of 64)
+    assert lib.sigsvgd_vec_fused_workspace_bytes(64, 64, 7, ctypes.byref(n)) == 0 and n.value == 0  # one split: nothing to join
+    assert lib.sigsvgd_vec_fused_workspace_bytes(0, 64, 7, ctypes.byref(n)) == -1
+    assert lib.sigsvgd_vec_fused_workspace_bytes(64, 64, 7, None) == -1
+
+
 def test_workspace_query_covers_every_pair_kernel(lib):
     """one query per kernel family (register-resident, quadrant, refined-grid, band, coverage), gradient and forward-only:
     status 0 and a size; the kernels that flag cancelled pairs for the fp64 pass need A * B bytes of flags even forward-only"""

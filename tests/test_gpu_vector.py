@@ -354,6 +354,32 @@ def test_vec_kernel_fused_fp32_vs_oracle(gpu, A, B, D, kind, offset):
     assert none is None and rel(dK2, want) < 2e-5
 
 
+@pytest.mark.parametrize("A,B,D", [(1024, 1024, 448), (700, 513, 64), (130, 130, 129), (64, 64, 7)])
+def test_vec_kernel_fused_is_reproducible_with_its_workspace(gpu, A, B, D):
+    """ABI 9: given its workspace the fused kernel stores one partial dK per column split and adds them in split order --
+    three calls, another stream busy with GEMMs, return the same bits; the one-launch route (atomics) agrees to rounding"""
+    from sigsvgd_amd import _lib, ops
+
+    rng = np.random.default_rng(A + B + D)
+    X = torch.as_tensor(rng.normal(size=(A, D)).astype(np.float32), device=gpu)
+    Y = torch.as_tensor(rng.normal(size=(B, D)).astype(np.float32), device=gpu)
+    h = float(np.sqrt(D))
+    side = torch.cuda.Stream()
+    junk = torch.randn(1024, 1024, device=gpu)
+    outs = []
+    for _ in range(3):
+        with torch.cuda.stream(side):
+            for _ in range(4):
+                junk = (junk @ junk).clamp_(-1, 1)
+        outs.append(ops.vec_kernel_fused(X, Y, _lib.VEC_GAUSSIAN, 1 / h**2, -1 / h**2))
+    torch.cuda.synchronize()
+    for K, dK in outs[1:]:
+        assert torch.equal(K, outs[0][0]) and torch.equal(dK, outs[0][1])
+    Ka, dKa = ops.vec_kernel_fused(X, Y, _lib.VEC_GAUSSIAN, 1 / h**2, -1 / h**2, reproducible=False)
+    assert torch.equal(Ka, outs[0][0])
+    assert float((dKa - outs[0][1]).abs().max() / outs[0][1].abs().max()) < 2e-6
+
+
 def test_vec_kernel_fused_metric_and_classes(gpu):
     """Scaled kernels (a non-symmetric metric included) through the fused launch, and the drop-in classes route a
     fixed bandwidth (argument or constant bandwidth_fn) to it with the same results as the two-launch path."""
