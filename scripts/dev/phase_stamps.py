@@ -1,6 +1,6 @@
 """Diagnostic build of the library with in-kernel phase stamps (-DSIGSVGD_PHASE_STAMPS): where a wave of
-gram_fast_kernel spends its cycles.  Builds ab/libsigsvgd_stamps.so (git-ignored scratch directory that travels to the GPU
-box; never the product library, and not inside the package) and
+gram_fast_kernel spends its cycles.  Builds sigsvgd_amd/_exp/libsigsvgd_stamps.so (git-ignored scratch directory that travels to the GPU
+box while it exists; never the product library; delete it after the profiling pass) and
 runs a few launches; the library prints the split to stderr after each launch.
 usage (on the GPU box): python scripts/dev/phase_stamps.py [N T d [sym|ordered|fwd|fwdsym|dyadic<k>]]      (build only: --build)"""
 import os
@@ -9,16 +9,14 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-OUT = os.environ.get("SIGSVGD_STAMPS_LIB") or os.path.join(ROOT, "ab", "libsigsvgd_stamps.so")
+OUT = os.environ.get("SIGSVGD_STAMPS_LIB") or os.path.join(ROOT, "sigsvgd_amd", "_exp", "libsigsvgd_stamps.so")
 
 
 def build():
     from sigsvgd_amd import _lib
 
-    cmd = [_lib._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DSIGSVGD_PHASE_STAMPS",
-           "-o", OUT] + [os.path.join(_lib._CSRC, s) for s in _lib.SOURCES] + ["-ldl"]
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    subprocess.run(cmd, check=True)
+    _lib.build(out_path=OUT, objdir=os.path.join(os.path.dirname(OUT), "_obj_stamps"), defines=("SIGSVGD_PHASE_STAMPS",))
 
 
 if __name__ == "__main__":

@@ -23,6 +23,8 @@
 // pass reads the same table), the reciprocals are multiplied, and each thread decodes its work units of the exponential's
 // adjoint once, before the point loop.  Signatures whose table does not fit next to the six working copies keep the decoding
 // per point (TAB = false).
+#include <type_traits>
+
 #include "sig_common.h"
 
 namespace sigsvgd {
@@ -37,10 +39,13 @@ struct SigLevels {
 
 constexpr int SB_UNITS = 4; // work units of the exponential's adjoint a thread can keep decoded (C depth (depth + 1) / 2 <= 4 threads)
 
-template <typename T, bool TAB>
+// DEPTH > 0: the truncation depth as a compile-time constant -- every loop over levels unrolls and the level tables (C^k and
+// the level offsets) are scalar registers; DEPTH = 0: any depth up to SB_MAX_DEPTH, tables in LDS (a load per loop bound).
+template <typename T, bool TAB, int DEPTH>
 __global__ __launch_bounds__(256) void signature_bwd_kernel(const T *__restrict__ X, const T *__restrict__ gsig, int L, int C,
-                                                            int depth, int basepoint, int sigdim, T *__restrict__ gX)
+                                                            int depth_arg, int basepoint, int sigdim, T *__restrict__ gX)
 {
+    const int depth = DEPTH > 0 ? DEPTH : depth_arg;
     extern __shared__ double sb_lds[];
     double *S = sb_lds, *Sn = S + sigdim, *G = Sn + sigdim, *Gn = G + sigdim, *A0 = Gn + sigdim, *A1 = A0 + sigdim;
     double *inc = A1 + sigdim, *gnext = inc + C, *parts = gnext + C; // parts: [C][depth (depth + 1) / 2]
@@ -52,51 +57,69 @@ __global__ __launch_bounds__(256) void signature_bwd_kernel(const T *__restrict_
     T *gx = gX + (size_t)blockIdx.x * L * C;
     const int U = depth * (depth + 1) / 2;
 
-    // (in LDS: as private arrays indexed by run-time levels they lived in scratch memory, one scratch load per use)
-    __shared__ SigLevels lv;
-    __shared__ double rcp[SB_MAX_DEPTH + 1]; // 1 / n
-    if (tid == 0) {
-        lv.pw[0] = 1;
-        lv.off[0] = 0;
-        lv.off[1] = 0;
-        for (int k = 1; k <= depth; ++k) {
-            lv.pw[k] = lv.pw[k - 1] * C;
-            lv.off[k + 1] = lv.off[k] + lv.pw[k];
-        }
-        rcp[0] = 1.0;
-        for (int n = 1; n <= SB_MAX_DEPTH; ++n) rcp[n] = 1.0 / (double)n;
+    // (run-time depth: in LDS -- as private arrays indexed by run-time levels they lived in scratch memory, one scratch load
+    //  per use; compile-time depth: private, every index is a constant after unrolling)
+    __shared__ SigLevels lv_lds;
+    __shared__ double rcp_lds[SB_MAX_DEPTH + 1]; // 1 / n
+    SigLevels lv_reg;
+    double rcp_reg[SB_MAX_DEPTH + 1];
+    lv_reg.pw[0] = 1;
+    lv_reg.off[0] = 0;
+    lv_reg.off[1] = 0;
+    rcp_reg[0] = 1.0;
+#pragma unroll
+    for (int k = 1; k <= SB_MAX_DEPTH; ++k) {
+        lv_reg.pw[k] = lv_reg.pw[k - 1] * C;
+        lv_reg.off[k + 1] = lv_reg.off[k] + lv_reg.pw[k];
+        rcp_reg[k] = 1.0 / (double)k;
+    }
+    if (tid == 0) { // (the LDS copy serves every index that is not a constant after unrolling: the work units' (m, r))
+        lv_lds = lv_reg;
+        for (int n = 0; n <= SB_MAX_DEPTH; ++n) rcp_lds[n] = rcp_reg[n];
     }
     __syncthreads();
+    struct Lv {
+        const SigLevels &r, &l;
+        const double *rr, *rl;
+        __device__ __forceinline__ int pw_(int k) const { return (DEPTH > 0 && __builtin_constant_p(k)) ? r.pw[k] : l.pw[k]; }
+        __device__ __forceinline__ int off_(int k) const { return (DEPTH > 0 && __builtin_constant_p(k)) ? r.off[k] : l.off[k]; }
+        __device__ __forceinline__ double rcp_(int n) const { return (DEPTH > 0 && __builtin_constant_p(n)) ? rr[n] : rl[n]; }
+    };
+    const Lv lv{lv_reg, lv_lds, rcp_reg, rcp_lds};
     auto load_inc = [&](int t, double sign) { // D_t = x_t - x_{t-1} (x_{-1} = 0: the base point)
         if (tid < C)
             inc[tid] = sign * ((double)x[(size_t)t * C + tid] - (t > 0 ? (double)x[(size_t)(t - 1) * C + tid] : 0.0));
     };
     // dst = src (x) exp(inc): element (a_1 .. a_k) in Horner form, h_r = src_r[a_1..a_r] + h_{r-1} inc[a_r] / (k - r + 1)
     if (TAB) {
+#pragma unroll
         for (int k = 1; k <= depth; ++k)
-            for (int e = tid; e < lv.pw[k]; e += nt)
+            for (int e = tid; e < lv.pw_(k); e += nt)
+#pragma unroll
                 for (int r = 1; r <= k; ++r) {
-                    const int pr = e / lv.pw[k - r];
-                    tab[(r - 1) * sigdim + lv.off[k] + e] = ((lv.off[r] + pr) << 8) | (pr % C);
+                    const int pr = e / lv.pw_(k - r);
+                    tab[(r - 1) * sigdim + lv.off_(k) + e] = ((lv.off_(r) + pr) << 8) | (pr % C);
                 }
     }
     auto chen = [&](const double *src, double *dst) {
+#pragma unroll
         for (int k = 1; k <= depth; ++k)
-            for (int e = tid; e < lv.pw[k]; e += nt) {
+            for (int e = tid; e < lv.pw_(k); e += nt) {
                 double h = 1.0;
                 if (TAB) {
-                    const int *tp = tab + lv.off[k] + e;
+                    const int *tp = tab + lv.off_(k) + e;
+#pragma unroll
                     for (int r = 1; r <= k; ++r) {
                         const int code = tp[(r - 1) * sigdim];
-                        h = __builtin_fma(h * inc[code & 255], rcp[k - r + 1], src[code >> 8]);
+                        h = __builtin_fma(h * inc[code & 255], lv.rcp_(k - r + 1), src[code >> 8]);
                     }
                 } else {
                     for (int r = 1; r <= k; ++r) {
-                        const int pr = e / lv.pw[k - r];
-                        h = __builtin_fma(h * inc[pr % C], rcp[k - r + 1], src[lv.off[r] + pr]);
+                        const int pr = e / lv.pw_(k - r);
+                        h = __builtin_fma(h * inc[pr % C], lv.rcp_(k - r + 1), src[lv.off_(r) + pr]);
                     }
                 }
-                dst[lv.off[k] + e] = h;
+                dst[lv.off_(k) + e] = h;
             }
     };
     // work units (a, m, r) of the exponential's adjoint, decoded once (TAB: C U <= SB_UNITS * threads)
@@ -113,8 +136,8 @@ __global__ __launch_bounds__(256) void signature_bwd_kernel(const T *__restrict_
         r = q + 1;
         phi = 0;
         plo = 0; // offsets of P_{r-1} and P_{m-r}
-        for (int k = 0; k < r - 1; ++k) phi += lv.pw[k];
-        for (int k = 0; k < m - r; ++k) plo += lv.pw[k];
+        for (int k = 0; k < r - 1; ++k) phi += lv.pw_(k);
+        for (int k = 0; k < m - r; ++k) plo += lv.pw_(k);
         double fm = 1.0;
         for (int k = 2; k <= m; ++k) fm *= (double)k;
         rf = 1.0 / fm;
@@ -161,16 +184,18 @@ __global__ __launch_bounds__(256) void signature_bwd_kernel(const T *__restrict_
         // adjoint of the left factor: m rounds of contracting the last letter with D
         double fact = 1.0, rfact = 1.0;
         double *a0 = A0, *a1 = A1;
+#pragma unroll
         for (int m = 1; m < depth; ++m) {
             fact *= (double)m;
             rfact = 1.0 / fact; // (uniform, once per round)
+#pragma unroll
             for (int j = 1; j <= depth - m; ++j)
-                for (int w = tid; w < lv.pw[j]; w += nt) {
-                    const double *src = a0 + lv.off[j + 1] + (size_t)w * C;
+                for (int w = tid; w < lv.pw_(j); w += nt) {
+                    const double *src = a0 + lv.off_(j + 1) + (size_t)w * C;
                     double s = 0.0;
                     for (int a = 0; a < C; ++a) s = __builtin_fma(src[a], inc[a], s);
-                    a1[lv.off[j] + w] = s;
-                    Gn[lv.off[j] + w] += s * rfact;
+                    a1[lv.off_(j) + w] = s;
+                    Gn[lv.off_(j) + w] += s * rfact;
                 }
             __syncthreads();
             double *tmp = a0;
@@ -179,26 +204,29 @@ __global__ __launch_bounds__(256) void signature_bwd_kernel(const T *__restrict_
         }
         // adjoint of the right factor, dE_m[v] (into a0), and the monomials P_k[w] = prod of D over the letters of w (into
         // a1: levels 0 .. depth-1 at offsets 0, 1, 1 + C, ...)
+#pragma unroll
         for (int m = 1; m <= depth; ++m)
-            for (int v = tid; v < lv.pw[m]; v += nt) {
-                double s = G[lv.off[m] + v];
+            for (int v = tid; v < lv.pw_(m); v += nt) {
+                double s = G[lv.off_(m) + v];
+#pragma unroll
                 for (int j = 1; j <= depth - m; ++j) {
-                    const double *sp = Sn + lv.off[j];
-                    const double *gp = G + lv.off[j + m] + v;
-                    for (int w = 0; w < lv.pw[j]; ++w) s = __builtin_fma(sp[w], gp[(size_t)w * lv.pw[m]], s);
+                    const double *sp = Sn + lv.off_(j);
+                    const double *gp = G + lv.off_(j + m) + v;
+                    for (int w = 0; w < lv.pw_(j); ++w) s = __builtin_fma(sp[w], gp[(size_t)w * lv.pw_(m)], s);
                 }
-                a0[lv.off[m] + v] = s;
+                a0[lv.off_(m) + v] = s;
             }
         if (tid == 0) a1[0] = 1.0;
         __syncthreads();
         {
             int poff = 0; // offset of P_{k-1}
+#pragma unroll
             for (int k = 1; k < depth; ++k) {
-                const int noff = poff + lv.pw[k - 1];
-                for (int e = tid; e < lv.pw[k]; e += nt) {
+                const int noff = poff + lv.pw_(k - 1);
+                for (int e = tid; e < lv.pw_(k); e += nt) {
                     if (TAB) { // prefix (a_1 .. a_{k-1}) and last letter of element e of level k: row k - 2 (offset) / k - 1 (letter)
-                        const int last = tab[(k - 1) * sigdim + lv.off[k] + e] & 255;
-                        const int pre = k > 1 ? (tab[(k - 2) * sigdim + lv.off[k] + e] >> 8) - lv.off[k - 1] : 0;
+                        const int last = tab[(k - 1) * sigdim + lv.off_(k) + e] & 255;
+                        const int pre = k > 1 ? (tab[(k - 2) * sigdim + lv.off_(k) + e] >> 8) - lv.off_(k - 1) : 0;
                         a1[noff + e] = a1[poff + pre] * inc[last];
                     } else {
                         a1[noff + e] = a1[poff + e / C] * inc[e % C];
@@ -210,13 +238,13 @@ __global__ __launch_bounds__(256) void signature_bwd_kernel(const T *__restrict_
         }
         // adjoint of the exponential: work unit (a, m, r) sums over the words with letter a at position r
         auto unit_sum = [&](int a, int m, int r, int phi, int plo, double rf) {
-            const double *de = a0 + lv.off[m];
+            const double *de = a0 + lv.off_(m);
             double s = 0.0;
-            for (int hi = 0; hi < lv.pw[r - 1]; ++hi) {
+            for (int hi = 0; hi < lv.pw_(r - 1); ++hi) {
                 const double ph = a1[phi + hi];
-                const double *row = de + (size_t)hi * lv.pw[m - r + 1] + (size_t)a * lv.pw[m - r];
+                const double *row = de + (size_t)hi * lv.pw_(m - r + 1) + (size_t)a * lv.pw_(m - r);
                 double sl = 0.0;
-                for (int lo = 0; lo < lv.pw[m - r]; ++lo) sl = __builtin_fma(row[lo], a1[plo + lo], sl);
+                for (int lo = 0; lo < lv.pw_(m - r); ++lo) sl = __builtin_fma(row[lo], a1[plo + lo], sl);
                 s = __builtin_fma(ph, sl, s);
             }
             return s * rf;
@@ -285,17 +313,20 @@ int signature_bwd_launch(const void *X, const void *gsig, int N, int L, int C, i
         }
         hipLaunchKernelGGL(kern, dim3(N), dim3(threads), lds, stream, Xp, gp, L, C, depth, basepoint, (int)sigdim, op);
     };
-    if (dtype == SIGSVGD_F64) {
-        auto *Xp = static_cast<const double *>(X), *gp = static_cast<const double *>(gsig);
-        auto *op = static_cast<double *>(gX);
-        if (tab) launch(&signature_bwd_kernel<double, true>, Xp, gp, op);
-        else launch(&signature_bwd_kernel<double, false>, Xp, gp, op);
-    } else {
-        auto *Xp = static_cast<const float *>(X), *gp = static_cast<const float *>(gsig);
-        auto *op = static_cast<float *>(gX);
-        if (tab) launch(&signature_bwd_kernel<float, true>, Xp, gp, op);
-        else launch(&signature_bwd_kernel<float, false>, Xp, gp, op);
-    }
+    auto dispatch = [&](auto *Xp, auto *gp, auto *op) {
+        using TT = std::remove_cv_t<std::remove_pointer_t<decltype(op)>>;
+        if (!tab) return launch(&signature_bwd_kernel<TT, false, 0>, Xp, gp, op);
+        switch (depth) { // (the depths the reference's kernels use, unrolled; others through the run-time form)
+        case 2: return launch(&signature_bwd_kernel<TT, true, 2>, Xp, gp, op);
+        case 3: return launch(&signature_bwd_kernel<TT, true, 3>, Xp, gp, op);
+        case 4: return launch(&signature_bwd_kernel<TT, true, 4>, Xp, gp, op);
+        default: return launch(&signature_bwd_kernel<TT, true, 0>, Xp, gp, op);
+        }
+    };
+    if (dtype == SIGSVGD_F64)
+        dispatch(static_cast<const double *>(X), static_cast<const double *>(gsig), static_cast<double *>(gX));
+    else
+        dispatch(static_cast<const float *>(X), static_cast<const float *>(gsig), static_cast<float *>(gX));
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(signature_bwd_kernel)");
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "launch signature_bwd_kernel");
