@@ -38,8 +38,8 @@ N, T, D_CH, H, LR = 1024, 64, 7, 1.0, 1e-3
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VALU_PEAK_TF = 78.6       # vector fp64: 256 CU x 4 SIMD x 16 FMA lanes x 2 x 2.4 GHz
 PROFILES = os.path.join(ROOT, "profiles")
-PMC_TRAFFIC_CSV = os.path.join(PROFILES, "r03_pmc_hbm_traffic.csv")   # written by scripts/pmc_summary.py
-PMC_SQ_CSV = os.path.join(PROFILES, "r03_sq_counters_gram_fast.csv")
+PMC_TRAFFIC_CSV = os.path.join(PROFILES, "r04_pmc_hbm_traffic.csv")   # written by scripts/pmc_summary.py
+PMC_SQ_CSV = os.path.join(PROFILES, "r04_sq_counters_gram_fast.csv")
 
 
 class HipBackend:
