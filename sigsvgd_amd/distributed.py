@@ -52,20 +52,21 @@ def all_gather_rows(shard: torch.Tensor, group=None, out: Optional[torch.Tensor]
     return out
 
 
-def all_gather_rows_pair(a: torch.Tensor, b: torch.Tensor, out_a: torch.Tensor, out_b: torch.Tensor, group=None) -> None:
+def all_gather_rows_pair(a: torch.Tensor, b: torch.Tensor, out_a: torch.Tensor, out_b: torch.Tensor, group=None) -> bool:
     """Two all-gathers (same shard shape) into their own contiguous outputs as one grouped collective where the backend has
-    one (RCCL: ncclGroupStart / ncclGroupEnd, a single launch); otherwise back to back."""
+    one (RCCL: ncclGroupStart / ncclGroupEnd, a single launch); otherwise back to back.  Returns whether the grouped form ran."""
     a, b = a.contiguous(), b.contiguous()
     if dist.get_backend(group) == "nccl" and hasattr(dist, "_coalescing_manager"):
         try:
             with dist._coalescing_manager(group=group, device=a.device, async_ops=False):
                 dist.all_gather_into_tensor(out_a, a, group=group)
                 dist.all_gather_into_tensor(out_b, b, group=group)
-            return
+            return True
         except (RuntimeError, TypeError, NotImplementedError):  # a torch build without the grouped form for this op
             pass
     dist.all_gather_into_tensor(out_a, a, group=group)
     dist.all_gather_into_tensor(out_b, b, group=group)
+    return False
 
 
 def reduce_scatter_rows(full: torch.Tensor, group=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -145,6 +146,7 @@ class ShardedSigSVGD:
         self.last_K_partial = None  # ALIASES the step's preallocated buffer: the next step() overwrites it (clone to keep it)
         self.last_K_rows = None
         self.phase_ms = None  # filled by step(profile=True): milliseconds per phase on this rank
+        self.last_gather_grouped = None  # whether the last step's two all-gathers went out as one grouped collective
         self._buf = {}        # per-step buffers, allocated once per (shape, dtype, device)
 
     def _buffers(self, X_shard: torch.Tensor, world: int):
@@ -173,7 +175,7 @@ class ShardedSigSVGD:
         buf = self._buffers(X_shard, world)
         # one grouped collective into preallocated, contiguous operands (no stack / split copies)
         X_full, s_full = buf["X_full"], buf["s_full"]
-        all_gather_rows_pair(X_shard, score_shard.to(X_shard.dtype), X_full, s_full, self.group)
+        self.last_gather_grouped = all_gather_rows_pair(X_shard, score_shard.to(X_shard.dtype), X_full, s_full, self.group)
         if mark:
             mark("all_gather")
         if self.rowwise or not self._partial_supported(X_full):

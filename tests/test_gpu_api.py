@@ -387,6 +387,7 @@ def test_sharded_step_on_rccl_single_rank(gpu):
         Xg, sg = X.to(gpu), s.to(gpu)
         sh = ShardedSigSVGD(1.0, 1e-2)
         Xa = sh.step(Xg, sg)
+        assert sh.last_gather_grouped is True  # X and score went out as ONE grouped RCCL collective (distributed.py, step 1)
         Kd = sh.gather_gram()
         K, g = ops.gram_fwd_bwd(Xg, Xg, 1.0, y_is_x=True)
         _, Xb = ops.svgd_phi(K, sg, g, X=Xg, lr=1e-2)
