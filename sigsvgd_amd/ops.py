@@ -121,7 +121,10 @@ def gram_fwd_bwd(X, Y, inv_h: float, dyadic_order: int = 0, static_kind: int = _
     Bit-reproducible: every reduction over pairs runs in an order fixed by the launch geometry (no floating-point
     atomics), so two calls on the same input -- eager or replayed from a captured graph -- return the same bits.
 
-    Every kernel behind this call keeps the forward solution, so there is no limit on how rough the paths may be.
+    Accuracy (include/sigsvgd_hip.h): every entry of K within 1e-5 of the fp64 reference's, relative to max(|K|, 0.1) --
+    the fp32-sweep kernels check every pair for cancellation and for its conditioning in the increments and hand the pairs
+    that fail to an exact fp64 pass inside the same call; the gradient of such a pair keeps the fp32 solution (its error is
+    relative to the largest gradient entry of the launch).  `force_generic=True`: fp64 sweeps for K and the gradient alike.
     `check_regime` and `stored_forward` are accepted for callers written against earlier versions (when long paths
     could run on a kernel that regenerated the forward solution and declined rough pairs) and have no effect."""
     L = _lib.load()

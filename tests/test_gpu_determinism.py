@@ -12,7 +12,10 @@ pytestmark = pytest.mark.gpu
 # register-resident kernel (8- and 4-row tiles, 32-slot ring, d > 8), quadrant kernel (both channel layouts, the global row
 # accumulator of d = 15, 16), coverage kernel (ordered pairs, and the symmetric solve from 4096 pairs on)
 SHAPES = [((96, 64, 7), 0), ((80, 32, 7), 0), ((40, 48, 12), 0), ((300, 20, 3), 0), ((24, 128, 14), 0), ((20, 100, 7), 0),
-          ((12, 70, 16), 0), ((16, 20, 2), 2), ((72, 10, 2), 3)]
+          ((12, 70, 16), 0), ((16, 20, 2), 2), ((72, 10, 2), 3),
+          # round 4 (ADVICE): the band kernel (129 .. 256 refined cells) and the refined-grid kernel at dyadic order 5 / 6, whose
+          # forced flush of the block sums (r lanes of a row block on one coarse cell) became a fixed butterfly
+          ((100, 10, 2), 4), ((35, 30, 2), 3), ((30, 5, 2), 5), ((20, 3, 7), 6), ((24, 33, 9), 1)]
 
 
 def _disturb(dev):
@@ -87,3 +90,23 @@ def test_two_captured_graphs_step_only_the_second(gpu):
     torch.cuda.synchronize()
     assert torch.equal(gb.K, K) and torch.equal(gb.grad_k, gk) and torch.equal(gb.X, Xn)
     assert ga.iterations == 0
+
+
+@pytest.mark.parametrize("N,T,d,scale,h", [(40, 64, 1, 0.2, 0.1), (30, 100, 2, 0.3, 0.3), (48, 32, 3, 0.1, 0.1)])
+def test_flagged_pairs_and_their_exact_pass_are_reproducible(gpu, N, T, d, scale, h):
+    """rough paths in few channels: many pairs are flagged (cancellation / conditioning) and solved again by the coverage
+    kernel's fp64 pass after the launch -- the flags, the repaired entries and the gradient are the same bits call after call"""
+    import numpy as np
+
+    from sigsvgd_amd import ops
+
+    rng = np.random.default_rng(N + T)
+    X = torch.as_tensor(np.cumsum(scale * rng.standard_normal((N, T, d)), axis=1).astype(np.float32), device=gpu)
+    outs = []
+    for _ in range(3):
+        side, keep = _disturb(gpu)
+        outs.append(ops.gram_fwd_bwd(X, X, 1.0 / h, 0, y_is_x=True) + (ops.gram_fwd(X, X.clone(), 1.0 / h, 0),))
+        side.synchronize()
+        del keep
+    for K, g, Kf in outs[1:]:
+        assert torch.equal(K, outs[0][0]) and torch.equal(g, outs[0][1]) and torch.equal(Kf, outs[0][2])
