@@ -50,9 +50,11 @@
  *           in the increments, sum |K_fwd U D| / max(|K|, 0.1), exceeds 150 (forward-only launches: the bound
  *           sum |K_fwd D| max(grid maximum, 1) / max(|K|, 0.1) exceeds 300): there the fp32 STORAGE of the
  *           increments limits K whatever the precision of the sweeps.
- *     Measured bound: every entry of K_out within 1e-5 of the fp64 reference's,
- *     relative to max(|K|, 0.1), over the committed rough-path cases and the random soak; unflagged pairs
- *     of the calibration study are within 2.5e-6.  Only K is repaired: the gradient of a flagged pair keeps
+ *     Measured bound (DESIGN.md sections 2, 3): every entry of K_out within 1e-5 RELATIVE of the fp64
+ *     reference's (plain |K - K_ref| / |K_ref|, no floor) over the committed rough-path cases and 18,000
+ *     random soak cases; unflagged pairs of the calibration study are within 2.5e-6.  (The 8- / 16-channel
+ *     kernels for T <= 64 have no exact pass: their cancelled pairs repeat the sweep in fp64 on fp32
+ *     increments, enough in every case seen with d >= 5.)  Only K is repaired: the gradient of a flagged pair keeps
  *     the fp32 solution (its error is relative to the largest gradient entry of the launch and stayed
  *     below 5e-6 of it in every regime measured).  SIGSVGD_FLAG_FORCE_GENERIC returns 6e-8 anywhere.
  *   - results are bit-reproducible: every reduction over pairs runs in an order fixed by the launch

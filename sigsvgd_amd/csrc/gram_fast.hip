@@ -63,7 +63,7 @@ struct FastArgs {
     TileMap tm;                   // row tiles owned by this launch, in the order of the enumeration (multi-GPU sharding)
     long long nitems;             // (owned row tile, column) items of the launch
     double inv_h;
-    unsigned char *kflag;         // [A][B] (d <= 3 only): 1 where the pair's fp32 solution cancelled or K is ill-conditioned in
+    unsigned char *kflag;         // [A][B] (d <= 4 only): 1 where the pair's fp32 solution cancelled or K is ill-conditioned in
                                   // the increments: the launcher lets the coverage kernel solve those pairs exactly (fp64)
 #ifdef SIGSVGD_PHASE_STAMPS
     unsigned long long *stamps; // diagnostic build only: [8] shader-clock totals per phase, summed over waves
@@ -663,7 +663,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
                     const float kf1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cur), 32 + P - 1));
                     kf = (lane >> 5) ? kf1 : kf;
                 }
-                // Paths in one to three channels (the 4-channel instantiations; the launcher passes a flag array for d <= 3 only):
+                // Paths in one to four channels (the 4-channel instantiations; the launcher passes a flag array for d <= 4 only --
+                // d = 4 since a soak case with T = 33, d = 4 showed an entry of |K| ~ 0.005 off by 1.7e-5 RELATIVE after the fp64
+                // re-sweep on fp32 increments: tiny entries need the exact pass whatever their conditioning):
                 // the fp64 re-sweep below runs on fp32 increments, which is not enough where the discrete solution is
                 // ill-conditioned, so such pairs are flagged for the EXACT fp64 pass of the coverage kernel that follows the
                 // launch (fp64 static kernel, increments and sweeps: 6e-8).  Two rules, either one flags the pair:
@@ -822,7 +824,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
                     for (int k0 = 56; k0 >= 0; k0 -= 8) sweep_rev8(cur, downA, downB, V, &Dsl[k0 & RM], &Ksl[k0 & RM], mk + k0, r3);
                 }
 
-                // ---- conditioning (4-channel kernels with a flag array, i.e. d <= 3): c1 = sum |S * D| / max(|K|, 0.1) ------
+                // ---- conditioning (4-channel kernels with a flag array, i.e. d <= 4): c1 = sum |S * D| / max(|K|, 0.1) ------
                 // The slots hold S = K_fwd * U (0 where there is no cell) and gamma = D / sqrt(12): 64 multiply-adds per lane, a
                 // wave sum, one byte per pair (see phase 2 for the rule and its measurement).  C3 (d = 3): +1.2 % instructions.
                 if constexpr (DPAD == 4) {
@@ -1119,10 +1121,10 @@ FastGeom fast_geometry(int A, int B, int T, int d, bool sym)
 int sym_tile_rows_fast(int T, int d) { return grad_nw(T, d); }
 
 namespace {
-// (the flag array of the exact fp64 pass: launches with paths in one to three channels only, see the kernel)
+// (the flag array of the exact fp64 pass: the 4-channel instantiations, i.e. paths in one to four channels; see the kernel)
 inline size_t fast_flag_bytes(int A, int B, int d)
 {
-    return d <= 3 ? (((size_t)A * B + 255) & ~(size_t)255) + generic_repair_bytes() : 0;
+    return d <= 4 ? (((size_t)A * B + 255) & ~(size_t)255) + generic_repair_bytes() : 0;
 }
 } // namespace
 
@@ -1235,7 +1237,7 @@ int run_grad(const GramProblem &p, FastArgs &a, bool sym, void *out, int out64)
         return SIGSVGD_E_WORKSPACE;
     }
     unsigned char *base = reinterpret_cast<unsigned char *>((reinterpret_cast<uintptr_t>(p.ws) + 255) & ~(uintptr_t)255);
-    a.kflag = p.d <= 3 ? base : nullptr;
+    a.kflag = p.d <= 4 ? base : nullptr;
     base += fast_flag_bytes(p.A, p.B, p.d);
     a.rseg = reinterpret_cast<double *>(base);
     a.cslab = sym ? reinterpret_cast<float *>(base + g.rseg_bytes) : nullptr;
@@ -1267,7 +1269,7 @@ int fast_launch(const GramProblem &p)
         return SIGSVGD_E_BADARG;
     }
     if (!grad) {
-        if (p.d <= 3) {
+        if (p.d <= 4) {
             if (!p.ws || p.ws_bytes < fast_flag_bytes(p.A, p.B, p.d) + 256) {
                 set_error("fast: workspace %zu B < required %zu B", p.ws_bytes, fast_flag_bytes(p.A, p.B, p.d) + 256);
                 return SIGSVGD_E_WORKSPACE;

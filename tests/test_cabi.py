@@ -56,7 +56,7 @@ def test_workspace_query_is_host_only(lib):
     # forward only: nothing is accumulated
     assert lib.sigsvgd_gram_workspace_bytes(1024, 1024, 64, 7, 0, 0, 0, 0, ctypes.byref(n)) == 0 and 0 < n.value <= 4096
     # paths in one to three channels: one byte per pair more, the flags of the pairs the coverage kernel solves again in fp64
-    for d in (1, 2, 3):
+    for d in (1, 2, 3, 4):
         assert lib.sigsvgd_gram_workspace_bytes(1024, 1024, 64, d, 0, 0, 0, 0, ctypes.byref(n)) == 0
         assert 1024 * 1024 <= n.value <= 1024 * 1024 + 4096
     # the static kernel decides the solver (ABI 9): the linear kernel runs every shape on the coverage kernel, whose scratch

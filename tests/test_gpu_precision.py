@@ -31,7 +31,7 @@ def _rel(a, b):
 
 def _relK(a, b):
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
-    return float((np.abs(a - b) / np.maximum(np.abs(b), 0.1)).max())
+    return float((np.abs(a - b) / np.maximum(np.abs(b), 1e-6)).max())
 
 
 # (A, B, T, d, h, scale, Y is X): the regimes of the nine soak cases of round 3 (gpurun_out/soak_r3m.log: 213, 492, 1118, 1995,
