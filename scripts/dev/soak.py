@@ -1,6 +1,6 @@
 """One-off differential soak on the GPU box: many random shapes (all four solvers, ordered / symmetric / forward-only /
 partial shares with cyclic and folded ownership, dyadic orders 0..6, smooth to oscillating regimes) against the C oracle.
-K per entry relative to max(|K_ref|, 0.1), gradients relative to their largest entry.
+K per entry as a plain relative error (SOAK_KFLOOR under the denominator, default 1e-6), gradients relative to their largest entry.
 usage: python scripts/dev/soak.py [cases] [seed]"""
 import sys
 import time
