@@ -21,6 +21,8 @@
 // src/kernels/_traj_kernels.py:176-195; callers src/inference/score.py:68-69.
 #include "sig_common.h"
 
+#include <atomic>
+
 namespace sigsvgd {
 
 struct BandArgs {
@@ -36,7 +38,22 @@ struct BandArgs {
     TileMap tm;
     long long nitems;
     double inv_h;
+#ifdef SIGSVGD_PHASE_STAMPS
+    unsigned long long *stamps; // diagnostic build: wave-cycles per phase of the band-parallel kernel
+#endif
 };
+
+// Diagnostic build (-DSIGSVGD_PHASE_STAMPS, scripts/dev/phase_stamps.py): s_memtime around the phases of the band-parallel kernel
+#ifdef SIGSVGD_PHASE_STAMPS
+#define SIGB_STAMP(i)                                                        \
+    {                                                                        \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();        \
+        ph_[i] += now_ - tlast_;                                             \
+        tlast_ = now_;                                                       \
+    }
+#else
+#define SIGB_STAMP(i)
+#endif
 
 namespace {
 // wavefronts (rows i) per workgroup: 8 (two per SIMD) when there are pairs to fill the chip, 4 (one per SIMD: a wavefront's
@@ -44,7 +61,37 @@ namespace {
 constexpr int BTMAX = 33;  // coarse points per path
 constexpr int BPMAX = 256; // refined cells per side
 constexpr int BPAD = 64;   // boundary rows: entry e lives at [BPAD + e]; lanes outside the grid write into the padding
-constexpr int BHN = BPMAX + 2 + 2 * BPAD;
+// LDS of a workgroup, sized by the launch's shape (round 4: the static layout for 33 points and 256 cells took 141 KB for eight
+// wavefronts whatever the shape -- one workgroup per CU, two wavefronts per SIMD, 40 % VALU utilisation on the notebook shape,
+// whose tables need 5 KB per wavefront).  Byte offsets; every block 16-byte aligned.
+struct BandLds {
+    int yd, yf, yref;                              // shared by the workgroup
+    int Sc, dumpd, Dc, hK, hU, dump, rowacc;       // inside a wavefront's block
+    int wave0, per_wave, total;
+};
+__host__ __device__ inline BandLds band_lds(int T, int P, int dpad, int nw)
+{
+    auto up16 = [](int b) { return (b + 15) & ~15; };
+    const int Tm = T - 1, cells = Tm * Tm, rows = T * dpad;
+    const int hn = 2 * BPAD + 64 * ((P + 62) / 64) + 66; // boundary rows: the refills read 64 entries at a time
+    BandLds L;
+    int o = 0;
+    L.yd = o;   o += up16(T * (dpad + 1) * 8);
+    L.yref = o; o += up16(dpad * 8);
+    L.yf = o;   o += up16(rows * 4);
+    L.wave0 = o;
+    int w = 0;
+    L.Sc = w;     w += up16(cells * 8);
+    L.dumpd = w;  w += 64 * 8;
+    L.Dc = w;     w += up16((cells > rows ? cells : rows) * 4);
+    L.hK = w;     w += up16(hn * 4);
+    L.hU = w;     w += up16(hn * 4);
+    L.dump = w;   w += 64 * 4;
+    L.rowacc = w; w += up16(rows * 4);
+    L.per_wave = w;
+    L.total = o + nw * w;
+    return L;
+}
 
 __device__ __forceinline__ double b_ldany(const void *b, size_t i, int io64)
 {
@@ -96,22 +143,18 @@ __device__ __forceinline__ float b_shl_take(float shifted, float from, int src, 
 // reference's orders 3 and 4 the plain add stays inside 5e-6 and the six instructions per step (+8 % / +19 % forward-only)
 // are left out.
 template <int DPAD, bool GRAD, bool SYM, bool COMP, int BNW>
-__global__ __launch_bounds__(BNW * 64) __attribute__((amdgpu_waves_per_eu(BNW == 8 ? 2 : 1, 2))) void gram_band_kernel(BandArgs a)
+__global__ __launch_bounds__(BNW * 64) __attribute__((amdgpu_waves_per_eu(BNW == 8 ? 2 : 1, 4))) void gram_band_kernel(BandArgs a)
 {
     constexpr int NT = BNW * 64;
-    constexpr int TM = BTMAX - 1; // coarse cells per side at most
-    __shared__ __align__(16) double yd[BTMAX * (DPAD + 1)]; // y~_n in fp64 (centred on y[0]), [DPAD] = -|y~_n|^2 / h
-    __shared__ __align__(16) float yf[BTMAX * DPAD];        // the same in fp32 for the coarse contraction
-    __shared__ double yref[DPAD];
+    extern __shared__ __align__(16) unsigned char band_smem[];
     struct WaveLds {
-        double Sc[TM * TM];    // block sums of S = K_fwd * U over the fine cells of every coarse cell
-        float Dc[TM * TM];     // coarse increments / (r^2 sqrt(12)); after the sweeps: the parked column-side sums
-        float hK[BHN], hU[BHN]; // K[64 b][.] left by band b - 1 for band b; U[64 b][.] left by band b for band b - 1
-        float dump[64];
-        double dumpd[64];           // where the lanes without a finished run add their zero (reverse sweep)
-        float rowacc[BTMAX * DPAD]; // row-side gradient of the wavefront's particle over the columns of a segment
+        double *Sc;    // [Tm][Tm] block sums of S = K_fwd * U over the fine cells of every coarse cell
+        float *Dc;     // [Tm][Tm] coarse increments / (r^2 sqrt(12)); after the sweeps: the parked column-side sums [T][DPAD]
+        float *hK, *hU; // K[64 b][.] left by band b - 1 for band b; U[64 b][.] left by band b for band b - 1
+        float *dump;    // [64]
+        double *dumpd;  // [64] where the lanes without a finished run add their zero (reverse sweep)
+        float *rowacc;  // [T][DPAD] row-side gradient of the wavefront's particle over the columns of a segment
     };
-    __shared__ WaveLds wl_all[BNW];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -121,7 +164,19 @@ __global__ __launch_bounds__(BNW * 64) __attribute__((amdgpu_waves_per_eu(BNW ==
     const float m2h = (float)(-2.0 * inv_h);
     const double dscale = 1.0 / ((double)r * (double)r * 3.46410161513775459); // 1 / (r^2 sqrt(12))
     const double inv_r2 = 1.0 / ((double)r * (double)r);
-    WaveLds &wl = wl_all[wave];
+    const BandLds lay = band_lds(T, P, DPAD, BNW);
+    double *yd = reinterpret_cast<double *>(band_smem + lay.yd);   // y~_n in fp64 (centred on y[0]), [DPAD] = -|y~_n|^2 / h
+    double *yref = reinterpret_cast<double *>(band_smem + lay.yref);
+    float *yf = reinterpret_cast<float *>(band_smem + lay.yf);     // the same in fp32 for the coarse contraction
+    unsigned char *wbase = band_smem + lay.wave0 + wave * lay.per_wave;
+    WaveLds wl;
+    wl.Sc = reinterpret_cast<double *>(wbase + lay.Sc);
+    wl.dumpd = reinterpret_cast<double *>(wbase + lay.dumpd);
+    wl.Dc = reinterpret_cast<float *>(wbase + lay.Dc);
+    wl.hK = reinterpret_cast<float *>(wbase + lay.hK);
+    wl.hU = reinterpret_cast<float *>(wbase + lay.hU);
+    wl.dump = reinterpret_cast<float *>(wbase + lay.dump);
+    wl.rowacc = reinterpret_cast<float *>(wbase + lay.rowacc);
     float *wsw = GRAD ? a.wsk + ((size_t)blockIdx.x * BNW + wave) * a.wsk_per_wave + 16 * 64 : nullptr; // (16 rows of padding in front)
 
     // static item ranges: (owned row tile, column), tile-major; symmetric launches only the columns from the tile's first row
@@ -147,7 +202,7 @@ __global__ __launch_bounds__(BNW * 64) __attribute__((amdgpu_waves_per_eu(BNW ==
     const int j0 = cfirst + cstart, j1 = j0 + ncolr;
     const bool row_ok = i < a.A;
     if (GRAD)
-        for (int e = lane; e < BTMAX * DPAD; e += 64) wl.rowacc[e] = 0.f;
+        for (int e = lane; e < T * DPAD; e += 64) wl.rowacc[e] = 0.f;
 
 #pragma unroll 1
     for (int j = j0; j < j1; ++j, ++item) {
@@ -449,7 +504,8 @@ __global__ __launch_bounds__(BNW * 64) __attribute__((amdgpu_waves_per_eu(BNW ==
                 const int nn = e / d, c = e - nn * d;
                 float s = 0.f;
 #pragma unroll
-                for (int w = 0; w < BNW; ++w) s += wl_all[w].Dc[nn * DPAD + c];
+                for (int w = 0; w < BNW; ++w)
+                    s += reinterpret_cast<const float *>(band_smem + lay.wave0 + w * lay.per_wave + lay.Dc)[nn * DPAD + c];
                 dstc[e] = s;
             }
         }
@@ -470,6 +526,559 @@ __global__ __launch_bounds__(BNW * 64) __attribute__((amdgpu_waves_per_eu(BNW ==
     } // row tiles of the range
 }
 
+namespace {
+// ---- band-parallel kernel: one wavefront per BAND of a pair ----------------------------------------------------------
+// The reference's refined call shapes come with few pairs (notebook 5,050, maze 630): one wavefront per pair leaves most of
+// the chip's 1,024 SIMDs with one wavefront or none, and each of them walks nb (P + 63) dependent steps per sweep.  Here the nb
+// bands of a pair run on nb wavefronts of one workgroup, as a pipeline: band b needs, on its step s, the entry lane 63 of band
+// b - 1 wrote on step s + 63, so it runs BLAG phases of BGS steps behind its neighbour, with a workgroup barrier between the
+// phases (every wavefront of the workgroup runs the same phase schedule; a band outside its step range just waits).  A sweep
+// takes ceil((P + 63) / BGS) + BLAG (nb - 1) phases instead of nb (P + 63) steps: 368 against 621 step times at the notebook
+// shape, 544 against 1,180 at the maze shape.  The arithmetic of every cell, the order of every sum (a coarse cell's fine rows
+// lie inside one band, since r divides 64) and hence every result bit are those of the serial band sweep above.
+// A workgroup holds BPP pairs (rows i, i + 1 against the staged column j): 2 nb wavefronts.
+constexpr int BGS = 16; // steps per phase
+constexpr int BLAG = 5; // phases a band runs behind its neighbour: BLAG * BGS > 62 + BGS + 1 steps (see the refills in the kernel)
+constexpr int BPP = 1;  // pairs per workgroup
+constexpr int BUO = 96; // offset of entry 0 in a reverse boundary row (a phase reads down to entry P - 16 - sp0 >= -78)
+// The increment table carries BZP zeros on either side of every row and one row of zeros behind the last: a lane outside the
+// grid (column < 0 or >= P on the ramps of its band, or a row >= P of the last band) reads gamma = 0, for which a step leaves
+// V alone and copies the neighbour's value -- ahead of its row that is the boundary value 1 all the way down the lanes, so a
+// lane starts its row from the right state with no activity test and none of the three selects in the step (columns reach
+// -63 - 15 .. P + 78, i.e. at most ten coarse cells past a row's end for r >= 8).
+constexpr int BZP = 10;
+
+struct BandPLds {
+    int yd, yf, yref;                        // shared by the workgroup
+    int Sc, Dc, hK, hU, rowacc, misc, dump;  // inside a pair's block (dump: nb blocks of 64 floats + 64 doubles)
+    int hn;                                  // floats per boundary row
+    int pair0, per_pair, total;
+};
+__host__ __device__ inline BandPLds bandp_lds(int T, int P, int dpad)
+{
+    auto up16 = [](int b) { return (b + 15) & ~15; };
+    const int Tm = T - 1, cells = Tm * Tm, rows = T * dpad, nb = (P + 63) >> 6;
+    BandPLds L;
+    L.hn = 2 * BPAD + 64 * ((P + 62) / 64) + 80;
+    int o = 0;
+    L.yd = o;   o += up16(T * (dpad + 1) * 8);
+    L.yref = o; o += up16(dpad * 8);
+    L.yf = o;   o += up16(rows * 4);
+    L.pair0 = o;
+    int w = 0;
+    L.Sc = w;     w += up16(cells * 8);
+    L.misc = w;   w += 64;
+    const int dtab = (Tm + 1) * (Tm + 2 * BZP); // padded increment table (see BZP)
+    L.Dc = w;     w += up16((dtab > rows ? dtab : rows) * 4);
+    L.hK = w;     w += up16((nb - 1) * L.hn * 4);
+    L.hU = w;     w += up16((nb - 1) * L.hn * 4);
+    L.rowacc = w; w += up16(rows * 4);
+    L.dump = w;   w += nb * (96 * 4 + 64 * 8);
+    L.per_pair = w;
+    L.total = o + BPP * w;
+    return L;
+}
+
+// One phase (BGS steps) of a band's forward sweep, unrolled: the boundary row's entries of the phase arrive in `hv` (one
+// uniform 16-byte read per four steps) and reach lane 0 as the `old` operand of the DPP shift -- a lane without a source
+// keeps it -- so the shift is one instruction; the store of the forward solution and the hand-over write take the step
+// number as an immediate offset.  PLAT: every lane is inside the grid on every step of the phase (steps 64 .. P - 1 of a band
+// of 64 valid rows): no activity test and none of the three selects.
+struct BandFwd {
+    float cur, upprev, V, clo, kmax;
+    int q1;
+};
+constexpr int BHS = 8; // steps per unrolled group (two per phase: the registers of 16 unrolled steps cost a wavefront per SIMD)
+// FREEZE: a lane keeps its state once its row has ended -- the last band from the phase of its first row's end on, so that
+// K[P][P] stays in its lane; everywhere else a lane past its row's end runs on (gamma = 0), which nobody reads.
+template <bool FREEZE, bool COMP, bool GRAD>
+__device__ __forceinline__ void bandp_fwd_phase(BandFwd &st, const float (&hv)[BHS], const float *dcrow, int n, unsigned qlim,
+                                                float *ho, const float *wrow, int lane4)
+{
+    float gq[BHS]; // the group's increments up front (one LDS round trip per group instead of one per step on the dependent chain)
+#pragma unroll
+    for (int k = 0; k < BHS; ++k) gq[k] = dcrow[(st.q1 - 1 + k) >> n]; // (a column outside the grid: one of the row's zeros)
+#pragma unroll
+    for (int u = 0; u < BHS; ++u) {
+        const bool active = !FREEZE || (unsigned)(st.q1 - 1) < qlim;
+        const float g = gq[u];
+        const float up = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(hv[u]), __float_as_int(st.cur), 0x138, 0xF, 0xF, false));
+        // K11 - K01 = (K10 - K00) + F,  F = gamma (sqrt(3) t + gamma (t + K00)),  t = K10 + K01
+        const float t = st.cur + up;
+        float y = 1.7320508075688772f * t;
+        y = __builtin_fmaf(t + st.upprev, g, y);
+        const float Vn = __builtin_fmaf(g, y, st.V);
+        float Vt = Vn, nlo = 0.f;
+        if constexpr (COMP)
+            Vt += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(st.clo), 0x138, 0xF, 0xF, true));
+        const float nw = up + Vt;
+        if constexpr (COMP) nlo = Vt - (nw - up);
+        if (GRAD) asm volatile("global_store_dword %0, %1, %2 offset:%3" ::"v"(lane4), "v"(st.upprev), "s"(wrow), "n"(u * 256));
+        ho[u] = COMP ? nw + nlo : nw;
+        st.cur = active ? nw : st.cur;
+        asm("v_max_f32 %0, |%1|, %0" : "+v"(st.kmax) : "v"(st.cur));
+        if constexpr (COMP) st.clo = active ? nlo : st.clo;
+        st.V = active ? Vn : st.V;
+        st.upprev = active ? up : st.upprev;
+        ++st.q1;
+    }
+}
+// The same for the reverse sweep: the boundary lane is lane 63 of a full band (no DPP source from above: keeps hv[u]); the
+// last band's boundary is U = 1, which lane L - 1 finds in lane L (a row outside the grid never leaves its initial 1).
+struct BandRev {
+    float cur, dprev, V, run;
+    int q;
+};
+// ALLIN: every lane is inside the grid on every step of the phase (no activity test for the block sums).  The state of a lane
+// outside the grid needs no protection in this direction (zeros around the rows, see BZP; nothing is read from it later).
+template <bool ALLIN>
+__device__ __forceinline__ void bandp_rev_phase(BandRev &st, const float (&hv)[BHS], float (&kfr)[8], const float *rnext, int lanep,
+                                                const float *dcrow, double *scrow, double *dumpl, int n, int r, int P, bool rowvalid,
+                                                float *ho)
+{
+    float gq[BHS];
+#pragma unroll
+    for (int k = 0; k < BHS; ++k) gq[k] = dcrow[(st.q - k) >> n]; // (a column outside the grid: one of the row's zeros)
+#pragma unroll
+    for (int u = 0; u < BHS; ++u) {
+        const bool active = ALLIN || (rowvalid && (unsigned)st.q < (unsigned)P);
+        const float g = gq[u];
+        const float kf = kfr[u & 7];
+        kfr[u & 7] = rnext[lanep - 64 * u];
+        const float down = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(hv[u]), __float_as_int(st.cur), 0x130, 0xF, 0xF, false));
+        // block sums without a branch: every lane adds every step -- its finished run to the coarse cell when it has just taken
+        // the cell's leftmost fine column, a zero to its own dump cell otherwise
+        st.run = __builtin_fmaf(active ? kf : 0.f, st.dprev, st.run);
+        const bool fl = active && (st.q & (r - 1)) == 0;
+        float addend = fl ? st.run : 0.f;
+        asm volatile("" : "+v"(addend)); // (select, then convert: hipcc otherwise converts and selects both halves)
+        unsafeAtomicAdd(fl ? scrow + (st.q >> n) : dumpl, (double)addend); // ds_add_f64
+        st.run = fl ? 0.f : st.run;
+        const float t = st.cur + down;
+        float y = 1.7320508075688772f * t;
+        y = __builtin_fmaf(t + st.dprev, g, y);
+        const float Vn = __builtin_fmaf(g, y, st.V);
+        const float nw = down + Vn;
+        ho[-u] = nw; // (a lane outside the grid writes into the padding, or entries nobody reads)
+        st.cur = nw;
+        st.V = Vn;
+        st.dprev = down;
+        --st.q;
+    }
+}
+
+template <int DPAD, bool GRAD, bool SYM, bool COMP>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(1, 4))) void gram_bandp_kernel(BandArgs a)
+{
+    extern __shared__ __align__(16) unsigned char band_smem[];
+    const int tid = threadIdx.x, lane = tid & 63, NT = blockDim.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int T = a.T, d = a.d, n = a.n, io64 = a.io64, Tm = T - 1, r = 1 << n;
+    const int P = Tm << n, nb = (P + 63) >> 6, nsteps = P + 63;
+    const int slot = __builtin_amdgcn_readfirstlane(wave / nb), band = wave - slot * nb; // pair of the workgroup, band of the pair
+    const double inv_h = a.inv_h;
+    const float m2h = (float)(-2.0 * inv_h);
+    const double dscale = 1.0 / ((double)r * (double)r * 3.46410161513775459); // 1 / (r^2 sqrt(12))
+    const double inv_r2 = 1.0 / ((double)r * (double)r);
+    const BandPLds lay = bandp_lds(T, P, DPAD);
+    const int DS = Tm + 2 * BZP; // floats per row of the increment table
+    double *yd = reinterpret_cast<double *>(band_smem + lay.yd);
+    double *yref = reinterpret_cast<double *>(band_smem + lay.yref);
+    float *yf = reinterpret_cast<float *>(band_smem + lay.yf);
+    unsigned char *pbase = band_smem + lay.pair0 + slot * lay.per_pair;
+    double *Sc = reinterpret_cast<double *>(pbase + lay.Sc);          // [Tm][Tm] block sums of S = K_fwd * U
+    float *Dc = reinterpret_cast<float *>(pbase + lay.Dc);            // [Tm][Tm] coarse increments; later the parked column sums
+    float *hKall = reinterpret_cast<float *>(pbase + lay.hK);         // row b: K[64 (b + 1)][.], written by band b, read by band b + 1
+    float *hUall = reinterpret_cast<float *>(pbase + lay.hU);         // row b: U[64 (b + 1)][.], written by band b + 1, read by band b
+    float *rowacc = reinterpret_cast<float *>(pbase + lay.rowacc);
+    float *misc = reinterpret_cast<float *>(pbase + lay.misc);        // [0..1]: K[P][P] (double), [4 + b]: grid maximum of band b
+    float *dump = reinterpret_cast<float *>(pbase + lay.dump + band * (96 * 4 + 64 * 8)); // [96]: a phase writes 16 entries from the lane's cell
+    double *dumpd = reinterpret_cast<double *>(pbase + lay.dump + band * (96 * 4 + 64 * 8) + 96 * 4);
+    float *wsw = GRAD ? a.wsk + ((size_t)blockIdx.x * BPP + slot) * a.wsk_per_wave + 32 * 64 : nullptr; // the pair's forward solution (32 rows of padding in front)
+    const int ngf = (nsteps + BGS - 1) / BGS;               // forward phases of one band
+    const int nsr = ngf * BGS;                              // rows of a band's forward-solution scratch (whole phases)
+    const int ngr = (P + 63 + BGS - 1) / BGS;               // reverse phases of a full band (P + L - 1 <= P + 63 steps)
+    const int Mf = ngf + BLAG * (nb - 1), Mr = ngr + BLAG * (nb - 1);
+
+#ifdef SIGSVGD_PHASE_STAMPS
+    unsigned long long ph_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast_ = __builtin_amdgcn_s_memtime();
+#endif
+    const long long it0 = a.nitems * blockIdx.x / gridDim.x, it1 = a.nitems * (blockIdx.x + 1) / gridDim.x;
+    int remaining = (int)(it1 - it0);
+    long long item = it0;
+    int kq = 0, cstart = 0;
+    {
+        long long rem = it0;
+        for (;; ++kq) {
+            const int cn = a.B - (SYM ? a.tm.tile_of(kq) * BPP : 0);
+            if (rem < cn) break;
+            rem -= cn;
+        }
+        cstart = (int)rem;
+    }
+#pragma unroll 1
+    while (remaining > 0) {
+    const int itile = a.tm.tile_of(kq);
+    const int cfirst = SYM ? itile * BPP : 0;
+    const int ncolr = min(a.B - cfirst - cstart, remaining);
+    const int i0 = itile * BPP, i = i0 + slot;
+    const int j0 = cfirst + cstart, j1 = j0 + ncolr;
+    const bool row_ok = slot < BPP && i < a.A;
+    if (GRAD && band == 0 && slot < BPP)
+        for (int e = lane; e < T * DPAD; e += 64) rowacc[e] = 0.f;
+
+#pragma unroll 1
+    for (int j = j0; j < j1; ++j, ++item) {
+        int lanep = lane;
+        asm volatile("" : "+v"(lanep));
+        // ---- stage y_j (coarse points, centred on its first point) ------------------------------------------------
+        __syncthreads();
+        for (int e = tid; e < T * DPAD; e += NT) {
+            const int t = e / DPAD, c = e % DPAD;
+            const double r0 = c < d ? b_ldany(a.Y, (size_t)j * T * d + c, io64) : 0.0;
+            const double v = c < d ? b_ldany(a.Y, ((size_t)j * T + t) * d + c, io64) - r0 : 0.0;
+            yd[t * (DPAD + 1) + c] = v;
+            yf[t * DPAD + c] = (float)v;
+            if (t == 0) yref[c] = r0;
+            double s = v * v;
+#pragma unroll
+            for (int off = 1; off < DPAD; off <<= 1) s += __shfl_xor(s, off, 64);
+            if (c == 0) yd[t * (DPAD + 1) + DPAD] = -s * inv_h;
+        }
+        __syncthreads();
+
+        SIGB_STAMP(0)
+        const bool valid = row_ok && (!SYM || j >= i); // (uniform per wavefront)
+        if (valid && band == 0) {
+            for (int e = lanep; e < (Tm + 1) * DS; e += 64) Dc[e] = 0.f; // the zeros around the rows (the table is reused per pair)
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            // ---- coarse static kernel: lane m = point row m; G[m][b] in fp64, row differences, 4-corner increments --------
+            const int m = min(lanep, T - 1);
+            double xs[DPAD], xn = 0.0;
+#pragma unroll
+            for (int c = 0; c < DPAD; ++c) {
+                const double xc = c < d ? b_ldany(a.X, ((size_t)i * T + m) * d + c, io64) - yref[c] : 0.0;
+                xn = __builtin_fma(xc, xc, xn);
+                xs[c] = xc * (2.0 * inv_h);
+            }
+            xn = -xn * inv_h;
+            double gprev = 0.0;
+            for (int b = 0; b < T; ++b) {
+                const double *yr = yd + b * (DPAD + 1);
+                double e2 = xn + yr[DPAD];
+#pragma unroll
+                for (int c = 0; c < DPAD; ++c) e2 = __builtin_fma(xs[c], yr[c], e2);
+                const double g = exp64(e2);
+                const double rd = g - gprev; // G[m][b] - G[m][b-1]
+                gprev = g;
+                const double nbr = shfl_down_f64(rd); // row m + 1
+                if (b >= 1 && lanep < Tm) Dc[lanep * DS + BZP + (b - 1)] = (float)((nbr - rd) * dscale);
+            }
+            if (GRAD)
+                for (int e = lanep; e < Tm * Tm; e += 64) Sc[e] = 0.0;
+        }
+        SIGB_STAMP(1)
+        __syncthreads(); // the pair's increment table is complete
+        SIGB_STAMP(3)
+
+        // ---- forward sweep: this wavefront's band, BGS steps per phase ---------------------------------------------
+        float kmax = 1.f; // largest |K| this lane has seen on the pair's grid
+        {
+            const int p = 64 * band + lanep;
+            const bool rowvalid = p < P;
+            const float *dcrow = Dc + (rowvalid ? (p >> n) : Tm) * DS + BZP; // (a row outside the grid: the row of zeros)
+            const float *wb = GRAD ? wsw + (size_t)band * nsr * 64 : nullptr;
+            BandFwd st;
+            st.cur = 1.f; st.upprev = 1.f; st.V = 0.f; st.clo = 0.f; st.kmax = 1.f;
+            st.q1 = 1 - lanep; // column + 1 of the cell in work
+            // lane 63 hands K[64 band + 64][q + 1] over through entry q + 1 of row `band` (entry e at [BPAD - 1 + e]: the 16
+            // entries a phase of the next band reads start on a 16-byte boundary); the other lanes write into the dump block
+            const bool hands = lanep == 63 && band < nb - 1;
+            float *ho = hands ? hKall + band * lay.hn + (BPAD - 1) + st.q1 : dump + lanep;
+            const int hinc = hands ? BGS : 0;
+            const float *hin = hKall + (band - 1) * lay.hn + BPAD; // (band 0: not read)
+            const unsigned qlim = rowvalid ? (unsigned)P : 0u;
+#pragma unroll 1
+            for (int ph = 0; ph < Mf; ++ph) {
+                const int gi = ph - BLAG * band;
+                if (valid && gi >= 0 && gi < ngf) {
+                    const int s0 = gi * BGS;
+                    // lane 0's upper neighbour on step s is entry s + 1 of the row band - 1 leaves: written on ITS step s + 63,
+                    // i.e. the 16 entries of this phase by step s0 + 78 < (gi + BLAG) BGS, the steps the neighbour has finished
+                    const bool freeze = band == nb - 1 && s0 + BGS > P; // (the last band, once its first row may have ended)
+#pragma unroll 1
+                    for (int h = 0; h < BGS; h += BHS) {
+                        float hv[BHS];
+                        if (band) {
+                            const float4 *h4 = reinterpret_cast<const float4 *>(hin + s0 + h);
+#pragma unroll
+                            for (int k = 0; k < BHS / 4; ++k) {
+                                const float4 v = h4[k];
+                                hv[4 * k] = v.x; hv[4 * k + 1] = v.y; hv[4 * k + 2] = v.z; hv[4 * k + 3] = v.w;
+                            }
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < BHS; ++k) hv[k] = 1.f;
+                        }
+                        if (band && s0 + h + BHS > P) { // entries beyond P were never written: their lanes are past the grid, but
+#pragma unroll                                            // whatever they read reaches the grid maximum (kmax)
+                            for (int k = 0; k < BHS; ++k)
+                                if (s0 + h + k + 1 > P) hv[k] = 1.f;
+                        }
+                        const float *wrow = GRAD ? wb + (size_t)(s0 + h) * 64 : nullptr;
+                        if (freeze)
+                            bandp_fwd_phase<true, COMP, GRAD>(st, hv, dcrow, n, qlim, ho + (hands ? h : 0), wrow, lanep * 4);
+                        else
+                            bandp_fwd_phase<false, COMP, GRAD>(st, hv, dcrow, n, qlim, ho + (hands ? h : 0), wrow, lanep * 4);
+                    }
+                    ho += hinc;
+                    SIGB_STAMP(2)
+                }
+                __syncthreads();
+                SIGB_STAMP(3)
+            }
+            kmax = st.kmax;
+            if (valid) {
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) kmax = fmaxf(kmax, __shfl_xor(kmax, off, 64));
+                if (lanep == 0) misc[4 + band] = kmax;
+                if (band == nb - 1 && p == P - 1) *reinterpret_cast<double *>(misc) = (double)st.cur + (double)st.clo;
+            }
+        }
+        __syncthreads();
+        double kfin = 1.0;
+        float kfin_keep = 0.f;
+        bool canc_keep = false;
+        if (valid && band == 0) {
+            kfin = *reinterpret_cast<const double *>(misc);
+            float km = misc[4];
+            for (int b = 1; b < nb; ++b) km = fmaxf(km, misc[4 + b]);
+            const float kfv = (float)kfin;
+            const bool cancelled = kfv == kfv && km > (d == 1 ? 2.f : (d == 2 || !COMP) ? 4.f : 8.f) * fmaxf(fabsf(kfv), 0.1f);
+            if (lanep == 0) {
+                b_stany(a.K, (size_t)i * a.B + j, kfin, io64);
+                if (SYM && j != i) b_stany(a.K, (size_t)j * a.B + i, kfin, io64);
+                if (!GRAD) a.kflag[(size_t)i * a.B + j] = cancelled ? 1 : 0;
+            }
+            kfin_keep = kfv;
+            canc_keep = cancelled;
+        }
+
+        if (GRAD) {
+            // ---- reverse sweep: the last band leads ---------------------------------------------------------------------
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this band's forward solution has left the wavefront
+            {
+                const int p = 64 * band + lanep;
+                const bool rowvalid = p < P;
+                const int L = min(64, P - 64 * band);
+                const int arow = min(p, P - 1) >> n;
+                const float *dcrow = Dc + (rowvalid ? arow : Tm) * DS + BZP;
+                double *scrow = Sc + arow * Tm;
+                const bool lastband = band == nb - 1;
+                BandRev st;
+                st.cur = 1.f; st.dprev = 1.f; st.V = 0.f; st.run = 0.f;
+                st.q = P - 1 + (L - 1 - lanep);
+                // K_fwd[p][q] was stored on forward step lane + q: row R = P + L - 2 - sp of the band's scratch on step sp
+                const float *wrow = wsw + (size_t)band * nsr * 64 + lanep;
+                const int R = P + L - 2;
+                const float *rnext = wsw + ((size_t)band * nsr + (R - 8)) * 64; // (uniform row pointer of the ring's next load)
+                // lane 0 hands U[64 band][q] over through entry q of row band - 1 (entry e at [BUO + e])
+                const bool hands = lanep == 0 && band > 0;
+                float *ho = hands ? hUall + (band - 1) * lay.hn + BUO + st.q : dump + 16 + lanep;
+                const int hinc = hands ? -BGS : 0;
+                const float *hin = hUall + band * lay.hn + BUO + (P - BGS); // (last band: not read)
+                float kfr[8];
+                if (valid) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) kfr[u] = wrow[(size_t)max(R - u, 0) * 64];
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) kfr[u] = 0.f;
+                }
+                const int ngb = (P + L - 1 + BGS - 1) / BGS; // this band's phases
+                const int rb = nb - 1 - band;
+#pragma unroll 1
+                for (int ph = 0; ph < Mr; ++ph) {
+                    const int gi = ph - BLAG * rb;
+                    if (valid && gi >= 0 && gi < ngb) {
+                        const int sp0 = gi * BGS;
+                        // lane 63's lower neighbour on step sp is entry P - 1 - sp of the row band + 1 leaves (its lane 0 on
+                        // its step L' - 1 + sp): the 16 entries of this phase are there once it has finished step sp0 + L' + 14
+                        const bool plat = L == 64 && sp0 >= 64 && sp0 + BGS <= P; // every lane inside the grid on every step
+#pragma unroll 1
+                        for (int h = 0; h < BGS; h += BHS) {
+                            float hv[BHS];
+                            if (!lastband) {
+                                // entries P - 8 - (sp0 + h) .. P - 1 - (sp0 + h), descending over the group's steps
+                                const float4 *h4 = reinterpret_cast<const float4 *>(hin + (BGS - BHS) - sp0 - h);
+#pragma unroll
+                                for (int k = 0; k < BHS / 4; ++k) {
+                                    const float4 v = h4[k];
+                                    hv[BHS - 1 - 4 * k] = v.x; hv[BHS - 2 - 4 * k] = v.y; hv[BHS - 3 - 4 * k] = v.z; hv[BHS - 4 - 4 * k] = v.w;
+                                }
+                            } else {
+#pragma unroll
+                                for (int k = 0; k < BHS; ++k) hv[k] = 1.f;
+                            }
+                            if (!lastband && sp0 + h + BHS > P) { // entries below 0 were never written (lanes past the grid)
+#pragma unroll
+                                for (int k = 0; k < BHS; ++k)
+                                    if (sp0 + h + k > P - 1) hv[k] = 1.f;
+                            }
+                            if (plat)
+                                bandp_rev_phase<true>(st, hv, kfr, rnext - h * 64, lanep, dcrow, scrow, dumpd + lanep, n, r, P, rowvalid, ho - (hands ? h : 0));
+                            else
+                                bandp_rev_phase<false>(st, hv, kfr, rnext - h * 64, lanep, dcrow, scrow, dumpd + lanep, n, r, P, rowvalid, ho - (hands ? h : 0));
+                        }
+                        rnext -= BGS * 64;
+                        ho += hinc;
+                        SIGB_STAMP(4)
+                    }
+                    __syncthreads();
+                    SIGB_STAMP(5)
+                }
+                // (the ring's last loads are never used: consumed here, or hipcc carries them as pending into the next pair's
+                //  forward step loop and waits for vmcnt(0) in every step -- behind the step's own store, a memory round trip)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) asm volatile("" ::"v"(kfr[u]));
+            }
+
+            if (valid && band == 0) {
+                // the pair's verdict for the exact fp64 pass (see the serial kernel)
+                {
+                    bool ill = false;
+                    if (d <= 3) {
+                        float cs = 0.f;
+                        for (int e = lanep; e < Tm * Tm; e += 64) {
+                            const int ra = e / Tm;
+                            cs = __builtin_fmaf(fabsf((float)Sc[e]), fabsf(Dc[ra * DS + BZP + (e - ra * Tm)]), cs);
+                        }
+#pragma unroll
+                        for (int off = 1; off < 64; off <<= 1) cs += __shfl_xor(cs, off, 64);
+                        ill = kfin_keep == kfin_keep && cs * 3.46410161513775459f > 150.f * fmaxf(fabsf(kfin_keep), 0.1f);
+                    }
+                    if (lanep == 0) a.kflag[(size_t)i * a.B + j] = (canc_keep || ill) ? 1 : 0;
+                }
+                // ---- coarse gradient: R = 4-corner scatter of S_coarse / r^2, RBF derivative, both contractions ----------
+                // (the weights and x~_m in fp32 are read again here: held through the sweeps they cost the kernel a wavefront per SIMD)
+                float w_ij = 1.f, w_ji = 1.f;
+                if (a.go) {
+                    w_ij = (float)b_ldany(a.go, (size_t)i * a.B + j, io64);
+                    if (SYM || a.symw) w_ji = (float)b_ldany(a.go, (size_t)j * a.B + i, io64);
+                    if (a.symw) { w_ij += w_ji; w_ji = w_ij; }
+                } else if (a.symw) {
+                    w_ij = 2.f; w_ji = 2.f;
+                }
+                if (SYM && j == i) w_ji = 0.f; // diagonal pair: first-slot derivative only
+                float xf[DPAD];
+                {
+                    const int m = min(lanep, T - 1);
+#pragma unroll
+                    for (int c = 0; c < DPAD; ++c)
+                        xf[c] = c < d ? (float)(b_ldany(a.X, ((size_t)i * T + m) * d + c, io64) - yref[c]) : 0.f;
+                }
+                const float ns32 = (float)(-inv_h * 1.4426950408889634074);
+                auto Sat = [&](int aa, int bb) -> float {
+                    return (aa >= 0 && aa < Tm && bb >= 0 && bb < Tm) ? (float)(Sc[aa * Tm + bb] * inv_r2) : 0.f;
+                };
+                if (lanep < T) {
+                    const int m = lanep;
+                    float acc[DPAD];
+#pragma unroll
+                    for (int c = 0; c < DPAD; ++c) acc[c] = 0.f;
+                    for (int nn = 0; nn < T; ++nn) {
+                        const float Rv = (Sat(m - 1, nn - 1) + Sat(m, nn)) - (Sat(m - 1, nn) + Sat(m, nn - 1));
+                        const float *yr = yf + nn * DPAD;
+                        float df[DPAD], e2 = 0.f;
+#pragma unroll
+                        for (int c = 0; c < DPAD; ++c) {
+                            df[c] = xf[c] - yr[c];
+                            e2 = __builtin_fmaf(df[c], df[c], e2);
+                        }
+                        const float rg = Rv * __builtin_amdgcn_exp2f(e2 * ns32);
+#pragma unroll
+                        for (int c = 0; c < DPAD; ++c) acc[c] = __builtin_fmaf(rg, df[c], acc[c]);
+                    }
+#pragma unroll
+                    for (int c = 0; c < DPAD; ++c)
+                        if (c < d) rowacc[m * DPAD + c] += w_ij * m2h * acc[c];
+                }
+                if (SYM) {
+                    float *xl = Dc; // (the increments are not needed any more) x~ rows [T][DPAD], then the parked sums
+                    if (lanep < T) {
+#pragma unroll
+                        for (int c = 0; c < DPAD; ++c) xl[lanep * DPAD + c] = xf[c];
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
+                    float acc[DPAD];
+#pragma unroll
+                    for (int c = 0; c < DPAD; ++c) acc[c] = 0.f;
+                    const int nn = min(lanep, T - 1);
+                    const float *yr = yf + nn * DPAD;
+                    for (int m = 0; m < T; ++m) {
+                        const float Rv = (Sat(m - 1, nn - 1) + Sat(m, nn)) - (Sat(m - 1, nn) + Sat(m, nn - 1));
+                        const float *xr = xl + m * DPAD;
+                        float df[DPAD], e2 = 0.f;
+#pragma unroll
+                        for (int c = 0; c < DPAD; ++c) {
+                            df[c] = xr[c] - yr[c];
+                            e2 = __builtin_fmaf(df[c], df[c], e2);
+                        }
+                        const float rg = Rv * __builtin_amdgcn_exp2f(e2 * ns32);
+#pragma unroll
+                        for (int c = 0; c < DPAD; ++c) acc[c] = __builtin_fmaf(rg, df[c], acc[c]);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
+                    if (lanep < T) {
+#pragma unroll
+                        for (int c = 0; c < DPAD; ++c) xl[lanep * DPAD + c] = -(w_ji * m2h) * acc[c];
+                    }
+                }
+            } else if (SYM && band == 0 && slot < BPP) {
+                for (int e = lane; e < T * DPAD; e += 64) Dc[e] = 0.f; // no pair in this slot: nothing to add to the column
+            }
+        }
+
+        SIGB_STAMP(6)
+        if (GRAD && SYM) {
+            __syncthreads(); // every pair has parked its column-side sums
+            float *dstc = a.cslab + (size_t)item * (T * d);
+            for (int e = tid; e < T * d; e += NT) {
+                const int nn = e / d, c = e - nn * d;
+                float s = 0.f;
+#pragma unroll
+                for (int w = 0; w < BPP; ++w)
+                    s += reinterpret_cast<const float *>(band_smem + lay.pair0 + w * lay.per_pair + lay.Dc)[nn * DPAD + c];
+                dstc[e] = s;
+            }
+        }
+    }
+    if (GRAD && row_ok && band == 0) { // the segment's row-side sums
+        const int tot = T * d;
+        double *dstr = a.rseg + (((size_t)(kq + (int)blockIdx.x)) * BPP + slot) * (size_t)tot;
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        for (int e = lane; e < tot; e += 64) {
+            const int m = e / d, c = e - m * d;
+            dstr[e] = (double)rowacc[m * DPAD + c];
+        }
+    }
+    remaining -= ncolr;
+    ++kq;
+    cstart = 0;
+    } // row tiles of the range
+#ifdef SIGSVGD_PHASE_STAMPS
+    SIGB_STAMP(0)
+    if (lane == 0 && a.stamps)
+        for (int k = 0; k < 8; ++k) atomicAdd(&a.stamps[k], ph_[k]);
+#endif
+}
+
+} // namespace
+
 bool band_supported(int A, int B, int T, int d, int n, int kind, unsigned flags)
 {
     (void)A; (void)B;
@@ -487,18 +1096,28 @@ inline int band_nw(int A, int B, bool sym)
     const long long pairs = sym ? (long long)A * (A + 1) / 2 : (long long)A * B;
     return pairs <= 4ll * device_cu_count() ? 4 : 8;
 }
-inline GradGeom band_geometry(int A, int B, int T, int d, bool sym, int nw)
+// workgroups a CU holds: by LDS (160 KB a CU) and by wavefronts (four per SIMD: the kernel's register budget)
+inline int band_wg_per_cu(int T, int d, int n, int nw)
 {
-    return grad_geometry(A, B, T * d, sym, 0, 1, false, nw, (long long)device_cu_count());
+    const BandLds L = band_lds(T, (T - 1) << n, d <= 8 ? 8 : 16, nw);
+    const int by_lds = (160 * 1024) / (L.total + 1024);
+    const int by_waves = (d <= 8 ? 16 : 12) / nw; // (16-channel gradient instantiations: 157 registers, three wavefronts per SIMD)
+    const int k = by_lds < by_waves ? by_lds : by_waves;
+    return k < 1 ? 1 : k;
+}
+inline GradGeom band_geometry(int A, int B, int T, int d, int n, bool sym, int nw)
+{
+    return grad_geometry(A, B, T * d, sym, 0, 1, false, nw, (long long)device_cu_count() * band_wg_per_cu(T, d, n, nw));
 }
 inline size_t band_wsk_per_wave(int T, int n)
 {
     const int P = (T - 1) << n;
     return (size_t)((P + 63) >> 6) * (size_t)(P + 63) * 64 + 16 * 64; // floats (+ 16 rows in front: the ring's loads need no clamp)
 }
-inline size_t band_wsk_bytes(int T, int n)
+// forward-solution scratch: one block per resident wavefront of the launch
+inline size_t band_wsk_bytes(int T, int d, int n, int nw)
 {
-    return (((size_t)device_cu_count() * 8 * band_wsk_per_wave(T, n) * sizeof(float)) + 255) & ~(size_t)255;
+    return (((size_t)device_cu_count() * band_wg_per_cu(T, d, n, nw) * nw * band_wsk_per_wave(T, n) * sizeof(float)) + 255) & ~(size_t)255;
 }
 } // namespace
 
@@ -506,21 +1125,75 @@ namespace {
 inline size_t band_flag_bytes(int A, int B) { return (((size_t)A * B + 255) & ~(size_t)255) + generic_repair_bytes(); }
 } // namespace
 
+namespace {
+inline int bandp_wg_per_cu(int T, int d, int n, bool grad = true)
+{
+    const int P = (T - 1) << n, nb = (P + 63) >> 6;
+    const BandPLds L = bandp_lds(T, P, d <= 8 ? 8 : 16);
+    const int by_lds = (160 * 1024) / (L.total + 1024);
+    const int by_waves = 16 / (BPP * nb); // (every instantiation fits four wavefronts per SIMD: <= 128 registers)
+    const int k = by_lds < by_waves ? by_lds : by_waves;
+    return k < 1 ? 1 : k;
+}
+inline GradGeom bandp_geometry(int A, int B, int T, int d, int n, bool sym, bool grad = true)
+{
+    return grad_geometry(A, B, T * d, sym, 0, 1, false, BPP, (long long)device_cu_count() * bandp_wg_per_cu(T, d, n, grad));
+}
+inline size_t bandp_wsk_per_pair(int T, int n)
+{
+    const int P = (T - 1) << n;
+    const size_t rows = (size_t)((P + 63 + BGS - 1) / BGS) * BGS; // whole phases per band
+    return (size_t)((P + 63) >> 6) * rows * 64 + 32 * 64; // floats (+ 32 rows in front: the ring's loads need no clamp)
+}
+inline size_t bandp_wsk_bytes(int T, int d, int n)
+{
+    return (((size_t)device_cu_count() * bandp_wg_per_cu(T, d, n) * BPP * bandp_wsk_per_pair(T, n) * sizeof(float)) + 255) & ~(size_t)255;
+}
+} // namespace
+
 int band_workspace_bytes(int A, int B, int T, int d, int n, int want_grad, size_t *bytes)
 {
     *bytes = band_flag_bytes(A, B) + 512;
     if (!want_grad) return SIGSVGD_OK;
-    const GradGeom o = band_geometry(A, B, T, d, false, band_nw(A, B, false));
-    size_t need = o.rseg_bytes;
+    const int nwo = band_nw(A, B, false);
+    const GradGeom o = band_geometry(A, B, T, d, n, false, nwo);
+    size_t need = o.rseg_bytes, wsk = band_wsk_bytes(T, d, n, nwo);
     if (A == B) {
-        const GradGeom y = band_geometry(A, B, T, d, true, band_nw(A, B, true));
+        const int nwy = band_nw(A, B, true);
+        const GradGeom y = band_geometry(A, B, T, d, n, true, nwy);
         if (y.rseg_bytes + y.cslab_bytes > need) need = y.rseg_bytes + y.cslab_bytes;
+        if (band_wsk_bytes(T, d, n, nwy) > wsk) wsk = band_wsk_bytes(T, d, n, nwy);
     }
-    *bytes = need + band_wsk_bytes(T, n) + band_flag_bytes(A, B) + 1024;
+    *bytes = need + wsk + band_flag_bytes(A, B) + 1024;
+    { // the band-parallel launch
+        const GradGeom po = bandp_geometry(A, B, T, d, n, false);
+        size_t pneed = po.rseg_bytes;
+        if (A == B) {
+            const GradGeom py = bandp_geometry(A, B, T, d, n, true);
+            if (py.rseg_bytes + py.cslab_bytes > pneed) pneed = py.rseg_bytes + py.cslab_bytes;
+        }
+        const size_t pb = pneed + bandp_wsk_bytes(T, d, n) + band_flag_bytes(A, B) + 1024;
+        if (pb > *bytes) *bytes = pb;
+    }
     return SIGSVGD_OK;
 }
 
 namespace {
+// (the dynamic-LDS limit of an instantiation, raised once per device: see gram_generic.hip)
+template <int DPAD, bool GRAD, bool SYM, bool COMP, int BNW>
+hipError_t band_raise_lds()
+{
+    static std::atomic<unsigned long long> raised{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !((raised.load(std::memory_order_acquire) >> dev) & 1ull)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gram_band_kernel<DPAD, GRAD, SYM, COMP, BNW>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        if (dev >= 0 && dev < 64) raised.fetch_or(1ull << dev, std::memory_order_release);
+    }
+    return hipSuccess;
+}
 template <int DPAD, int BNW>
 int band_launch_variant(const GramProblem &p, BandArgs &a, const GradGeom &g, bool grad, bool sym)
 {
@@ -529,10 +1202,13 @@ int band_launch_variant(const GramProblem &p, BandArgs &a, const GradGeom &g, bo
     a.nitems = g.nitems;
     dim3 grid((unsigned)g.grid), block(BNW * 64);
     const bool comp = p.n >= 5;
+    const unsigned lds = (unsigned)band_lds(p.T, (p.T - 1) << p.n, DPAD, BNW).total;
 #define SIGB_LAUNCH(G, S)                                                                                       \
     {                                                                                                           \
-        if (comp) hipLaunchKernelGGL((gram_band_kernel<DPAD, G, S, true, BNW>), grid, block, 0, p.stream, a);   \
-        else hipLaunchKernelGGL((gram_band_kernel<DPAD, G, S, false, BNW>), grid, block, 0, p.stream, a);       \
+        hipError_t ae = comp ? band_raise_lds<DPAD, G, S, true, BNW>() : band_raise_lds<DPAD, G, S, false, BNW>(); \
+        if (ae != hipSuccess) return hip_fail(ae, "hipFuncSetAttribute(gram_band_kernel)");                     \
+        if (comp) hipLaunchKernelGGL((gram_band_kernel<DPAD, G, S, true, BNW>), grid, block, lds, p.stream, a); \
+        else hipLaunchKernelGGL((gram_band_kernel<DPAD, G, S, false, BNW>), grid, block, lds, p.stream, a);     \
     }
     if (grad && sym)
         SIGB_LAUNCH(true, true)
@@ -549,8 +1225,128 @@ int band_launch_variant(const GramProblem &p, BandArgs &a, const GradGeom &g, bo
 }
 } // namespace
 
+namespace {
+template <int DPAD, bool GRAD, bool SYM, bool COMP>
+hipError_t bandp_raise_lds()
+{
+    static std::atomic<unsigned long long> raised{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !((raised.load(std::memory_order_acquire) >> dev) & 1ull)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gram_bandp_kernel<DPAD, GRAD, SYM, COMP>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        if (dev >= 0 && dev < 64) raised.fetch_or(1ull << dev, std::memory_order_release);
+    }
+    return hipSuccess;
+}
+template <int DPAD>
+int bandp_launch_variant(const GramProblem &p, BandArgs &a, const GradGeom &g, bool grad, bool sym)
+{
+    if (g.tm.owned <= 0 || g.nitems <= 0) return SIGSVGD_OK;
+    a.tm = g.tm;
+    a.nitems = g.nitems;
+    const int P = (p.T - 1) << p.n, nb = (P + 63) >> 6;
+    dim3 grid((unsigned)g.grid), block(BPP * nb * 64);
+    const bool comp = p.n >= 5;
+    const unsigned lds = (unsigned)bandp_lds(p.T, P, DPAD).total;
+#define SIGBP_LAUNCH(G, S)                                                                                   \
+    {                                                                                                        \
+        hipError_t ae = comp ? bandp_raise_lds<DPAD, G, S, true>() : bandp_raise_lds<DPAD, G, S, false>();   \
+        if (ae != hipSuccess) return hip_fail(ae, "hipFuncSetAttribute(gram_bandp_kernel)");                 \
+        if (comp) hipLaunchKernelGGL((gram_bandp_kernel<DPAD, G, S, true>), grid, block, lds, p.stream, a);  \
+        else hipLaunchKernelGGL((gram_bandp_kernel<DPAD, G, S, false>), grid, block, lds, p.stream, a);      \
+    }
+    if (grad && sym)
+        SIGBP_LAUNCH(true, true)
+    else if (grad)
+        SIGBP_LAUNCH(true, false)
+    else if (sym)
+        SIGBP_LAUNCH(false, true)
+    else
+        SIGBP_LAUNCH(false, false)
+#undef SIGBP_LAUNCH
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "launch gram_bandp_kernel");
+    return SIGSVGD_OK;
+}
+// Which kernel a launch takes.  The band-parallel kernel wins while its workgroups (one pair each) pass through the chip in a
+// few rounds -- its wavefronts idle BLAG (nb - 1) phases of every sweep, which other workgroups on the CU fill, but the sum of
+// a pair's wavefront time is nb / (1 + BLAG (nb - 1) BGS / (P + 63)) times the serial kernel's; measured on MI355X (Gram +
+// gradient, symmetric): 10 points order 4 -- N = 50 / 100 / 150: 0.117 / 0.41 / 0.90 ms against 0.152 / 0.47 / 0.78 serial;
+// 30 points order 3 -- N = 35 / 60 / 100: 0.157 / 0.36 / 0.92 against 0.262 / 0.34 / 0.97.  Rule: at most four rounds.
+// SIGSVGD_BAND_MODE=serial|parallel (read per launch) overrides it: the tests drive both kernels over the same shapes.
+inline bool band_use_parallel(const GramProblem &p, bool sym)
+{
+    const char *e = getenv("SIGSVGD_BAND_MODE");
+    if (e && e[0] == 's') return false;
+    if (e && e[0] == 'p') return true;
+    const long long pairs = sym ? (long long)p.A * (p.A + 1) / 2 : (long long)p.A * p.B;
+    return pairs <= 4ll * device_cu_count() * bandp_wg_per_cu(p.T, p.d, p.n, p.gradX_out != nullptr);
+}
+} // namespace
+
+static int bandp_launch(const GramProblem &p)
+{
+    const bool grad = p.gradX_out != nullptr;
+    const bool sym = (p.flags & SIGSVGD_FLAG_Y_IS_X) && p.A == p.B;
+    BandArgs a;
+    a.X = p.X; a.Y = p.Y; a.go = p.grad_out; a.K = p.K_out; a.rseg = nullptr; a.cslab = nullptr; a.wsk = nullptr;
+    a.wsk_per_wave = bandp_wsk_per_pair(p.T, p.n);
+    a.io64 = p.dtype == SIGSVGD_F64; a.A = p.A; a.B = p.B; a.T = p.T; a.d = p.d; a.n = p.n;
+    a.symw = (p.flags & SIGSVGD_FLAG_SYM) ? 1 : 0; a.inv_h = p.inv_h;
+    a.nitems = 0;
+    if (a.symw && p.A != p.B) {
+        set_error("sym backward needs A == B");
+        return SIGSVGD_E_BADARG;
+    }
+    const GradGeom g = bandp_geometry(p.A, p.B, p.T, p.d, p.n, sym, grad);
+    const size_t slabs = grad ? (g.rseg_bytes + g.cslab_bytes + 255) & ~(size_t)255 : 0;
+    const size_t need = band_flag_bytes(p.A, p.B) + slabs + (grad ? bandp_wsk_bytes(p.T, p.d, p.n) : 0) + 256;
+    if (!p.ws || p.ws_bytes < need) {
+        set_error("band: workspace %zu B < required %zu B", p.ws_bytes, need);
+        return SIGSVGD_E_WORKSPACE;
+    }
+    unsigned char *base = reinterpret_cast<unsigned char *>((reinterpret_cast<uintptr_t>(p.ws) + 255) & ~(uintptr_t)255);
+    a.kflag = base;
+    base += band_flag_bytes(p.A, p.B);
+    if (grad) {
+        a.rseg = reinterpret_cast<double *>(base);
+        a.cslab = sym ? reinterpret_cast<float *>(base + g.rseg_bytes) : nullptr;
+        a.wsk = reinterpret_cast<float *>(base + slabs);
+    }
+#ifdef SIGSVGD_PHASE_STAMPS
+    {
+        static unsigned long long *dbg = nullptr;
+        if (!dbg) (void)hipMalloc(&dbg, 8 * sizeof(unsigned long long));
+        (void)hipMemsetAsync(dbg, 0, 8 * sizeof(unsigned long long), p.stream);
+        a.stamps = dbg;
+    }
+#endif
+    int rc = p.d <= 8 ? bandp_launch_variant<8>(p, a, g, grad, sym) : bandp_launch_variant<16>(p, a, g, grad, sym);
+    if (rc) return rc;
+#ifdef SIGSVGD_PHASE_STAMPS
+    {
+        unsigned long long hs[8];
+        (void)hipStreamSynchronize(p.stream);
+        (void)hipMemcpy(hs, a.stamps, sizeof(hs), hipMemcpyDeviceToHost);
+        double tot = 0;
+        for (int k = 0; k < 8; ++k) tot += (double)hs[k];
+        static const char *nm[8] = {"staging/other", "static kernel (band 0)", "forward steps", "forward barriers + idle phases",
+                                    "reverse steps", "reverse barriers + idle phases", "verdict + coarse gradient (band 0) / wait", "-"};
+        fprintf(stderr, "[phase stamps band-parallel] A=%d T=%d d=%d n=%d grad=%d sym=%d: ", p.A, p.T, p.d, p.n, grad ? 1 : 0, sym ? 1 : 0);
+        for (int k = 0; k < 7; ++k) fprintf(stderr, "%s %.1f%% | ", nm[k], 100.0 * (double)hs[k] / tot);
+        fprintf(stderr, "total %.3e wave-cycles\n", tot);
+    }
+#endif
+    rc = generic_repair_launch(p, a.kflag, nullptr, sym, g.tm, BPP);
+    if (rc || !grad) return rc;
+    return grad_reduce_launch(g, a.rseg, a.cslab, p.gradX_out, p.dtype == SIGSVGD_F64, p.A, p.B, p.T * p.d, sym, p.stream);
+}
+
 int band_launch(const GramProblem &p)
 {
+    if (band_use_parallel(p, (p.flags & SIGSVGD_FLAG_Y_IS_X) && p.A == p.B)) return bandp_launch(p);
     const bool grad = p.gradX_out != nullptr;
     const bool sym = (p.flags & SIGSVGD_FLAG_Y_IS_X) && p.A == p.B;
     BandArgs a;
@@ -564,9 +1360,9 @@ int band_launch(const GramProblem &p)
         return SIGSVGD_E_BADARG;
     }
     const int nw = band_nw(p.A, p.B, sym);
-    const GradGeom g = band_geometry(p.A, p.B, p.T, p.d, sym, nw);
+    const GradGeom g = band_geometry(p.A, p.B, p.T, p.d, p.n, sym, nw);
     const size_t slabs = grad ? (g.rseg_bytes + g.cslab_bytes + 255) & ~(size_t)255 : 0;
-    const size_t need = band_flag_bytes(p.A, p.B) + slabs + (grad ? band_wsk_bytes(p.T, p.n) : 0) + 256;
+    const size_t need = band_flag_bytes(p.A, p.B) + slabs + (grad ? band_wsk_bytes(p.T, p.d, p.n, nw) : 0) + 256;
     if (!p.ws || p.ws_bytes < need) {
         set_error("band: workspace %zu B < required %zu B", p.ws_bytes, need);
         return SIGSVGD_E_WORKSPACE;

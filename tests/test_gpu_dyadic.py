@@ -102,7 +102,10 @@ def test_dyadic_reference_shapes_at_their_sizes(gpu):
     bandwidth 5) and the maze controller's (35 policies x 30 steps x 2, order 3, sigma^2 = 32)"""
     from sigsvgd_amd import ops
 
-    for N, T, d, n, h in [(30, 5, 2, 5, 0.9), (16, 20, 2, 2, 1.0), (300, 5, 2, 5, 1.0), (100, 10, 2, 4, 5.0), (35, 30, 2, 3, 5.6)]:
+    # (150 x 10, order 4: 11,325 pairs, more than four rounds of band-parallel workgroups -- the serial band kernel by the
+    #  launcher's own rule; the notebook and maze sizes take the band-parallel kernel)
+    for N, T, d, n, h in [(30, 5, 2, 5, 0.9), (16, 20, 2, 2, 1.0), (300, 5, 2, 5, 1.0), (100, 10, 2, 4, 5.0), (35, 30, 2, 3, 5.6),
+                          (150, 10, 2, 4, 5.0)]:
         X = _paths(N, T, d, 11, 0.3)
         Xg = torch.as_tensor(X, device=gpu)
         K, g = ops.gram_fwd_bwd(Xg, Xg, 1.0 / h, n, y_is_x=True)
@@ -132,3 +135,35 @@ def test_band_kernel_rough_and_smooth_extremes(gpu, T, n, d, scale, h, offset):
         assert _rel(g.cpu().numpy(), gref) < TOL
     for K in [ops.gram_fwd(Xg, Xg, 1.0 / h, n, y_is_x=True), ops.gram_fwd(Xg, Xg.clone(), 1.0 / h, n)]:
         assert _relK(K.cpu().numpy(), Kref) < 5e-6
+
+
+@pytest.mark.parametrize("T,n,d", BAND_SHAPES)
+@pytest.mark.parametrize("sym", [True, False])
+def test_band_kernels_agree(gpu, monkeypatch, T, n, d, sym):
+    """gram_band.hip holds two kernels for 129 .. 256 cells per side: one wavefront per pair (launches with many pairs) and one
+    wavefront per BAND of a pair, pipelined over a workgroup (the reference's sizes).  Same arithmetic per cell and the same
+    order in every block sum: K and the flags of the exact pass are equal bit for bit; the gradients differ by the order of
+    the fixed-order reduction only (tiles of 8 or 4 rows against tiles of one).  SIGSVGD_BAND_MODE picks the kernel."""
+    from sigsvgd_amd import ops
+
+    A, B = 11, 11 if sym else 7
+    X = _paths(A, T, d, 21, 0.2)
+    Y = X if sym else _paths(B, T, d, 22, 0.2)
+    go = np.random.default_rng(3).uniform(0.5, 1.5, (A, B)).astype(np.float32)
+    Kref, gref = C.gram_fwd_bwd(X, Y, 1.0, n, grad_out=go.astype(np.float64))
+    Xg, gog = torch.as_tensor(X, device=gpu), torch.as_tensor(go, device=gpu)
+    Yg = Xg if sym else torch.as_tensor(Y, device=gpu)
+    res = {}
+    for mode in ("serial", "parallel"):
+        monkeypatch.setenv("SIGSVGD_BAND_MODE", mode)
+        K, g = ops.gram_fwd_bwd(Xg, Yg, 1.0, n, grad_out=gog, y_is_x=sym)
+        Kf = ops.gram_fwd(Xg, Yg, 1.0, n, y_is_x=sym)
+        K2, g2 = ops.gram_fwd_bwd(Xg, Yg, 1.0, n, grad_out=gog, y_is_x=sym)
+        torch.cuda.synchronize()
+        assert torch.equal(K, K2) and torch.equal(g, g2)  # (reproducible, each of them)
+        assert _relK(K.cpu().numpy(), Kref) < TOL and _relK(Kf.cpu().numpy(), Kref) < TOL
+        assert _rel(g.cpu().numpy(), gref) < TOL
+        res[mode] = (K.cpu().numpy(), Kf.cpu().numpy(), g.cpu().numpy())
+    assert np.array_equal(res["serial"][0], res["parallel"][0])
+    assert np.array_equal(res["serial"][1], res["parallel"][1])
+    assert _rel(res["parallel"][2], res["serial"][2].astype(np.float64)) < 2e-6
