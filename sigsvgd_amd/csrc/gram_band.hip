@@ -541,12 +541,12 @@ constexpr int BGS = 16; // steps per phase
 constexpr int BLAG = 5; // phases a band runs behind its neighbour: BLAG * BGS > 62 + BGS + 1 steps (see the refills in the kernel)
 constexpr int BPP = 1;  // pairs per workgroup
 constexpr int BUO = 96; // offset of entry 0 in a reverse boundary row (a phase reads down to entry P - 16 - sp0 >= -78)
-// The increment table carries BZP zeros on either side of every row and one row of zeros behind the last: a lane outside the
+// The increment table carries zeros on either side of every row and one row of zeros behind the last: a lane outside the
 // grid (column < 0 or >= P on the ramps of its band, or a row >= P of the last band) reads gamma = 0, for which a step leaves
 // V alone and copies the neighbour's value -- ahead of its row that is the boundary value 1 all the way down the lanes, so a
-// lane starts its row from the right state with no activity test and none of the three selects in the step (columns reach
-// -63 - 15 .. P + 78, i.e. at most ten coarse cells past a row's end for r >= 8).
-constexpr int BZP = 10;
+// lane starts its row from the right state with no activity test and none of the three selects in the step.  Columns reach
+// -78 .. P + 78: band_zpad(r) coarse cells past a row's end.
+__host__ __device__ inline int band_zpad(int r) { return 80 / r + 2; }
 
 struct BandPLds {
     int yd, yf, yref;                        // shared by the workgroup
@@ -568,7 +568,7 @@ __host__ __device__ inline BandPLds bandp_lds(int T, int P, int dpad)
     int w = 0;
     L.Sc = w;     w += up16(cells * 8);
     L.misc = w;   w += 64;
-    const int dtab = (Tm + 1) * (Tm + 2 * BZP); // padded increment table (see BZP)
+    const int dtab = (Tm + 1) * (Tm + 2 * band_zpad(P / Tm)); // padded increment table (see band_zpad)
     L.Dc = w;     w += up16((dtab > rows ? dtab : rows) * 4);
     L.hK = w;     w += up16((nb - 1) * L.hn * 4);
     L.hU = w;     w += up16((nb - 1) * L.hn * 4);
@@ -602,7 +602,8 @@ __device__ __forceinline__ void bandp_fwd_phase(BandFwd &st, const float (&hv)[B
     for (int u = 0; u < BHS; ++u) {
         const bool active = !FREEZE || (unsigned)(st.q1 - 1) < qlim;
         const float g = gq[u];
-        const float up = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(hv[u]), __float_as_int(st.cur), 0x138, 0xF, 0xF, false));
+        float up = hv[u]; // (lane 0 has no source lane: it keeps the boundary row's entry.  asm: the builtin copies hv[u] first)
+        asm("s_nop 1\n\tv_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(up) : "v"(st.cur));
         // K11 - K01 = (K10 - K00) + F,  F = gamma (sqrt(3) t + gamma (t + K00)),  t = K10 + K01
         const float t = st.cur + up;
         float y = 1.7320508075688772f * t;
@@ -626,15 +627,27 @@ __device__ __forceinline__ void bandp_fwd_phase(BandFwd &st, const float (&hv)[B
 // The same for the reverse sweep: the boundary lane is lane 63 of a full band (no DPP source from above: keeps hv[u]); the
 // last band's boundary is U = 1, which lane L - 1 finds in lane L (a row outside the grid never leaves its initial 1).
 struct BandRev {
-    float cur, dprev, V, run;
+    float cur, dprev, V, run, out;
     int q;
 };
 // ALLIN: every lane is inside the grid on every step of the phase (no activity test for the block sums).  The state of a lane
-// outside the grid needs no protection in this direction (zeros around the rows, see BZP; nothing is read from it later).
+// outside the grid needs no protection in this direction (zeros around the rows, see band_zpad; nothing is read from it later).
+//
+// Block sums of S = K_fwd * U: a lane sums its row over the r fine columns of a coarse cell (`run`), and the r lanes of a coarse
+// row pass the cell's sum UP the lanes -- lane l + 1 ends a cell one step before lane l, so `out` = run + what the lane below
+// handed over the step before (one DPP move and one multiply-add; `chain` = 0 in the bottom lane of a coarse row) is the
+// cell's sum over the rows from l down on the step lane l ends it.  The TOP lanes of all coarse rows end their cells on the
+// same steps, sp = L - 2 mod r -- and L - 2 = 6 mod 8 in every band (P and the band offsets are multiples of 8 <= r), i.e.
+// always on step BFU = 6 of an unrolled group of 8: the group hands that step's sum and cell out, and the caller adds it to
+// the fp64 table BEHIND the group on the groups that end a cell (a uniform test per group; a branch inside the unrolled steps
+// was measured: it splits the scheduling region and costs 8 %).  Rounds 3-4 / the serial kernel: one ds_add_f64 of every
+// lane on every step, 8 of the step's 27 instructions.  The sum over a coarse row's lanes is fp32 (r <= 64 terms), the table
+// stays fp64.
+constexpr int BFU = 6;
 template <bool ALLIN>
 __device__ __forceinline__ void bandp_rev_phase(BandRev &st, const float (&hv)[BHS], float (&kfr)[8], const float *rnext, int lanep,
-                                                const float *dcrow, double *scrow, double *dumpl, int n, int r, int P, bool rowvalid,
-                                                float *ho)
+                                                const float *dcrow, float chain, bool top, int n, int r, int P, bool rowvalid,
+                                                float *ho, float &out6, int &cell6)
 {
     float gq[BHS];
 #pragma unroll
@@ -645,15 +658,16 @@ __device__ __forceinline__ void bandp_rev_phase(BandRev &st, const float (&hv)[B
         const float g = gq[u];
         const float kf = kfr[u & 7];
         kfr[u & 7] = rnext[lanep - 64 * u];
-        const float down = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(hv[u]), __float_as_int(st.cur), 0x130, 0xF, 0xF, false));
-        // block sums without a branch: every lane adds every step -- its finished run to the coarse cell when it has just taken
-        // the cell's leftmost fine column, a zero to its own dump cell otherwise
+        float down = hv[u]; // (lane 63 has no source lane: it keeps the boundary row's entry)
+        asm("s_nop 1\n\tv_mov_b32_dpp %0, %1 wave_shl:1 row_mask:0xf bank_mask:0xf" : "+v"(down) : "v"(st.cur));
         st.run = __builtin_fmaf(active ? kf : 0.f, st.dprev, st.run);
-        const bool fl = active && (st.q & (r - 1)) == 0;
-        float addend = fl ? st.run : 0.f;
-        asm volatile("" : "+v"(addend)); // (select, then convert: hipcc otherwise converts and selects both halves)
-        unsafeAtomicAdd(fl ? scrow + (st.q >> n) : dumpl, (double)addend); // ds_add_f64
-        st.run = fl ? 0.f : st.run;
+        const float recv = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(st.out), 0x130, 0xF, 0xF, true)); // lane 63: 0
+        st.out = __builtin_fmaf(recv, chain, st.run);
+        if (u == BFU) { // the one step of a group on which the top lanes can end a cell (see BFU): flushed behind the group
+            out6 = st.out;
+            cell6 = (top && active) ? st.q >> n : -1;
+        }
+        st.run = (st.q & (r - 1)) == 0 ? 0.f : st.run; // (a lane outside the grid carries run = 0 anyway)
         const float t = st.cur + down;
         float y = 1.7320508075688772f * t;
         y = __builtin_fmaf(t + st.dprev, g, y);
@@ -681,7 +695,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
     const double dscale = 1.0 / ((double)r * (double)r * 3.46410161513775459); // 1 / (r^2 sqrt(12))
     const double inv_r2 = 1.0 / ((double)r * (double)r);
     const BandPLds lay = bandp_lds(T, P, DPAD);
-    const int DS = Tm + 2 * BZP; // floats per row of the increment table
+    const int BZP = band_zpad(r), DS = Tm + 2 * BZP; // zeros on either side of a row of the increment table, floats per row
     double *yd = reinterpret_cast<double *>(band_smem + lay.yd);
     double *yref = reinterpret_cast<double *>(band_smem + lay.yref);
     float *yf = reinterpret_cast<float *>(band_smem + lay.yf);
@@ -877,8 +891,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
                 double *scrow = Sc + arow * Tm;
                 const bool lastband = band == nb - 1;
                 BandRev st;
-                st.cur = 1.f; st.dprev = 1.f; st.V = 0.f; st.run = 0.f;
+                st.cur = 1.f; st.dprev = 1.f; st.V = 0.f; st.run = 0.f; st.out = 0.f;
                 st.q = P - 1 + (L - 1 - lanep);
+                const int rr = min(r, 64);
+                const float chain = ((p & (rr - 1)) == rr - 1) ? 0.f : 1.f; // the bottom lane of a coarse row takes nothing from below
+                const bool top = rowvalid && (p & (rr - 1)) == 0;
                 // K_fwd[p][q] was stored on forward step lane + q: row R = P + L - 2 - sp of the band's scratch on step sp
                 const float *wrow = wsw + (size_t)band * nsr * 64 + lanep;
                 const int R = P + L - 2;
@@ -926,10 +943,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
                                 for (int k = 0; k < BHS; ++k)
                                     if (sp0 + h + k > P - 1) hv[k] = 1.f;
                             }
+                            float out6;
+                            int cell6;
                             if (plat)
-                                bandp_rev_phase<true>(st, hv, kfr, rnext - h * 64, lanep, dcrow, scrow, dumpd + lanep, n, r, P, rowvalid, ho - (hands ? h : 0));
+                                bandp_rev_phase<true>(st, hv, kfr, rnext - h * 64, lanep, dcrow, chain, top, n, r, P, rowvalid, ho - (hands ? h : 0), out6, cell6);
                             else
-                                bandp_rev_phase<false>(st, hv, kfr, rnext - h * 64, lanep, dcrow, scrow, dumpd + lanep, n, r, P, rowvalid, ho - (hands ? h : 0));
+                                bandp_rev_phase<false>(st, hv, kfr, rnext - h * 64, lanep, dcrow, chain, top, n, r, P, rowvalid, ho - (hands ? h : 0), out6, cell6);
+                            // (step BFU of the group ends the top lanes' cells iff L - 2 - (sp0 + h + BFU) = 0 mod r)
+                            if (((L - 2 - sp0 - h - BFU) & (r - 1)) == 0 && cell6 >= 0) unsafeAtomicAdd(scrow + cell6, (double)out6); // ds_add_f64
                         }
                         rnext -= BGS * 64;
                         ho += hinc;
@@ -1084,7 +1105,7 @@ bool band_supported(int A, int B, int T, int d, int n, int kind, unsigned flags)
     (void)A; (void)B;
     if (n < 1 || n > 7 || T < 3 || T > BTMAX || d > 16) return false;
     const int P = (T - 1) << n;
-    if (P <= 128 || P > BPMAX) return false;
+    if (P <= 128 || P > BPMAX) return false; // (so r = P / (T - 1) >= 8: the kernels' unrolled groups rely on it)
     if (kind != SIGSVGD_STATIC_RBF) return false;
     if (flags & SIGSVGD_FLAG_NAIVE_SOLVER) return false;
     return true;
