@@ -572,6 +572,7 @@ __host__ __device__ inline BandPLds bandp_lds(int T, int P, int dpad)
     L.Dc = w;     w += up16((dtab > rows ? dtab : rows) * 4);
     L.hK = w;     w += up16((nb - 1) * L.hn * 4);
     L.hU = w;     w += up16((nb - 1) * L.hn * 4);
+    if (w - L.hK < up16((T * T + rows) * 4)) w = L.hK + up16((T * T + rows) * 4); // (the contraction's tables reuse the two blocks)
     L.rowacc = w; w += up16(rows * 4);
     L.dump = w;   w += nb * (96 * 4 + 64 * 8);
     L.per_pair = w;
@@ -644,8 +645,9 @@ struct BandRev {
 // lane on every step, 8 of the step's 27 instructions.  The sum over a coarse row's lanes is fp32 (r <= 64 terms), the table
 // stays fp64.
 constexpr int BFU = 6;
-template <bool ALLIN>
-__device__ __forceinline__ void bandp_rev_phase(BandRev &st, const float (&hv)[BHS], float (&kfr)[8], const float *rnext, int lanep,
+constexpr int BKR = 8; // depth of the register ring the forward solution comes back through (16: maze shape -1.6 %, but 142 registers)
+template <bool ALLIN, int H>
+__device__ __forceinline__ void bandp_rev_phase(BandRev &st, const float (&hv)[BHS], float (&kfr)[BKR], const float *rnext, int lanep,
                                                 const float *dcrow, float chain, bool top, int n, int r, int P, bool rowvalid,
                                                 float *ho, float &out6, int &cell6)
 {
@@ -656,8 +658,8 @@ __device__ __forceinline__ void bandp_rev_phase(BandRev &st, const float (&hv)[B
     for (int u = 0; u < BHS; ++u) {
         const bool active = ALLIN || (rowvalid && (unsigned)st.q < (unsigned)P);
         const float g = gq[u];
-        const float kf = kfr[u & 7];
-        kfr[u & 7] = rnext[lanep - 64 * u];
+        const float kf = kfr[(H + u) & (BKR - 1)];
+        kfr[(H + u) & (BKR - 1)] = rnext[lanep - 64 * u];
         float down = hv[u]; // (lane 63 has no source lane: it keeps the boundary row's entry)
         asm("s_nop 1\n\tv_mov_b32_dpp %0, %1 wave_shl:1 row_mask:0xf bank_mask:0xf" : "+v"(down) : "v"(st.cur));
         st.run = __builtin_fmaf(active ? kf : 0.f, st.dprev, st.run);
@@ -673,7 +675,7 @@ __device__ __forceinline__ void bandp_rev_phase(BandRev &st, const float (&hv)[B
         y = __builtin_fmaf(t + st.dprev, g, y);
         const float Vn = __builtin_fmaf(g, y, st.V);
         const float nw = down + Vn;
-        ho[-u] = nw; // (a lane outside the grid writes into the padding, or entries nobody reads)
+        ho[BHS - 1 - u] = nw; // (`ho` is the group's LAST entry: LDS offsets are unsigned.  A lane outside the grid writes into the padding, or entries nobody reads)
         st.cur = nw;
         st.V = Vn;
         st.dprev = down;
@@ -706,6 +708,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
     float *hUall = reinterpret_cast<float *>(pbase + lay.hU);         // row b: U[64 (b + 1)][.], written by band b + 1, read by band b
     float *rowacc = reinterpret_cast<float *>(pbase + lay.rowacc);
     float *misc = reinterpret_cast<float *>(pbase + lay.misc);        // [0..1]: K[P][P] (double), [4 + b]: grid maximum of band b
+    float *ones = misc + 8;                                           // [8]: the boundary of the first / last band
     float *dump = reinterpret_cast<float *>(pbase + lay.dump + band * (96 * 4 + 64 * 8)); // [96]: a phase writes 16 entries from the lane's cell
     double *dumpd = reinterpret_cast<double *>(pbase + lay.dump + band * (96 * 4 + 64 * 8) + 96 * 4);
     float *wsw = GRAD ? a.wsk + ((size_t)blockIdx.x * BPP + slot) * a.wsk_per_wave + 32 * 64 : nullptr; // the pair's forward solution (32 rows of padding in front)
@@ -717,6 +720,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
 #ifdef SIGSVGD_PHASE_STAMPS
     unsigned long long ph_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast_ = __builtin_amdgcn_s_memtime();
 #endif
+    if (band == 0 && lane < 8) ones[lane] = 1.f; // (read after the first pair's staging barriers)
     const long long it0 = a.nitems * blockIdx.x / gridDim.x, it1 = a.nitems * (blockIdx.x + 1) / gridDim.x;
     int remaining = (int)(it1 - it0);
     long long item = it0;
@@ -810,7 +814,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
             // entries a phase of the next band reads start on a 16-byte boundary); the other lanes write into the dump block
             const bool hands = lanep == 63 && band < nb - 1;
             float *ho = hands ? hKall + band * lay.hn + (BPAD - 1) + st.q1 : dump + lanep;
-            const int hinc = hands ? BGS : 0;
+            const int hinc = hands ? BHS : 0; // (per group of steps)
             const float *hin = hKall + (band - 1) * lay.hn + BPAD; // (band 0: not read)
             const unsigned qlim = rowvalid ? (unsigned)P : 0u;
 #pragma unroll 1
@@ -824,16 +828,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
 #pragma unroll 1
                     for (int h = 0; h < BGS; h += BHS) {
                         float hv[BHS];
-                        if (band) {
-                            const float4 *h4 = reinterpret_cast<const float4 *>(hin + s0 + h);
+                        { // (band 0: eight ones kept in LDS -- a select of the address instead of a branch around the loads)
+                            const float4 *h4 = reinterpret_cast<const float4 *>(band ? hin + s0 + h : ones);
 #pragma unroll
                             for (int k = 0; k < BHS / 4; ++k) {
                                 const float4 v = h4[k];
                                 hv[4 * k] = v.x; hv[4 * k + 1] = v.y; hv[4 * k + 2] = v.z; hv[4 * k + 3] = v.w;
                             }
-                        } else {
-#pragma unroll
-                            for (int k = 0; k < BHS; ++k) hv[k] = 1.f;
                         }
                         if (band && s0 + h + BHS > P) { // entries beyond P were never written: their lanes are past the grid, but
 #pragma unroll                                            // whatever they read reaches the grid maximum (kmax)
@@ -842,11 +843,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
                         }
                         const float *wrow = GRAD ? wb + (size_t)(s0 + h) * 64 : nullptr;
                         if (freeze)
-                            bandp_fwd_phase<true, COMP, GRAD>(st, hv, dcrow, n, qlim, ho + (hands ? h : 0), wrow, lanep * 4);
+                            bandp_fwd_phase<true, COMP, GRAD>(st, hv, dcrow, n, qlim, ho, wrow, lanep * 4);
                         else
-                            bandp_fwd_phase<false, COMP, GRAD>(st, hv, dcrow, n, qlim, ho + (hands ? h : 0), wrow, lanep * 4);
+                            bandp_fwd_phase<false, COMP, GRAD>(st, hv, dcrow, n, qlim, ho, wrow, lanep * 4);
+                        ho += hinc;
                     }
-                    ho += hinc;
                     SIGB_STAMP(2)
                 }
                 __syncthreads();
@@ -899,19 +900,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
                 // K_fwd[p][q] was stored on forward step lane + q: row R = P + L - 2 - sp of the band's scratch on step sp
                 const float *wrow = wsw + (size_t)band * nsr * 64 + lanep;
                 const int R = P + L - 2;
-                const float *rnext = wsw + ((size_t)band * nsr + (R - 8)) * 64; // (uniform row pointer of the ring's next load)
+                const float *rnext = wsw + ((size_t)band * nsr + (R - BKR)) * 64; // (uniform row pointer of the ring's next load)
                 // lane 0 hands U[64 band][q] over through entry q of row band - 1 (entry e at [BUO + e])
                 const bool hands = lanep == 0 && band > 0;
                 float *ho = hands ? hUall + (band - 1) * lay.hn + BUO + st.q : dump + 16 + lanep;
-                const int hinc = hands ? -BGS : 0;
+                const int hinc = hands ? -BHS : 0; // (per group of steps)
                 const float *hin = hUall + band * lay.hn + BUO + (P - BGS); // (last band: not read)
-                float kfr[8];
+                float kfr[BKR];
                 if (valid) {
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) kfr[u] = wrow[(size_t)max(R - u, 0) * 64];
+                    for (int u = 0; u < BKR; ++u) kfr[u] = wrow[(size_t)max(R - u, 0) * 64];
                 } else {
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) kfr[u] = 0.f;
+                    for (int u = 0; u < BKR; ++u) kfr[u] = 0.f;
                 }
                 const int ngb = (P + L - 1 + BGS - 1) / BGS; // this band's phases
                 const int rb = nb - 1 - band;
@@ -926,17 +927,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
 #pragma unroll 1
                         for (int h = 0; h < BGS; h += BHS) {
                             float hv[BHS];
-                            if (!lastband) {
-                                // entries P - 8 - (sp0 + h) .. P - 1 - (sp0 + h), descending over the group's steps
-                                const float4 *h4 = reinterpret_cast<const float4 *>(hin + (BGS - BHS) - sp0 - h);
+                            {
+                                // entries P - 8 - (sp0 + h) .. P - 1 - (sp0 + h), descending over the group's steps (last band: ones)
+                                const float4 *h4 = reinterpret_cast<const float4 *>(lastband ? ones : hin + (BGS - BHS) - sp0 - h);
 #pragma unroll
                                 for (int k = 0; k < BHS / 4; ++k) {
                                     const float4 v = h4[k];
                                     hv[BHS - 1 - 4 * k] = v.x; hv[BHS - 2 - 4 * k] = v.y; hv[BHS - 3 - 4 * k] = v.z; hv[BHS - 4 - 4 * k] = v.w;
                                 }
-                            } else {
-#pragma unroll
-                                for (int k = 0; k < BHS; ++k) hv[k] = 1.f;
                             }
                             if (!lastband && sp0 + h + BHS > P) { // entries below 0 were never written (lanes past the grid)
 #pragma unroll
@@ -945,15 +943,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
                             }
                             float out6;
                             int cell6;
+                            static_assert(BKR == BHS, "a deeper ring needs the group's position in it as a compile-time constant");
                             if (plat)
-                                bandp_rev_phase<true>(st, hv, kfr, rnext - h * 64, lanep, dcrow, chain, top, n, r, P, rowvalid, ho - (hands ? h : 0), out6, cell6);
+                                bandp_rev_phase<true, 0>(st, hv, kfr, rnext, lanep, dcrow, chain, top, n, r, P, rowvalid, ho - (BHS - 1), out6, cell6);
                             else
-                                bandp_rev_phase<false>(st, hv, kfr, rnext - h * 64, lanep, dcrow, chain, top, n, r, P, rowvalid, ho - (hands ? h : 0), out6, cell6);
+                                bandp_rev_phase<false, 0>(st, hv, kfr, rnext, lanep, dcrow, chain, top, n, r, P, rowvalid, ho - (BHS - 1), out6, cell6);
+                            rnext -= BHS * 64;
+                            ho += hinc;
                             // (step BFU of the group ends the top lanes' cells iff L - 2 - (sp0 + h + BFU) = 0 mod r)
                             if (((L - 2 - sp0 - h - BFU) & (r - 1)) == 0 && cell6 >= 0) unsafeAtomicAdd(scrow + cell6, (double)out6); // ds_add_f64
                         }
-                        rnext -= BGS * 64;
-                        ho += hinc;
                         SIGB_STAMP(4)
                     }
                     __syncthreads();
@@ -962,27 +961,45 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
                 // (the ring's last loads are never used: consumed here, or hipcc carries them as pending into the next pair's
                 //  forward step loop and waits for vmcnt(0) in every step -- behind the step's own store, a memory round trip)
 #pragma unroll
-                for (int u = 0; u < 8; ++u) asm volatile("" ::"v"(kfr[u]));
+                for (int u = 0; u < BKR; ++u) asm volatile("" ::"v"(kfr[u]));
             }
 
+            // ---- after the sweeps: the coarse contraction, spread over the pair's wavefronts -------------------------------
+            // R = 4-corner scatter of S_coarse / r^2 as an fp32 table and x~ in fp32, staged by all of them in the boundary
+            // rows' LDS (free now); then the row side on band 0's wavefront and the column side on band 1's, side by side.
+            float *Rt = hKall;         // [T][T]
+            float *xl = hKall + T * T; // [T][DPAD]
+            if (valid) {
+                auto Sat = [&](int aa, int bb) -> float {
+                    return (aa >= 0 && aa < Tm && bb >= 0 && bb < Tm) ? (float)(Sc[aa * Tm + bb] * inv_r2) : 0.f;
+                };
+                const int wtid = band * 64 + lanep, wnt = nb * 64;
+                for (int e = wtid; e < T * T; e += wnt) {
+                    const int m = e / T, nn = e - m * T;
+                    Rt[e] = (Sat(m - 1, nn - 1) + Sat(m, nn)) - (Sat(m - 1, nn) + Sat(m, nn - 1));
+                }
+                for (int e = wtid; e < T * DPAD; e += wnt) {
+                    const int m = e / DPAD, c = e - m * DPAD;
+                    xl[e] = c < d ? (float)(b_ldany(a.X, ((size_t)i * T + m) * d + c, io64) - yref[c]) : 0.f;
+                }
+            }
             if (valid && band == 0) {
                 // the pair's verdict for the exact fp64 pass (see the serial kernel)
-                {
-                    bool ill = false;
-                    if (d <= 3) {
-                        float cs = 0.f;
-                        for (int e = lanep; e < Tm * Tm; e += 64) {
-                            const int ra = e / Tm;
-                            cs = __builtin_fmaf(fabsf((float)Sc[e]), fabsf(Dc[ra * DS + BZP + (e - ra * Tm)]), cs);
-                        }
-#pragma unroll
-                        for (int off = 1; off < 64; off <<= 1) cs += __shfl_xor(cs, off, 64);
-                        ill = kfin_keep == kfin_keep && cs * 3.46410161513775459f > 150.f * fmaxf(fabsf(kfin_keep), 0.1f);
+                bool ill = false;
+                if (d <= 3) {
+                    float cs = 0.f;
+                    for (int e = lanep; e < Tm * Tm; e += 64) {
+                        const int ra = e / Tm;
+                        cs = __builtin_fmaf(fabsf((float)Sc[e]), fabsf(Dc[ra * DS + BZP + (e - ra * Tm)]), cs);
                     }
-                    if (lanep == 0) a.kflag[(size_t)i * a.B + j] = (canc_keep || ill) ? 1 : 0;
+#pragma unroll
+                    for (int off = 1; off < 64; off <<= 1) cs += __shfl_xor(cs, off, 64);
+                    ill = kfin_keep == kfin_keep && cs * 3.46410161513775459f > 150.f * fmaxf(fabsf(kfin_keep), 0.1f);
                 }
-                // ---- coarse gradient: R = 4-corner scatter of S_coarse / r^2, RBF derivative, both contractions ----------
-                // (the weights and x~_m in fp32 are read again here: held through the sweeps they cost the kernel a wavefront per SIMD)
+                if (lanep == 0) a.kflag[(size_t)i * a.B + j] = (canc_keep || ill) ? 1 : 0;
+            }
+            __syncthreads(); // the tables are staged; the increments (verdict) are not needed any more
+            if (valid && band <= (SYM ? 1 : 0)) {
                 float w_ij = 1.f, w_ji = 1.f;
                 if (a.go) {
                     w_ij = (float)b_ldany(a.go, (size_t)i * a.B + j, io64);
@@ -992,24 +1009,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
                     w_ij = 2.f; w_ji = 2.f;
                 }
                 if (SYM && j == i) w_ji = 0.f; // diagonal pair: first-slot derivative only
-                float xf[DPAD];
-                {
-                    const int m = min(lanep, T - 1);
-#pragma unroll
-                    for (int c = 0; c < DPAD; ++c)
-                        xf[c] = c < d ? (float)(b_ldany(a.X, ((size_t)i * T + m) * d + c, io64) - yref[c]) : 0.f;
-                }
                 const float ns32 = (float)(-inv_h * 1.4426950408889634074);
-                auto Sat = [&](int aa, int bb) -> float {
-                    return (aa >= 0 && aa < Tm && bb >= 0 && bb < Tm) ? (float)(Sc[aa * Tm + bb] * inv_r2) : 0.f;
-                };
-                if (lanep < T) {
-                    const int m = lanep;
-                    float acc[DPAD];
+                const int me = min(lanep, T - 1);
+                float acc[DPAD];
 #pragma unroll
-                    for (int c = 0; c < DPAD; ++c) acc[c] = 0.f;
+                for (int c = 0; c < DPAD; ++c) acc[c] = 0.f;
+                if (band == 0) { // row side: lane m sums over the columns n
+                    float xf[DPAD];
+#pragma unroll
+                    for (int c = 0; c < DPAD; ++c) xf[c] = xl[me * DPAD + c];
                     for (int nn = 0; nn < T; ++nn) {
-                        const float Rv = (Sat(m - 1, nn - 1) + Sat(m, nn)) - (Sat(m - 1, nn) + Sat(m, nn - 1));
+                        const float Rv = Rt[me * T + nn];
                         const float *yr = yf + nn * DPAD;
                         float df[DPAD], e2 = 0.f;
 #pragma unroll
@@ -1021,25 +1031,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
 #pragma unroll
                         for (int c = 0; c < DPAD; ++c) acc[c] = __builtin_fmaf(rg, df[c], acc[c]);
                     }
-#pragma unroll
-                    for (int c = 0; c < DPAD; ++c)
-                        if (c < d) rowacc[m * DPAD + c] += w_ij * m2h * acc[c];
-                }
-                if (SYM) {
-                    float *xl = Dc; // (the increments are not needed any more) x~ rows [T][DPAD], then the parked sums
                     if (lanep < T) {
 #pragma unroll
-                        for (int c = 0; c < DPAD; ++c) xl[lanep * DPAD + c] = xf[c];
+                        for (int c = 0; c < DPAD; ++c)
+                            if (c < d) rowacc[me * DPAD + c] += w_ij * m2h * acc[c];
                     }
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_s_waitcnt(0xc07f);
-                    float acc[DPAD];
-#pragma unroll
-                    for (int c = 0; c < DPAD; ++c) acc[c] = 0.f;
-                    const int nn = min(lanep, T - 1);
-                    const float *yr = yf + nn * DPAD;
+                } else { // column side (Y is X): lane n sums over the rows m; the sums are parked in the increment table's place
+                    const float *yr = yf + me * DPAD;
                     for (int m = 0; m < T; ++m) {
-                        const float Rv = (Sat(m - 1, nn - 1) + Sat(m, nn)) - (Sat(m - 1, nn) + Sat(m, nn - 1));
+                        const float Rv = Rt[m * T + me];
                         const float *xr = xl + m * DPAD;
                         float df[DPAD], e2 = 0.f;
 #pragma unroll
@@ -1051,14 +1051,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
 #pragma unroll
                         for (int c = 0; c < DPAD; ++c) acc[c] = __builtin_fmaf(rg, df[c], acc[c]);
                     }
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_s_waitcnt(0xc07f);
-                    if (lanep < T) {
+                    if (lanep < T) { // d k(x_j, x_i) / d y_n = -(2/h) sum_m R G (y~_n - x~_m)
 #pragma unroll
-                        for (int c = 0; c < DPAD; ++c) xl[lanep * DPAD + c] = -(w_ji * m2h) * acc[c];
+                        for (int c = 0; c < DPAD; ++c) Dc[lanep * DPAD + c] = -(w_ji * m2h) * acc[c];
                     }
                 }
-            } else if (SYM && band == 0 && slot < BPP) {
+            } else if (SYM && !valid && band == 0) {
                 for (int e = lane; e < T * DPAD; e += 64) Dc[e] = 0.f; // no pair in this slot: nothing to add to the column
             }
         }
@@ -1294,8 +1292,9 @@ int bandp_launch_variant(const GramProblem &p, BandArgs &a, const GradGeom &g, b
 // Which kernel a launch takes.  The band-parallel kernel wins while its workgroups (one pair each) pass through the chip in a
 // few rounds -- its wavefronts idle BLAG (nb - 1) phases of every sweep, which other workgroups on the CU fill, but the sum of
 // a pair's wavefront time is nb / (1 + BLAG (nb - 1) BGS / (P + 63)) times the serial kernel's; measured on MI355X (Gram +
-// gradient, symmetric): 10 points order 4 -- N = 50 / 100 / 150: 0.117 / 0.41 / 0.90 ms against 0.152 / 0.47 / 0.78 serial;
-// 30 points order 3 -- N = 35 / 60 / 100: 0.157 / 0.36 / 0.92 against 0.262 / 0.34 / 0.97.  Rule: at most four rounds.
+// gradient, symmetric, ms): 10 points order 4 -- N = 50 / 70 / 100 / 150: 0.103 / 0.186 / 0.363 / 0.82 against 0.152 / 0.231 /
+// 0.471 / 0.78 serial (1,275 .. 11,325 pairs on 1,280 resident workgroups); 30 points order 3 -- N = 35 / 60 / 100: 0.136 /
+// 0.331 / 0.86 against 0.261 / 0.338 / 0.97 (630 .. 5,050 pairs on 1,024).  Rule: at most five rounds.
 // SIGSVGD_BAND_MODE=serial|parallel (read per launch) overrides it: the tests drive both kernels over the same shapes.
 inline bool band_use_parallel(const GramProblem &p, bool sym)
 {
@@ -1303,7 +1302,7 @@ inline bool band_use_parallel(const GramProblem &p, bool sym)
     if (e && e[0] == 's') return false;
     if (e && e[0] == 'p') return true;
     const long long pairs = sym ? (long long)p.A * (p.A + 1) / 2 : (long long)p.A * p.B;
-    return pairs <= 4ll * device_cu_count() * bandp_wg_per_cu(p.T, p.d, p.n, p.gradX_out != nullptr);
+    return pairs <= 5ll * device_cu_count() * bandp_wg_per_cu(p.T, p.d, p.n, p.gradX_out != nullptr);
 }
 } // namespace
 

@@ -102,7 +102,7 @@ def test_dyadic_reference_shapes_at_their_sizes(gpu):
     bandwidth 5) and the maze controller's (35 policies x 30 steps x 2, order 3, sigma^2 = 32)"""
     from sigsvgd_amd import ops
 
-    # (150 x 10, order 4: 11,325 pairs, more than four rounds of band-parallel workgroups -- the serial band kernel by the
+    # (150 x 10, order 4: 11,325 pairs, more than five rounds of band-parallel workgroups -- the serial band kernel by the
     #  launcher's own rule; the notebook and maze sizes take the band-parallel kernel)
     for N, T, d, n, h in [(30, 5, 2, 5, 0.9), (16, 20, 2, 2, 1.0), (300, 5, 2, 5, 1.0), (100, 10, 2, 4, 5.0), (35, 30, 2, 3, 5.6),
                           (150, 10, 2, 4, 5.0)]:
