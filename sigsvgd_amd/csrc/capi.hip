@@ -125,7 +125,7 @@ static int dispatch(const GramProblem &p)
         return quad_launch(p);
     // short paths with dyadic refinement whose refined grid has 64 .. 128 cells per side (the reference's own call shapes)
     if (!(p.flags & SIGSVGD_FLAG_FORCE_GENERIC) && dyad_supported(p.A, p.B, p.T, p.d, p.n, p.kind, p.flags))
-        return dyad_launch(p);
+        return band_takes_refined(p) ? band_launch(p) : dyad_launch(p); // (small launches of 65 .. 128 cells: one wavefront per band)
     if (!(p.flags & SIGSVGD_FLAG_FORCE_GENERIC) && band_supported(p.A, p.B, p.T, p.d, p.n, p.kind, p.flags))
         return band_launch(p);
     return generic_launch(p);
@@ -158,8 +158,14 @@ int sigsvgd_gram_workspace_bytes(int A, int B, int T, int d, int dyadic_order, i
         return fast_workspace_bytes(A, B, T, d, want_grad, flags, bytes);
     if (!forced && quad_supported(A, B, T, d, dyadic_order, static_kind, flags))
         return quad_workspace_bytes(A, B, T, d, want_grad, bytes);
-    if (!forced && dyad_supported(A, B, T, d, dyadic_order, static_kind, flags))
-        return dyad_workspace_bytes(A, B, T, d, want_grad, bytes);
+    if (!forced && dyad_supported(A, B, T, d, dyadic_order, static_kind, flags)) {
+        const int rc = dyad_workspace_bytes(A, B, T, d, want_grad, bytes);
+        if (rc == SIGSVGD_OK && ((T - 1) << dyadic_order) > 64 && dyadic_order >= 2) { // either kernel may take the launch
+            const size_t pb = band_refined_workspace_bytes(A, B, T, d, dyadic_order, want_grad);
+            if (pb > *bytes) *bytes = pb;
+        }
+        return rc;
+    }
     if (!forced && band_supported(A, B, T, d, dyadic_order, static_kind, flags))
         return band_workspace_bytes(A, B, T, d, dyadic_order, want_grad, bytes);
     return generic_workspace_bytes(A, B, T, d, dyadic_order, want_grad, forced, bytes);

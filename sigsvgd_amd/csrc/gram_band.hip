@@ -640,7 +640,8 @@ struct BandRev {
 // cell's sum over the rows from l down on the step lane l ends it.  The TOP lanes of all coarse rows end their cells on the
 // same steps, sp = L - 2 mod r -- and L - 2 = 6 mod 8 in every band (P and the band offsets are multiples of 8 <= r), i.e.
 // always on step BFU = 6 of an unrolled group of 8: the group hands that step's sum and cell out, and the caller adds it to
-// the fp64 table BEHIND the group on the groups that end a cell (a uniform test per group; a branch inside the unrolled steps
+// the fp64 table BEHIND the group on the groups that end a cell (r = 4, the coarsest refinement this kernel takes: L = 0 mod 4
+// and the steps are 2 and 6 of every group; a uniform test per group; a branch inside the unrolled steps
 // was measured: it splits the scheduling region and costs 8 %).  Rounds 3-4 / the serial kernel: one ds_add_f64 of every
 // lane on every step, 8 of the step's 27 instructions.  The sum over a coarse row's lanes is fp32 (r <= 64 terms), the table
 // stays fp64.
@@ -649,7 +650,7 @@ constexpr int BKR = 8; // depth of the register ring the forward solution comes 
 template <bool ALLIN, int H>
 __device__ __forceinline__ void bandp_rev_phase(BandRev &st, const float (&hv)[BHS], float (&kfr)[BKR], const float *rnext, int lanep,
                                                 const float *dcrow, float chain, bool top, int n, int r, int P, bool rowvalid,
-                                                float *ho, float &out6, int &cell6)
+                                                float *ho, float &out6, int &cell6, float &out2, int &cell2)
 {
     float gq[BHS];
 #pragma unroll
@@ -668,6 +669,10 @@ __device__ __forceinline__ void bandp_rev_phase(BandRev &st, const float (&hv)[B
         if (u == BFU) { // the one step of a group on which the top lanes can end a cell (see BFU): flushed behind the group
             out6 = st.out;
             cell6 = (top && active) ? st.q >> n : -1;
+        }
+        if (u == BFU - 4) { // (r = 4, grids of 65 .. 128 cells: the second such step of a group)
+            out2 = st.out;
+            cell2 = (top && active) ? st.q >> n : -1;
         }
         st.run = (st.q & (r - 1)) == 0 ? 0.f : st.run; // (a lane outside the grid carries run = 0 anyway)
         const float t = st.cur + down;
@@ -941,16 +946,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
                                 for (int k = 0; k < BHS; ++k)
                                     if (sp0 + h + k > P - 1) hv[k] = 1.f;
                             }
-                            float out6;
-                            int cell6;
+                            float out6, out2;
+                            int cell6, cell2;
                             static_assert(BKR == BHS, "a deeper ring needs the group's position in it as a compile-time constant");
                             if (plat)
-                                bandp_rev_phase<true, 0>(st, hv, kfr, rnext, lanep, dcrow, chain, top, n, r, P, rowvalid, ho - (BHS - 1), out6, cell6);
+                                bandp_rev_phase<true, 0>(st, hv, kfr, rnext, lanep, dcrow, chain, top, n, r, P, rowvalid, ho - (BHS - 1), out6, cell6, out2, cell2);
                             else
-                                bandp_rev_phase<false, 0>(st, hv, kfr, rnext, lanep, dcrow, chain, top, n, r, P, rowvalid, ho - (BHS - 1), out6, cell6);
+                                bandp_rev_phase<false, 0>(st, hv, kfr, rnext, lanep, dcrow, chain, top, n, r, P, rowvalid, ho - (BHS - 1), out6, cell6, out2, cell2);
                             rnext -= BHS * 64;
                             ho += hinc;
                             // (step BFU of the group ends the top lanes' cells iff L - 2 - (sp0 + h + BFU) = 0 mod r)
+                            if (r == 4 && cell2 >= 0) unsafeAtomicAdd(scrow + cell2, (double)out2); // (L = 0 mod 4: steps 2 and 6 of every group)
                             if (((L - 2 - sp0 - h - BFU) & (r - 1)) == 0 && cell6 >= 0) unsafeAtomicAdd(scrow + cell6, (double)out6); // ds_add_f64
                         }
                         SIGB_STAMP(4)
@@ -1306,6 +1312,30 @@ inline bool band_use_parallel(const GramProblem &p, bool sym)
 }
 } // namespace
 
+// Refined grids of 65 .. 128 cells per side (two bands) with r >= 4 -- BASELINE C1, the planning script's shape: the
+// band-parallel kernel takes them from the refined-grid kernel (gram_dyad.hip) while the launch is small (the same rule as
+// above; SIGSVGD_BAND_MODE=serial keeps them on gram_dyad.hip).
+bool band_takes_refined(const GramProblem &p)
+{
+    if (p.n < 2 || p.n > 7 || p.T < 3 || p.T > BTMAX || p.d > 16) return false;
+    const int P = (p.T - 1) << p.n;
+    if (P <= 64 || P > 128) return false;
+    if (p.kind != SIGSVGD_STATIC_RBF || (p.flags & (SIGSVGD_FLAG_NAIVE_SOLVER | SIGSVGD_FLAG_FORCE_GENERIC))) return false;
+    return band_use_parallel(p, (p.flags & SIGSVGD_FLAG_Y_IS_X) && p.A == p.B);
+}
+size_t band_refined_workspace_bytes(int A, int B, int T, int d, int n, int want_grad)
+{
+    size_t bytes = band_flag_bytes(A, B) + 512;
+    if (!want_grad) return bytes;
+    const GradGeom po = bandp_geometry(A, B, T, d, n, false);
+    size_t pneed = po.rseg_bytes;
+    if (A == B) {
+        const GradGeom py = bandp_geometry(A, B, T, d, n, true);
+        if (py.rseg_bytes + py.cslab_bytes > pneed) pneed = py.rseg_bytes + py.cslab_bytes;
+    }
+    return pneed + bandp_wsk_bytes(T, d, n) + band_flag_bytes(A, B) + 1024;
+}
+
 static int bandp_launch(const GramProblem &p)
 {
     const bool grad = p.gradX_out != nullptr;
@@ -1366,7 +1396,7 @@ static int bandp_launch(const GramProblem &p)
 
 int band_launch(const GramProblem &p)
 {
-    if (band_use_parallel(p, (p.flags & SIGSVGD_FLAG_Y_IS_X) && p.A == p.B)) return bandp_launch(p);
+    if (((p.T - 1) << p.n) <= 128 || band_use_parallel(p, (p.flags & SIGSVGD_FLAG_Y_IS_X) && p.A == p.B)) return bandp_launch(p);
     const bool grad = p.gradX_out != nullptr;
     const bool sym = (p.flags & SIGSVGD_FLAG_Y_IS_X) && p.A == p.B;
     BandArgs a;

@@ -167,3 +167,32 @@ def test_band_kernels_agree(gpu, monkeypatch, T, n, d, sym):
     assert np.array_equal(res["serial"][0], res["parallel"][0])
     assert np.array_equal(res["serial"][1], res["parallel"][1])
     assert _rel(res["parallel"][2], res["serial"][2].astype(np.float64)) < 2e-6
+
+
+@pytest.mark.parametrize("T,n,d", [s for s in SHAPES if 64 < (s[0] - 1) << s[1] <= 128 and s[1] >= 2])
+@pytest.mark.parametrize("sym", [True, False])
+def test_refined_shapes_on_both_kernels(gpu, monkeypatch, T, n, d, sym):
+    """65 .. 128 refined cells (two bands): small launches take the band-parallel kernel of gram_band.hip, large ones the
+    refined-grid kernel of gram_dyad.hip; SIGSVGD_BAND_MODE=serial keeps a small launch on gram_dyad.hip.  Both against the
+    oracle, and reproducible."""
+    from sigsvgd_amd import ops
+
+    A, B = 11, 11 if sym else 7
+    X = _paths(A, T, d, 31, 0.2)
+    Y = X if sym else _paths(B, T, d, 32, 0.2)
+    go = np.random.default_rng(4).uniform(0.5, 1.5, (A, B)).astype(np.float32)
+    Kref, gref = C.gram_fwd_bwd(X, Y, 1.0, n, grad_out=go.astype(np.float64))
+    Xg, gog = torch.as_tensor(X, device=gpu), torch.as_tensor(go, device=gpu)
+    Yg = Xg if sym else torch.as_tensor(Y, device=gpu)
+    res = {}
+    for mode in ("serial", "parallel"):
+        monkeypatch.setenv("SIGSVGD_BAND_MODE", mode)
+        K, g = ops.gram_fwd_bwd(Xg, Yg, 1.0, n, grad_out=gog, y_is_x=sym)
+        Kf = ops.gram_fwd(Xg, Yg, 1.0, n, y_is_x=sym)
+        K2, g2 = ops.gram_fwd_bwd(Xg, Yg, 1.0, n, grad_out=gog, y_is_x=sym)
+        torch.cuda.synchronize()
+        assert torch.equal(K, K2) and torch.equal(g, g2)
+        assert _relK(K.cpu().numpy(), Kref) < TOL and _relK(Kf.cpu().numpy(), Kref) < TOL
+        assert _rel(g.cpu().numpy(), gref) < TOL
+        res[mode] = K.cpu().numpy()
+    assert _relK(res["parallel"], res["serial"].astype(np.float64)) < TOL
