@@ -1,21 +1,20 @@
 // Signature-kernel Gram forward/backward for short paths whose REFINED grid has 129 .. 256 cells per side -- the
-// reference's remaining call shapes: examples/script_sequential_distribution.ipynb (10 points, dyadic order 4: 144 cells)
-// and examples/script_control_particle_maze.py:43-44 (30 points, order 3: 232 cells).  Until round 3 they ran on the
-// coverage kernel (gram_generic.hip: fp64 sweeps, 53 instructions per step of which 8 are the stencil).
+// reference's call shapes examples/script_sequential_distribution.ipynb (10 points, dyadic order 4: 144 cells) and
+// examples/script_control_particle_maze.py:43-44 (30 points, order 3: 232 cells) -- and, for small launches, 65 .. 128 cells
+// (BASELINE C1; examples/script_planning_obstacle_field.py:156-158,325).
 //
-// Same frame as gram_dyad.hip -- one wavefront per trajectory pair, eight per workgroup sharing the staged column
-// trajectory, everything around the sweeps on the COARSE grid (static kernel T x T in fp64, increment table
-// D_coarse / (r^2 sqrt(12)) in LDS, block sums of S = K_fwd * U in fp64 LDS, 4-corner scatter and both contractions once
-// per pair in fp32 on the differences x_m - y_n), gradient partial sums through the segment / item slabs of
-// grad_reduce_kernel (no atomics between wavefronts, bit-reproducible) -- but the sweeps run over BANDS of 64 cell rows
-// and all P columns, like the coverage kernel's: a quadrant decomposition of a 144-cell grid spends 60 % of its lane-steps
-// outside the grid and needs the forward solution three times.  Per step: the lane's increment is read from the table
-// (one LDS read, fetched a step ahead), the stencil is the fp32 difference form of gram_fast.hip (V = K[p+1][q] - K[p][q]
-// carried along the row, one full-magnitude add per cell that never feeds back), lane 0 takes the band's upper boundary
-// value through v_readlane and a select from a register refilled every 64 steps, lane 63 hands its row over through a
-// lane-selected LDS address, and the forward solution goes to a per-wavefront scratch in [band][step][lane] order
-// (coalesced 256-B rows, read back by the same wavefront through an eight-deep register ring; measured on the coverage
-// kernel: that round trip is not what limits the step).
+// Same frame as gram_dyad.hip: everything around the sweeps on the COARSE grid (static kernel T x T in fp64, increment table
+// D_coarse / (r^2 sqrt(12)) in LDS, block sums of S = K_fwd * U in fp64 LDS, 4-corner scatter and both contractions once per
+// pair in fp32 on the differences x_m - y_n), gradient partial sums through the segment / item slabs of grad_reduce_kernel (no
+// atomics between wavefronts, bit-reproducible).  The sweeps run over BANDS of 64 cell rows and all P columns, in the fp32
+// difference form of gram_fast.hip (V = K[p+1][q] - K[p][q] carried along the row, one full-magnitude add per cell that never
+// feeds back); a band hands its last row to the next through LDS, and the forward solution goes to a per-pair scratch in
+// [band][step][lane] order (coalesced 256-B rows, read back through an eight-deep register ring).  ONE kernel, two schedules:
+//   * band-parallel (the reference's sizes: few pairs): the bands of a pair on as many wavefronts of one workgroup, pipelined;
+//   * serial (launches with many pairs): a wavefront per pair, its bands one after the other, several pairs per workgroup
+//     around one staged column trajectory.
+// Rounds 3-4 had a separate one-wavefront-per-pair kernel with compiler-scheduled steps (31 + 42 instructions per step against
+// about 20 + 28 here, overhead included); it is gone.
 //
 // Reference semantics: sigkernel _SigKernelGram.forward/backward [RECALLED, SURVEY.md App. A]; static kernel
 // src/kernels/_traj_kernels.py:176-195; callers src/inference/score.py:68-69.
@@ -56,43 +55,9 @@ struct BandArgs {
 #endif
 
 namespace {
-// wavefronts (rows i) per workgroup: 8 (two per SIMD) when there are pairs to fill the chip, 4 (one per SIMD: a wavefront's
-// dependent chain has the SIMD to itself) for launches of at most 4 pairs per CU, as in gram_dyad.hip
 constexpr int BTMAX = 33;  // coarse points per path
 constexpr int BPMAX = 256; // refined cells per side
 constexpr int BPAD = 64;   // boundary rows: entry e lives at [BPAD + e]; lanes outside the grid write into the padding
-// LDS of a workgroup, sized by the launch's shape (round 4: the static layout for 33 points and 256 cells took 141 KB for eight
-// wavefronts whatever the shape -- one workgroup per CU, two wavefronts per SIMD, 40 % VALU utilisation on the notebook shape,
-// whose tables need 5 KB per wavefront).  Byte offsets; every block 16-byte aligned.
-struct BandLds {
-    int yd, yf, yref;                              // shared by the workgroup
-    int Sc, dumpd, Dc, hK, hU, dump, rowacc;       // inside a wavefront's block
-    int wave0, per_wave, total;
-};
-__host__ __device__ inline BandLds band_lds(int T, int P, int dpad, int nw)
-{
-    auto up16 = [](int b) { return (b + 15) & ~15; };
-    const int Tm = T - 1, cells = Tm * Tm, rows = T * dpad;
-    const int hn = 2 * BPAD + 64 * ((P + 62) / 64) + 66; // boundary rows: the refills read 64 entries at a time
-    BandLds L;
-    int o = 0;
-    L.yd = o;   o += up16(T * (dpad + 1) * 8);
-    L.yref = o; o += up16(dpad * 8);
-    L.yf = o;   o += up16(rows * 4);
-    L.wave0 = o;
-    int w = 0;
-    L.Sc = w;     w += up16(cells * 8);
-    L.dumpd = w;  w += 64 * 8;
-    L.Dc = w;     w += up16((cells > rows ? cells : rows) * 4);
-    L.hK = w;     w += up16(hn * 4);
-    L.hU = w;     w += up16(hn * 4);
-    L.dump = w;   w += 64 * 4;
-    L.rowacc = w; w += up16(rows * 4);
-    L.per_wave = w;
-    L.total = o + nw * w;
-    return L;
-}
-
 __device__ __forceinline__ double b_ldany(const void *b, size_t i, int io64)
 {
     return io64 ? static_cast<const double *>(b)[i] : (double)static_cast<const float *>(b)[i];
@@ -104,427 +69,7 @@ __device__ __forceinline__ void b_stany(void *b, size_t i, double v, int io64)
     else
         static_cast<float *>(b)[i] = (float)v;
 }
-// lane l <- lane l-1 (lane 0 keeps its own) / lane l <- lane l+1 (lane 63 keeps its own)
-__device__ __forceinline__ float b_shr(float v)
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x138, 0xF, 0xF, false));
-}
-__device__ __forceinline__ float b_shl(float v)
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x130, 0xF, 0xF, false));
-}
-// The forward neighbour shift of a sweep step: lane 0 of `dst` takes the value lane `src` of `from` holds (v_readlane ->
-// v_writelane), every other lane its upper neighbour's `v` (DPP move; lane 0 has no source and keeps what v_writelane put
-// there).  One asm statement because the hazards between its instructions are not hipcc's to pad: a VALU-written SGPR
-// wants wait states before the next VALU instruction reads it (s_nop), and the three instructions in front of the DPP move
-// are also the wait states between the stencil's write of `v` and the DPP read.
-__device__ __forceinline__ void b_shr_take(float &dst, float v, float from, int src)
-{
-    int sb;
-    asm("v_readlane_b32 %1, %2, %3\n\ts_nop 3\n\tv_writelane_b32 %0, %1, 0\n\t"
-        "v_mov_b32_dpp %0, %4 wave_shr:1 row_mask:0xf bank_mask:0xf"
-        : "+v"(dst), "=&s"(sb)
-        : "v"(from), "s"(src), "v"(v));
-}
-// (the reverse shift's boundary lane is the band's last row, known at run time only: a second scalar operand is one too
-//  many for v_writelane, so that lane takes its value through a select on a mask that does not change over the sweep.
-//  `shifted` is an argument on purpose: written as `here ? sb : b_shl(v)` the DPP move is evaluated where `here` is false
-//  only, i.e. with the boundary lane switched off in EXEC -- and a DPP move does not write a lane whose SOURCE lane is
-//  switched off: the lane next to the boundary kept a stale value and every gradient was wrong by O(1))
-__device__ __forceinline__ float b_shl_take(float shifted, float from, int src, bool here)
-{
-    const float sb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(from), src));
-    return here ? sb : shifted;
-}
 } // namespace
-
-// COMP: the forward sweep's full-magnitude add in two floats (see `clo` below): dyadic order >= 5, where the refined
-// increments are so uniform that its rounding drifts (order 6, 256 cells, smooth paths: 1.2e-5 without, 1e-7 with); at the
-// reference's orders 3 and 4 the plain add stays inside 5e-6 and the six instructions per step (+8 % / +19 % forward-only)
-// are left out.
-template <int DPAD, bool GRAD, bool SYM, bool COMP, int BNW>
-__global__ __launch_bounds__(BNW * 64) __attribute__((amdgpu_waves_per_eu(BNW == 8 ? 2 : 1, 4))) void gram_band_kernel(BandArgs a)
-{
-    constexpr int NT = BNW * 64;
-    extern __shared__ __align__(16) unsigned char band_smem[];
-    struct WaveLds {
-        double *Sc;    // [Tm][Tm] block sums of S = K_fwd * U over the fine cells of every coarse cell
-        float *Dc;     // [Tm][Tm] coarse increments / (r^2 sqrt(12)); after the sweeps: the parked column-side sums [T][DPAD]
-        float *hK, *hU; // K[64 b][.] left by band b - 1 for band b; U[64 b][.] left by band b for band b - 1
-        float *dump;    // [64]
-        double *dumpd;  // [64] where the lanes without a finished run add their zero (reverse sweep)
-        float *rowacc;  // [T][DPAD] row-side gradient of the wavefront's particle over the columns of a segment
-    };
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int T = a.T, d = a.d, n = a.n, io64 = a.io64, Tm = T - 1, r = 1 << n;
-    const int P = Tm << n, nb = (P + 63) >> 6, nsteps = P + 63;
-    const double inv_h = a.inv_h;
-    const float m2h = (float)(-2.0 * inv_h);
-    const double dscale = 1.0 / ((double)r * (double)r * 3.46410161513775459); // 1 / (r^2 sqrt(12))
-    const double inv_r2 = 1.0 / ((double)r * (double)r);
-    const BandLds lay = band_lds(T, P, DPAD, BNW);
-    double *yd = reinterpret_cast<double *>(band_smem + lay.yd);   // y~_n in fp64 (centred on y[0]), [DPAD] = -|y~_n|^2 / h
-    double *yref = reinterpret_cast<double *>(band_smem + lay.yref);
-    float *yf = reinterpret_cast<float *>(band_smem + lay.yf);     // the same in fp32 for the coarse contraction
-    unsigned char *wbase = band_smem + lay.wave0 + wave * lay.per_wave;
-    WaveLds wl;
-    wl.Sc = reinterpret_cast<double *>(wbase + lay.Sc);
-    wl.dumpd = reinterpret_cast<double *>(wbase + lay.dumpd);
-    wl.Dc = reinterpret_cast<float *>(wbase + lay.Dc);
-    wl.hK = reinterpret_cast<float *>(wbase + lay.hK);
-    wl.hU = reinterpret_cast<float *>(wbase + lay.hU);
-    wl.dump = reinterpret_cast<float *>(wbase + lay.dump);
-    wl.rowacc = reinterpret_cast<float *>(wbase + lay.rowacc);
-    float *wsw = GRAD ? a.wsk + ((size_t)blockIdx.x * BNW + wave) * a.wsk_per_wave + 16 * 64 : nullptr; // (16 rows of padding in front)
-
-    // static item ranges: (owned row tile, column), tile-major; symmetric launches only the columns from the tile's first row
-    const long long it0 = a.nitems * blockIdx.x / gridDim.x, it1 = a.nitems * (blockIdx.x + 1) / gridDim.x;
-    int remaining = (int)(it1 - it0);
-    long long item = it0;
-    int kq = 0, cstart = 0;
-    {
-        long long rem = it0;
-        for (;; ++kq) {
-            const int cn = a.B - (SYM ? a.tm.tile_of(kq) * BNW : 0);
-            if (rem < cn) break;
-            rem -= cn;
-        }
-        cstart = (int)rem;
-    }
-#pragma unroll 1
-    while (remaining > 0) {
-    const int itile = a.tm.tile_of(kq);
-    const int cfirst = SYM ? itile * BNW : 0;
-    const int ncolr = min(a.B - cfirst - cstart, remaining);
-    const int i0 = itile * BNW, i = i0 + wave;
-    const int j0 = cfirst + cstart, j1 = j0 + ncolr;
-    const bool row_ok = i < a.A;
-    if (GRAD)
-        for (int e = lane; e < T * DPAD; e += 64) wl.rowacc[e] = 0.f;
-
-#pragma unroll 1
-    for (int j = j0; j < j1; ++j, ++item) {
-        int lanep = lane;
-        asm volatile("" : "+v"(lanep));
-        // ---- stage y_j (coarse points, centred on its first point) ------------------------------------------------
-        __syncthreads();
-        for (int e = tid; e < T * DPAD; e += NT) {
-            const int t = e / DPAD, c = e % DPAD;
-            const double r0 = c < d ? b_ldany(a.Y, (size_t)j * T * d + c, io64) : 0.0;
-            const double v = c < d ? b_ldany(a.Y, ((size_t)j * T + t) * d + c, io64) - r0 : 0.0;
-            yd[t * (DPAD + 1) + c] = v;
-            yf[t * DPAD + c] = (float)v;
-            if (t == 0) yref[c] = r0;
-            double s = v * v;
-#pragma unroll
-            for (int off = 1; off < DPAD; off <<= 1) s += __shfl_xor(s, off, 64);
-            if (c == 0) yd[t * (DPAD + 1) + DPAD] = -s * inv_h;
-        }
-        __syncthreads();
-
-        if (row_ok && (!SYM || j >= i)) {
-            float w_ij = 1.f, w_ji = 1.f;
-            if (GRAD) {
-                if (a.go) {
-                    w_ij = (float)b_ldany(a.go, (size_t)i * a.B + j, io64);
-                    if (SYM || a.symw) w_ji = (float)b_ldany(a.go, (size_t)j * a.B + i, io64);
-                    if (a.symw) { w_ij += w_ji; w_ji = w_ij; }
-                } else if (a.symw) {
-                    w_ij = 2.f; w_ji = 2.f;
-                }
-                if (SYM && j == i) w_ji = 0.f; // diagonal pair: first-slot derivative only
-            }
-            // ---- coarse static kernel: lane m = point row m; G[m][b] in fp64, row differences, 4-corner increments --------
-            float xf[DPAD]; // x~_m in fp32 for the coarse contraction
-            {
-                const int m = min(lanep, T - 1);
-                double xs[DPAD], xn = 0.0;
-#pragma unroll
-                for (int c = 0; c < DPAD; ++c) {
-                    const double xc = c < d ? b_ldany(a.X, ((size_t)i * T + m) * d + c, io64) - yref[c] : 0.0;
-                    xn = __builtin_fma(xc, xc, xn);
-                    xs[c] = xc * (2.0 * inv_h);
-                    xf[c] = (float)xc;
-                }
-                xn = -xn * inv_h;
-                double gprev = 0.0;
-                for (int b = 0; b < T; ++b) {
-                    const double *yr = yd + b * (DPAD + 1);
-                    double e2 = xn + yr[DPAD];
-#pragma unroll
-                    for (int c = 0; c < DPAD; ++c) e2 = __builtin_fma(xs[c], yr[c], e2);
-                    const double g = exp64(e2);
-                    const double rd = g - gprev; // G[m][b] - G[m][b-1]
-                    gprev = g;
-                    const double nbr = shfl_down_f64(rd); // row m + 1
-                    if (b >= 1 && lanep < Tm) wl.Dc[lanep * Tm + (b - 1)] = (float)((nbr - rd) * dscale);
-                }
-                if (GRAD)
-                    for (int e = lanep; e < Tm * Tm; e += 64) wl.Sc[e] = 0.0;
-            }
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-
-            // ---- forward sweep, band by band -------------------------------------------------------------------------
-            double kfin = 1.0;
-            float kmax = 1.f; // largest |K| this lane has seen on the pair's grid
-            float kfin_keep = 0.f;
-            bool canc_keep = false;
-#pragma unroll 1
-            for (int kb = 0; kb < nb; ++kb) {
-                const int p = 64 * kb + lanep;
-                const bool rowvalid = p < P;
-                const float *dcrow = wl.Dc + (min(p, P - 1) >> n) * Tm;
-                float *wb = GRAD ? wsw + (size_t)kb * nsteps * 64 : nullptr; // (uniform: the store takes it as a scalar base)
-                float cur = 1.f, upprev = 1.f, V = 0.f, hbv = 1.f, up = 1.f;
-                // K[p+1][q] = cur + clo: the one full-magnitude add of a step, K11 = K01 + V, is made in two floats.  On a
-                // refined grid the increments of neighbouring cells are nearly identical, so its rounding has the same sign row
-                // after row and K drifts by up to 6e-8 per ROW (1.2e-5 at 256 cells per side with smooth paths, K ~ 1);
-                // the rounding error of each add travels down the rows as the low word (one more DPP move, three adds and a
-                // select per step) and the drift is gone.  It feeds nothing else: the stencil takes the high words.
-                float clo = 0.f;
-                int q1 = 1 - lanep; // column + 1 of the cell in work
-                // lane 63 hands K[64 kb + 64][q + 1] over through entry q + 1 of hK (entries below 1 and beyond P are padding:
-                // a lane outside the grid writes whatever it computed there); the other lanes store into their own dump cell
-                float *ho = (lanep == 63) ? wl.hK + BPAD + q1 : wl.dump + lanep;
-                const int hinc = (lanep == 63) ? 1 : 0;
-                const unsigned qlim = rowvalid ? (unsigned)P : 0u; // (no row: never inside the grid)
-                float g = dcrow[(q1 - 1) >> n]; // (q < 0: a harmless read below the row; the lane is outside the grid)
-#pragma unroll 1
-                for (int s0 = 0; s0 < nsteps; s0 += 64) {
-                    // lane 0's upper neighbour on step s is entry s + 1 of the row band kb - 1 left: 64 entries per refill
-                    hbv = kb ? wl.hK[BPAD + s0 + lanep + 1] : 1.f;
-                    const int send = __builtin_amdgcn_readfirstlane(min(64, nsteps - s0)); // (a scalar loop bound)
-#pragma unroll 1
-                    for (int u = 0; u < send; ++u) {
-                        const bool active = (unsigned)(q1 - 1) < qlim;
-                        const float gnx = dcrow[q1 >> n];
-                        b_shr_take(up, cur, hbv, u);
-                        // K11 - K01 = (K10 - K00) + F,  F = gamma (sqrt(3) t + gamma (t + K00)),  t = K10 + K01
-                        const float t = cur + up;
-                        float y = 1.7320508075688772f * t;
-                        y = __builtin_fmaf(t + upprev, g, y);
-                        const float Vn = __builtin_fmaf(g, y, V);
-                        // (lane 0: the row the band above handed over carries its low word already -- 0 from the shift)
-                        float Vt = Vn, nlo = 0.f;
-                        if constexpr (COMP)
-                            Vt += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(clo), 0x138, 0xF, 0xF, true));
-                        const float nw = up + Vt;
-                        if constexpr (COMP) nlo = Vt - (nw - up); // (exact while |K01| >= |V|; otherwise merely no better than before)
-                        if (GRAD) { // K[p][q]: only the entries of grid cells are read back.  (asm: a scalar row base + the lane's
-                                    //  constant offset instead of a 64-bit vector pointer bumped every step; the reverse sweep waits
-                                    //  for these stores with s_waitcnt vmcnt(0) and a compiler barrier)
-                            const float *rowp = wb + (size_t)(s0 + u) * 64;
-                            asm volatile("global_store_dword %0, %1, %2" ::"v"(lanep * 4), "v"(upprev), "s"(rowp));
-                        }
-                        *ho = COMP ? nw + nlo : nw;
-                        ho += hinc;
-                        cur = active ? nw : cur;
-                        asm("v_max_f32 %0, |%1|, %0" : "+v"(kmax) : "v"(cur)); // (fmaxf costs two canonicalising moves more)
-                        if constexpr (COMP) clo = active ? nlo : clo;
-                        V = active ? Vn : V;
-                        upprev = active ? up : upprev;
-                        g = gnx;
-                        ++q1;
-                    }
-                }
-                if (p == P - 1) kfin = (double)cur + (double)clo;
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_s_waitcnt(0xc07f); // the row is in LDS before the next band reads it
-            }
-            {
-                const float kfv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int((float)kfin), (P - 1) & 63));
-                // (round 4: no floor "grid maximum > 2" any more -- on a refined grid the full-magnitude add drifts by up to 6e-8 per
-                //  row of the largest value, the boundary value 1 included, so a pair that merely decays to K = 0.15 is as exposed as
-                //  one that oscillates (gram_dyad.hip, soak case 504); without the two-float add the ratio is at most 4)
-                const bool cancelled = __builtin_amdgcn_ballot_w64(kfv == kfv && kmax > (d == 1 ? 2.f : (d == 2 || !COMP) ? 4.f : 8.f) * fmaxf(fabsf(kfv), 0.1f)) != 0;
-                if (lanep == ((P - 1) & 63)) {
-                    b_stany(a.K, (size_t)i * a.B + j, kfin, io64);
-                    if (SYM && j != i) b_stany(a.K, (size_t)j * a.B + i, kfin, io64);
-                    if (!GRAD) a.kflag[(size_t)i * a.B + j] = cancelled ? 1 : 0; // (gradient launches: with the condition number, below)
-                }
-                kfin_keep = kfv;
-                canc_keep = cancelled;
-            }
-
-            if (GRAD) {
-                // ---- reverse sweep: U towards smaller rows and columns; S = K_fwd[p][q] * U[p+1][q+1] block-summed ------------
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the forward solution has left the wavefront
-#pragma unroll 1
-                for (int kb = nb - 1; kb >= 0; --kb) {
-                    const int p = 64 * kb + lanep;
-                    const bool rowvalid = p < P;
-                    const int L = min(64, P - 64 * kb);
-                    const int arow = min(p, P - 1) >> n;
-                    const float *dcrow = wl.Dc + arow * Tm;
-                    double *scrow = wl.Sc + arow * Tm;
-                    const bool lastband = kb == nb - 1;
-                    float cur = 1.f, dprev = 1.f, V = 0.f, run = 0.f, hbv = 1.f;
-                    const int nsp = P + L - 1;
-                    int q = P - 1 + (L - 1 - lanep);
-                    // K_fwd[p][q] was stored on forward step lane + q: row R = P + L - 2 - sp of the band's scratch on step sp
-                    const float *wrow = wsw + (size_t)kb * nsteps * 64 + lanep;
-                    int R = P + L - 2;
-                    // (uniform row pointer of the ring's next load; the last groups of steps reach up to 15 rows below the band's
-                    //  first: the 16 rows of padding in front of a wavefront's scratch, or the band below -- read, never used)
-                    const float *rnext = wsw + ((size_t)kb * nsteps + (R - 8)) * 64;
-                    // lane 0 hands U[64 kb][q] over through entry q of hU
-                    float *ho = (lanep == 0) ? wl.hU + BPAD + q : wl.dump + lanep;
-                    const int hinc = (lanep == 0) ? -1 : 0;
-                    float g = dcrow[min(q, P - 1) >> n];
-                    constexpr int KPF = 8;
-                    float kfr[KPF];
-#pragma unroll
-                    for (int u = 0; u < KPF; ++u) kfr[u] = wrow[(size_t)max(R - u, 0) * 64];
-#pragma unroll 1
-                    for (int sp0 = 0; sp0 < nsp; sp0 += KPF) {
-#pragma unroll
-                        for (int u = 0; u < KPF; ++u, --q, --R) {
-                            const int sp = sp0 + u;
-                            // lane L-1's lower neighbour on step sp is entry P - 1 - sp of the row band kb + 1 left
-                            if ((sp & 63) == 0) hbv = lastband ? 1.f : wl.hU[BPAD + max(P - 1 - sp - lanep, -BPAD)];
-                            const bool active = rowvalid && (unsigned)q < (unsigned)P;
-                            const float gnx = dcrow[(q - 1) >> n]; // (q < 1: a harmless read below the row)
-                            const float kf = kfr[u];
-                            kfr[u] = rnext[lanep];
-                            rnext -= 64;
-                            const float down = b_shl_take(b_shl(cur), hbv, sp & 63, lanep == L - 1);
-                            // block sums without a branch: every lane adds every step -- its finished run to the coarse cell
-                            // when it has just taken the cell's leftmost fine column, a zero to its own dump cell otherwise
-                            // (two nested EXEC regions per step cost the unrolled loop more than the LDS add)
-                            run = __builtin_fmaf(active ? kf : 0.f, dprev, run);
-                            const bool fl = active && (q & (r - 1)) == 0;
-                            float addend = fl ? run : 0.f;
-                            asm volatile("" : "+v"(addend)); // (select, then convert: hipcc otherwise converts and selects both halves)
-                            unsafeAtomicAdd(fl ? scrow + (q >> n) : wl.dumpd + lanep, (double)addend); // ds_add_f64
-                            run = fl ? 0.f : run;
-                            const float t = cur + down;
-                            float y = 1.7320508075688772f * t;
-                            y = __builtin_fmaf(t + dprev, g, y);
-                            const float Vn = __builtin_fmaf(g, y, V);
-                            const float nw = down + Vn;
-                            *ho = nw; // (a lane outside the grid writes into the padding, or entries nobody reads)
-                            ho += hinc;
-                            cur = active ? nw : cur;
-                            V = active ? Vn : V;
-                            dprev = active ? down : dprev;
-                            g = gnx;
-                        }
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_s_waitcnt(0xc07f);
-                }
-
-                // the pair's verdict for the exact fp64 pass: the grid maximum (above) or, in <= 3 channels, the condition number of
-                // K in the stored coarse increments, c1 = sqrt(12) sum |Sc * Dc| / max(|K|, 0.1) > 150 (gram_dyad.hip, gram_fast.hip)
-                {
-                    bool ill = false;
-                    if (d <= 3) {
-                        float cs = 0.f;
-                        for (int e = lanep; e < Tm * Tm; e += 64) cs = __builtin_fmaf(fabsf((float)wl.Sc[e]), fabsf(wl.Dc[e]), cs);
-#pragma unroll
-                        for (int off = 1; off < 64; off <<= 1) cs += __shfl_xor(cs, off, 64);
-                        ill = kfin_keep == kfin_keep && cs * 3.46410161513775459f > 150.f * fmaxf(fabsf(kfin_keep), 0.1f);
-                    }
-                    if (lanep == 0) a.kflag[(size_t)i * a.B + j] = (canc_keep || ill) ? 1 : 0;
-                }
-                // ---- coarse gradient: R = 4-corner scatter of S_coarse / r^2, RBF derivative, both contractions ----------
-                const float ns32 = (float)(-inv_h * 1.4426950408889634074);
-                auto Sat = [&](int aa, int bb) -> float {
-                    return (aa >= 0 && aa < Tm && bb >= 0 && bb < Tm) ? (float)(wl.Sc[aa * Tm + bb] * inv_r2) : 0.f;
-                };
-                // row side: lane m sums over the columns n
-                if (lanep < T) {
-                    const int m = lanep;
-                    float acc[DPAD];
-#pragma unroll
-                    for (int c = 0; c < DPAD; ++c) acc[c] = 0.f;
-                    for (int nn = 0; nn < T; ++nn) {
-                        const float Rv = (Sat(m - 1, nn - 1) + Sat(m, nn)) - (Sat(m - 1, nn) + Sat(m, nn - 1));
-                        const float *yr = yf + nn * DPAD;
-                        float df[DPAD], e2 = 0.f;
-#pragma unroll
-                        for (int c = 0; c < DPAD; ++c) {
-                            df[c] = xf[c] - yr[c];
-                            e2 = __builtin_fmaf(df[c], df[c], e2);
-                        }
-                        const float rg = Rv * __builtin_amdgcn_exp2f(e2 * ns32);
-#pragma unroll
-                        for (int c = 0; c < DPAD; ++c) acc[c] = __builtin_fmaf(rg, df[c], acc[c]);
-                    }
-#pragma unroll
-                    for (int c = 0; c < DPAD; ++c)
-                        if (c < d) wl.rowacc[m * DPAD + c] += w_ij * m2h * acc[c];
-                }
-                // column side (Y is X): lane n sums over the rows m; x~_m comes from the lanes through LDS (the parked area)
-                if (SYM) {
-                    float *xl = wl.Dc; // (the increments are not needed any more) x~ rows [T][DPAD], then the parked sums
-                    if (lanep < T) {
-#pragma unroll
-                        for (int c = 0; c < DPAD; ++c) xl[lanep * DPAD + c] = xf[c];
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_s_waitcnt(0xc07f);
-                    float acc[DPAD];
-#pragma unroll
-                    for (int c = 0; c < DPAD; ++c) acc[c] = 0.f;
-                    const int nn = min(lanep, T - 1);
-                    const float *yr = yf + nn * DPAD;
-                    for (int m = 0; m < T; ++m) {
-                        const float Rv = (Sat(m - 1, nn - 1) + Sat(m, nn)) - (Sat(m - 1, nn) + Sat(m, nn - 1));
-                        const float *xr = xl + m * DPAD;
-                        float df[DPAD], e2 = 0.f;
-#pragma unroll
-                        for (int c = 0; c < DPAD; ++c) {
-                            df[c] = xr[c] - yr[c];
-                            e2 = __builtin_fmaf(df[c], df[c], e2);
-                        }
-                        const float rg = Rv * __builtin_amdgcn_exp2f(e2 * ns32);
-#pragma unroll
-                        for (int c = 0; c < DPAD; ++c) acc[c] = __builtin_fmaf(rg, df[c], acc[c]);
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_s_waitcnt(0xc07f);
-                    if (lanep < T) { // d k(x_j, x_i) / d y_n = -(2/h) sum_m R G (y~_n - x~_m)
-#pragma unroll
-                        for (int c = 0; c < DPAD; ++c) xl[lanep * DPAD + c] = -(w_ji * m2h) * acc[c];
-                    }
-                }
-            }
-        } else if (GRAD && SYM) {
-            for (int e = lane; e < T * DPAD; e += 64) wl.Dc[e] = 0.f; // idle wavefront: nothing to add to the column
-        }
-
-        if (GRAD && SYM) {
-            __syncthreads(); // every wavefront has parked its column-side sums
-            float *dstc = a.cslab + (size_t)item * (T * d);
-            for (int e = tid; e < T * d; e += NT) {
-                const int nn = e / d, c = e - nn * d;
-                float s = 0.f;
-#pragma unroll
-                for (int w = 0; w < BNW; ++w)
-                    s += reinterpret_cast<const float *>(band_smem + lay.wave0 + w * lay.per_wave + lay.Dc)[nn * DPAD + c];
-                dstc[e] = s;
-            }
-        }
-    }
-    if (GRAD && row_ok) { // the segment's row-side sums
-        const int tot = T * d;
-        double *dstr = a.rseg + (((size_t)(kq + (int)blockIdx.x)) * BNW + wave) * (size_t)tot;
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        for (int e = lane; e < tot; e += 64) {
-            const int m = e / d, c = e - m * d;
-            dstr[e] = (double)wl.rowacc[m * DPAD + c];
-        }
-    }
-    remaining -= ncolr;
-    ++kq;
-    cstart = 0;
-    } // row tiles of the range
-}
 
 namespace {
 // ---- band-parallel kernel: one wavefront per BAND of a pair ----------------------------------------------------------
@@ -554,10 +99,13 @@ struct BandPLds {
     int hn;                                  // floats per boundary row
     int pair0, per_pair, total;
 };
-__host__ __device__ inline BandPLds bandp_lds(int T, int P, int dpad)
+// (serial_slots: 0 = band-parallel, one pair per workgroup with nb - 1 boundary rows each way; n > 0 = serial, n pairs per
+//  workgroup with ONE boundary row each way, reused in place)
+__host__ __device__ inline BandPLds bandp_lds(int T, int P, int dpad, int serial_slots)
 {
     auto up16 = [](int b) { return (b + 15) & ~15; };
     const int Tm = T - 1, cells = Tm * Tm, rows = T * dpad, nb = (P + 63) >> 6;
+    const int hrows = serial_slots ? 1 : (nb > 1 ? nb - 1 : 1), ndump = serial_slots ? 1 : nb;
     BandPLds L;
     L.hn = 2 * BPAD + 64 * ((P + 62) / 64) + 80;
     int o = 0;
@@ -570,21 +118,20 @@ __host__ __device__ inline BandPLds bandp_lds(int T, int P, int dpad)
     L.misc = w;   w += 64;
     const int dtab = (Tm + 1) * (Tm + 2 * band_zpad(P / Tm)); // padded increment table (see band_zpad)
     L.Dc = w;     w += up16((dtab > rows ? dtab : rows) * 4);
-    L.hK = w;     w += up16((nb - 1) * L.hn * 4);
-    L.hU = w;     w += up16((nb - 1) * L.hn * 4);
+    L.hK = w;     w += up16(hrows * L.hn * 4);
+    L.hU = w;     w += up16(hrows * L.hn * 4);
     if (w - L.hK < up16((T * T + rows) * 4)) w = L.hK + up16((T * T + rows) * 4); // (the contraction's tables reuse the two blocks)
     L.rowacc = w; w += up16(rows * 4);
-    L.dump = w;   w += nb * (96 * 4 + 64 * 8);
+    L.dump = w;   w += ndump * (96 * 4);
     L.per_pair = w;
-    L.total = o + BPP * w;
+    L.total = o + (serial_slots ? serial_slots : BPP) * w;
     return L;
 }
 
-// One phase (BGS steps) of a band's forward sweep, unrolled: the boundary row's entries of the phase arrive in `hv` (one
+// One group (BHS steps) of a band's forward sweep, unrolled: the boundary row's entries of the group arrive in `hv` (one
 // uniform 16-byte read per four steps) and reach lane 0 as the `old` operand of the DPP shift -- a lane without a source
 // keeps it -- so the shift is one instruction; the store of the forward solution and the hand-over write take the step
-// number as an immediate offset.  PLAT: every lane is inside the grid on every step of the phase (steps 64 .. P - 1 of a band
-// of 64 valid rows): no activity test and none of the three selects.
+// number as an immediate offset.
 struct BandFwd {
     float cur, upprev, V, clo, kmax;
     int q1;
@@ -688,20 +235,26 @@ __device__ __forceinline__ void bandp_rev_phase(BandRev &st, const float (&hv)[B
     }
 }
 
-template <int DPAD, bool GRAD, bool SYM, bool COMP>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(1, 4))) void gram_bandp_kernel(BandArgs a)
+// SER: the launches with many pairs -- every wavefront of the workgroup owns a pair of its own (rows i .. i + nslots - 1 against
+// the staged column) and walks its bands one after the other: the same groups of steps, no lag, no barrier inside a sweep,
+// one boundary row reused in place (a band's writes trail its reads by 55 entries forwards, lead them by 7 or more backwards).
+template <int DPAD, bool GRAD, bool SYM, bool COMP, bool SER>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(GRAD && SER ? 4 : 1, 4))) void gram_bandp_kernel(BandArgs a)
 {
     extern __shared__ __align__(16) unsigned char band_smem[];
     const int tid = threadIdx.x, lane = tid & 63, NT = blockDim.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int T = a.T, d = a.d, n = a.n, io64 = a.io64, Tm = T - 1, r = 1 << n;
     const int P = Tm << n, nb = (P + 63) >> 6, nsteps = P + 63;
-    const int slot = __builtin_amdgcn_readfirstlane(wave / nb), band = wave - slot * nb; // pair of the workgroup, band of the pair
+    const int nslots = SER ? (int)(blockDim.x >> 6) : BPP;                              // pairs per workgroup
+    const int slot = SER ? wave : __builtin_amdgcn_readfirstlane(wave / nb);           // pair of the workgroup
+    const int band0 = SER ? 0 : wave - slot * nb;                                      // band of the pair (SER: all of them in turn)
+    const bool lead = SER || band0 == 0;                                               // the wavefront with the pair's scalar work
     const double inv_h = a.inv_h;
     const float m2h = (float)(-2.0 * inv_h);
     const double dscale = 1.0 / ((double)r * (double)r * 3.46410161513775459); // 1 / (r^2 sqrt(12))
     const double inv_r2 = 1.0 / ((double)r * (double)r);
-    const BandPLds lay = bandp_lds(T, P, DPAD);
+    const BandPLds lay = bandp_lds(T, P, DPAD, SER ? nslots : 0);
     const int BZP = band_zpad(r), DS = Tm + 2 * BZP; // zeros on either side of a row of the increment table, floats per row
     double *yd = reinterpret_cast<double *>(band_smem + lay.yd);
     double *yref = reinterpret_cast<double *>(band_smem + lay.yref);
@@ -714,9 +267,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
     float *rowacc = reinterpret_cast<float *>(pbase + lay.rowacc);
     float *misc = reinterpret_cast<float *>(pbase + lay.misc);        // [0..1]: K[P][P] (double), [4 + b]: grid maximum of band b
     float *ones = misc + 8;                                           // [8]: the boundary of the first / last band
-    float *dump = reinterpret_cast<float *>(pbase + lay.dump + band * (96 * 4 + 64 * 8)); // [96]: a phase writes 16 entries from the lane's cell
-    double *dumpd = reinterpret_cast<double *>(pbase + lay.dump + band * (96 * 4 + 64 * 8) + 96 * 4);
-    float *wsw = GRAD ? a.wsk + ((size_t)blockIdx.x * BPP + slot) * a.wsk_per_wave + 32 * 64 : nullptr; // the pair's forward solution (32 rows of padding in front)
+    float *dump = reinterpret_cast<float *>(pbase + lay.dump + band0 * (96 * 4)); // [96]: a group writes 8 entries from the lane's cell
+    float *wsw = GRAD ? a.wsk + ((size_t)blockIdx.x * nslots + slot) * a.wsk_per_wave + 32 * 64 : nullptr; // the pair's forward solution (32 rows of padding in front)
     const int ngf = (nsteps + BGS - 1) / BGS;               // forward phases of one band
     const int nsr = ngf * BGS;                              // rows of a band's forward-solution scratch (whole phases)
     const int ngr = (P + 63 + BGS - 1) / BGS;               // reverse phases of a full band (P + L - 1 <= P + 63 steps)
@@ -725,7 +277,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
 #ifdef SIGSVGD_PHASE_STAMPS
     unsigned long long ph_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast_ = __builtin_amdgcn_s_memtime();
 #endif
-    if (band == 0 && lane < 8) ones[lane] = 1.f; // (read after the first pair's staging barriers)
+    if (lead && lane < 8) ones[lane] = 1.f; // (read after the first pair's staging barriers)
     const long long it0 = a.nitems * blockIdx.x / gridDim.x, it1 = a.nitems * (blockIdx.x + 1) / gridDim.x;
     int remaining = (int)(it1 - it0);
     long long item = it0;
@@ -733,7 +285,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
     {
         long long rem = it0;
         for (;; ++kq) {
-            const int cn = a.B - (SYM ? a.tm.tile_of(kq) * BPP : 0);
+            const int cn = a.B - (SYM ? a.tm.tile_of(kq) * nslots : 0);
             if (rem < cn) break;
             rem -= cn;
         }
@@ -742,12 +294,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
 #pragma unroll 1
     while (remaining > 0) {
     const int itile = a.tm.tile_of(kq);
-    const int cfirst = SYM ? itile * BPP : 0;
+    const int cfirst = SYM ? itile * nslots : 0;
     const int ncolr = min(a.B - cfirst - cstart, remaining);
-    const int i0 = itile * BPP, i = i0 + slot;
+    const int i0 = itile * nslots, i = i0 + slot;
     const int j0 = cfirst + cstart, j1 = j0 + ncolr;
-    const bool row_ok = slot < BPP && i < a.A;
-    if (GRAD && band == 0 && slot < BPP)
+    const bool row_ok = i < a.A;
+    if (GRAD && lead)
         for (int e = lane; e < T * DPAD; e += 64) rowacc[e] = 0.f;
 
 #pragma unroll 1
@@ -772,7 +324,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
 
         SIGB_STAMP(0)
         const bool valid = row_ok && (!SYM || j >= i); // (uniform per wavefront)
-        if (valid && band == 0) {
+        if (valid && lead) {
             for (int e = lanep; e < (Tm + 1) * DS; e += 64) Dc[e] = 0.f; // the zeros around the rows (the table is reused per pair)
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -807,24 +359,25 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
 
         // ---- forward sweep: this wavefront's band, BGS steps per phase ---------------------------------------------
         float kmax = 1.f; // largest |K| this lane has seen on the pair's grid
-        {
+        int band = band0;
+        do { // (SER: the bands in turn; otherwise this wavefront's band, once -- a compile-time fact, not a loop)
             const int p = 64 * band + lanep;
             const bool rowvalid = p < P;
             const float *dcrow = Dc + (rowvalid ? (p >> n) : Tm) * DS + BZP; // (a row outside the grid: the row of zeros)
             const float *wb = GRAD ? wsw + (size_t)band * nsr * 64 : nullptr;
             BandFwd st;
-            st.cur = 1.f; st.upprev = 1.f; st.V = 0.f; st.clo = 0.f; st.kmax = 1.f;
+            st.cur = 1.f; st.upprev = 1.f; st.V = 0.f; st.clo = 0.f; st.kmax = kmax;
             st.q1 = 1 - lanep; // column + 1 of the cell in work
             // lane 63 hands K[64 band + 64][q + 1] over through entry q + 1 of row `band` (entry e at [BPAD - 1 + e]: the 16
             // entries a phase of the next band reads start on a 16-byte boundary); the other lanes write into the dump block
             const bool hands = lanep == 63 && band < nb - 1;
-            float *ho = hands ? hKall + band * lay.hn + (BPAD - 1) + st.q1 : dump + lanep;
+            float *ho = hands ? hKall + (SER ? 0 : band) * lay.hn + (BPAD - 1) + st.q1 : dump + lanep;
             const int hinc = hands ? BHS : 0; // (per group of steps)
-            const float *hin = hKall + (band - 1) * lay.hn + BPAD; // (band 0: not read)
+            const float *hin = hKall + (SER ? 0 : band - 1) * lay.hn + BPAD; // (band 0: not read)
             const unsigned qlim = rowvalid ? (unsigned)P : 0u;
 #pragma unroll 1
-            for (int ph = 0; ph < Mf; ++ph) {
-                const int gi = ph - BLAG * band;
+            for (int ph = 0; ph < (SER ? ngf : Mf); ++ph) {
+                const int gi = SER ? ph : ph - BLAG * band;
                 if (valid && gi >= 0 && gi < ngf) {
                     const int s0 = gi * BGS;
                     // lane 0's upper neighbour on step s is entry s + 1 of the row band - 1 leaves: written on ITS step s + 63,
@@ -855,25 +408,25 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
                     }
                     SIGB_STAMP(2)
                 }
-                __syncthreads();
+                if (!SER) __syncthreads();
                 SIGB_STAMP(3)
             }
             kmax = st.kmax;
-            if (valid) {
+            if (valid && band == nb - 1 && p == P - 1) *reinterpret_cast<double *>(misc) = (double)st.cur + (double)st.clo;
+        } while (SER && ++band < nb);
+        if (valid) {
 #pragma unroll
-                for (int off = 1; off < 64; off <<= 1) kmax = fmaxf(kmax, __shfl_xor(kmax, off, 64));
-                if (lanep == 0) misc[4 + band] = kmax;
-                if (band == nb - 1 && p == P - 1) *reinterpret_cast<double *>(misc) = (double)st.cur + (double)st.clo;
-            }
+            for (int off = 1; off < 64; off <<= 1) kmax = fmaxf(kmax, __shfl_xor(kmax, off, 64));
+            if (lanep == 0) misc[4 + band0] = kmax;
         }
         __syncthreads();
         double kfin = 1.0;
         float kfin_keep = 0.f;
         bool canc_keep = false;
-        if (valid && band == 0) {
+        if (valid && lead) {
             kfin = *reinterpret_cast<const double *>(misc);
             float km = misc[4];
-            for (int b = 1; b < nb; ++b) km = fmaxf(km, misc[4 + b]);
+            for (int b = 1; b < (SER ? 1 : nb); ++b) km = fmaxf(km, misc[4 + b]);
             const float kfv = (float)kfin;
             const bool cancelled = kfv == kfv && km > (d == 1 ? 2.f : (d == 2 || !COMP) ? 4.f : 8.f) * fmaxf(fabsf(kfv), 0.1f);
             if (lanep == 0) {
@@ -888,7 +441,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
         if (GRAD) {
             // ---- reverse sweep: the last band leads ---------------------------------------------------------------------
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this band's forward solution has left the wavefront
-            {
+            band = SER ? nb - 1 : band0;
+            do {
                 const int p = 64 * band + lanep;
                 const bool rowvalid = p < P;
                 const int L = min(64, P - 64 * band);
@@ -908,9 +462,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
                 const float *rnext = wsw + ((size_t)band * nsr + (R - BKR)) * 64; // (uniform row pointer of the ring's next load)
                 // lane 0 hands U[64 band][q] over through entry q of row band - 1 (entry e at [BUO + e])
                 const bool hands = lanep == 0 && band > 0;
-                float *ho = hands ? hUall + (band - 1) * lay.hn + BUO + st.q : dump + 16 + lanep;
+                float *ho = hands ? hUall + (SER ? 0 : band - 1) * lay.hn + BUO + st.q : dump + 16 + lanep;
                 const int hinc = hands ? -BHS : 0; // (per group of steps)
-                const float *hin = hUall + band * lay.hn + BUO + (P - BGS); // (last band: not read)
+                const float *hin = hUall + (SER ? 0 : band) * lay.hn + BUO + (P - BGS); // (last band: not read)
                 float kfr[BKR];
                 if (valid) {
 #pragma unroll
@@ -922,8 +476,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
                 const int ngb = (P + L - 1 + BGS - 1) / BGS; // this band's phases
                 const int rb = nb - 1 - band;
 #pragma unroll 1
-                for (int ph = 0; ph < Mr; ++ph) {
-                    const int gi = ph - BLAG * rb;
+                for (int ph = 0; ph < (SER ? ngb : Mr); ++ph) {
+                    const int gi = SER ? ph : ph - BLAG * rb;
                     if (valid && gi >= 0 && gi < ngb) {
                         const int sp0 = gi * BGS;
                         // lane 63's lower neighbour on step sp is entry P - 1 - sp of the row band + 1 leaves (its lane 0 on
@@ -961,14 +515,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
                         }
                         SIGB_STAMP(4)
                     }
-                    __syncthreads();
+                    if (!SER) __syncthreads();
                     SIGB_STAMP(5)
                 }
                 // (the ring's last loads are never used: consumed here, or hipcc carries them as pending into the next pair's
                 //  forward step loop and waits for vmcnt(0) in every step -- behind the step's own store, a memory round trip)
 #pragma unroll
                 for (int u = 0; u < BKR; ++u) asm volatile("" ::"v"(kfr[u]));
-            }
+            } while (SER && --band >= 0);
 
             // ---- after the sweeps: the coarse contraction, spread over the pair's wavefronts -------------------------------
             // R = 4-corner scatter of S_coarse / r^2 as an fp32 table and x~ in fp32, staged by all of them in the boundary
@@ -979,7 +533,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
                 auto Sat = [&](int aa, int bb) -> float {
                     return (aa >= 0 && aa < Tm && bb >= 0 && bb < Tm) ? (float)(Sc[aa * Tm + bb] * inv_r2) : 0.f;
                 };
-                const int wtid = band * 64 + lanep, wnt = nb * 64;
+                const int wtid = band0 * 64 + lanep, wnt = SER ? 64 : nb * 64;
                 for (int e = wtid; e < T * T; e += wnt) {
                     const int m = e / T, nn = e - m * T;
                     Rt[e] = (Sat(m - 1, nn - 1) + Sat(m, nn)) - (Sat(m - 1, nn) + Sat(m, nn - 1));
@@ -989,8 +543,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
                     xl[e] = c < d ? (float)(b_ldany(a.X, ((size_t)i * T + m) * d + c, io64) - yref[c]) : 0.f;
                 }
             }
-            if (valid && band == 0) {
-                // the pair's verdict for the exact fp64 pass (see the serial kernel)
+            if (valid && lead) {
+                // the pair's verdict for the exact fp64 pass
                 bool ill = false;
                 if (d <= 3) {
                     float cs = 0.f;
@@ -1005,7 +559,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
                 if (lanep == 0) a.kflag[(size_t)i * a.B + j] = (canc_keep || ill) ? 1 : 0;
             }
             __syncthreads(); // the tables are staged; the increments (verdict) are not needed any more
-            if (valid && band <= (SYM ? 1 : 0)) {
+            if (valid && (SER || band0 <= (SYM ? 1 : 0))) {
                 float w_ij = 1.f, w_ji = 1.f;
                 if (a.go) {
                     w_ij = (float)b_ldany(a.go, (size_t)i * a.B + j, io64);
@@ -1020,7 +574,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
                 float acc[DPAD];
 #pragma unroll
                 for (int c = 0; c < DPAD; ++c) acc[c] = 0.f;
-                if (band == 0) { // row side: lane m sums over the columns n
+                if (lead) { // row side: lane m sums over the columns n
                     float xf[DPAD];
 #pragma unroll
                     for (int c = 0; c < DPAD; ++c) xf[c] = xl[me * DPAD + c];
@@ -1042,7 +596,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
                         for (int c = 0; c < DPAD; ++c)
                             if (c < d) rowacc[me * DPAD + c] += w_ij * m2h * acc[c];
                     }
-                } else { // column side (Y is X): lane n sums over the rows m; the sums are parked in the increment table's place
+                }
+                if (SYM && (SER || band0 == 1)) { // column side (Y is X): lane n sums over the rows m; the sums are parked in the increment table's place
+#pragma unroll
+                    for (int c = 0; c < DPAD; ++c) acc[c] = 0.f;
                     const float *yr = yf + me * DPAD;
                     for (int m = 0; m < T; ++m) {
                         const float Rv = Rt[m * T + me];
@@ -1062,7 +619,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
                         for (int c = 0; c < DPAD; ++c) Dc[lanep * DPAD + c] = -(w_ji * m2h) * acc[c];
                     }
                 }
-            } else if (SYM && !valid && band == 0) {
+            } else if (SYM && !valid && lead) {
                 for (int e = lane; e < T * DPAD; e += 64) Dc[e] = 0.f; // no pair in this slot: nothing to add to the column
             }
         }
@@ -1075,15 +632,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
                 const int nn = e / d, c = e - nn * d;
                 float s = 0.f;
 #pragma unroll
-                for (int w = 0; w < BPP; ++w)
+                for (int w = 0; w < nslots; ++w)
                     s += reinterpret_cast<const float *>(band_smem + lay.pair0 + w * lay.per_pair + lay.Dc)[nn * DPAD + c];
                 dstc[e] = s;
             }
         }
     }
-    if (GRAD && row_ok && band == 0) { // the segment's row-side sums
+    if (GRAD && row_ok && lead) { // the segment's row-side sums
         const int tot = T * d;
-        double *dstr = a.rseg + (((size_t)(kq + (int)blockIdx.x)) * BPP + slot) * (size_t)tot;
+        double *dstr = a.rseg + (((size_t)(kq + (int)blockIdx.x)) * nslots + slot) * (size_t)tot;
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_s_waitcnt(0xc07f);
         for (int e = lane; e < tot; e += 64) {
@@ -1116,124 +673,98 @@ bool band_supported(int A, int B, int T, int d, int n, int kind, unsigned flags)
 }
 
 namespace {
-inline int band_nw(int A, int B, bool sym)
-{
-    const long long pairs = sym ? (long long)A * (A + 1) / 2 : (long long)A * B;
-    return pairs <= 4ll * device_cu_count() ? 4 : 8;
-}
-// workgroups a CU holds: by LDS (160 KB a CU) and by wavefronts (four per SIMD: the kernel's register budget)
-inline int band_wg_per_cu(int T, int d, int n, int nw)
-{
-    const BandLds L = band_lds(T, (T - 1) << n, d <= 8 ? 8 : 16, nw);
-    const int by_lds = (160 * 1024) / (L.total + 1024);
-    const int by_waves = (d <= 8 ? 16 : 12) / nw; // (16-channel gradient instantiations: 157 registers, three wavefronts per SIMD)
-    const int k = by_lds < by_waves ? by_lds : by_waves;
-    return k < 1 ? 1 : k;
-}
-inline GradGeom band_geometry(int A, int B, int T, int d, int n, bool sym, int nw)
-{
-    return grad_geometry(A, B, T * d, sym, 0, 1, false, nw, (long long)device_cu_count() * band_wg_per_cu(T, d, n, nw));
-}
-inline size_t band_wsk_per_wave(int T, int n)
-{
-    const int P = (T - 1) << n;
-    return (size_t)((P + 63) >> 6) * (size_t)(P + 63) * 64 + 16 * 64; // floats (+ 16 rows in front: the ring's loads need no clamp)
-}
-// forward-solution scratch: one block per resident wavefront of the launch
-inline size_t band_wsk_bytes(int T, int d, int n, int nw)
-{
-    return (((size_t)device_cu_count() * band_wg_per_cu(T, d, n, nw) * nw * band_wsk_per_wave(T, n) * sizeof(float)) + 255) & ~(size_t)255;
-}
-} // namespace
-
-namespace {
 inline size_t band_flag_bytes(int A, int B) { return (((size_t)A * B + 255) & ~(size_t)255) + generic_repair_bytes(); }
-} // namespace
 
-namespace {
-inline int bandp_wg_per_cu(int T, int d, int n, bool grad = true)
+// pairs per workgroup of the serial schedule: eight (two wavefronts per SIMD) where LDS holds them
+inline int band_serial_slots(int T, int d, int n)
 {
-    const int P = (T - 1) << n, nb = (P + 63) >> 6;
-    const BandPLds L = bandp_lds(T, P, d <= 8 ? 8 : 16);
+    const int P = (T - 1) << n, dpad = d <= 8 ? 8 : 16;
+    const BandPLds one = bandp_lds(T, P, dpad, 1);
+    const int fit = (158 * 1024 - one.pair0) / one.per_pair;
+    return fit >= 8 ? 8 : (fit < 1 ? 1 : fit);
+}
+// workgroups a CU holds: by LDS (160 KB a CU) and by wavefronts (every instantiation fits four per SIMD: <= 128 registers)
+inline int band_wg_per_cu(int T, int d, int n, bool serial)
+{
+    const int P = (T - 1) << n, nb = (P + 63) >> 6, dpad = d <= 8 ? 8 : 16;
+    const int slots = serial ? band_serial_slots(T, d, n) : 0;
+    const BandPLds L = bandp_lds(T, P, dpad, slots);
     const int by_lds = (160 * 1024) / (L.total + 1024);
-    const int by_waves = 16 / (BPP * nb); // (every instantiation fits four wavefronts per SIMD: <= 128 registers)
+    const int by_waves = 16 / (serial ? slots : BPP * nb);
     const int k = by_lds < by_waves ? by_lds : by_waves;
     return k < 1 ? 1 : k;
 }
-inline GradGeom bandp_geometry(int A, int B, int T, int d, int n, bool sym, bool grad = true)
+inline GradGeom band_geometry(int A, int B, int T, int d, int n, bool sym, bool serial)
 {
-    return grad_geometry(A, B, T * d, sym, 0, 1, false, BPP, (long long)device_cu_count() * bandp_wg_per_cu(T, d, n, grad));
+    return grad_geometry(A, B, T * d, sym, 0, 1, false, serial ? band_serial_slots(T, d, n) : BPP,
+                         (long long)device_cu_count() * band_wg_per_cu(T, d, n, serial));
 }
-inline size_t bandp_wsk_per_pair(int T, int n)
+inline size_t band_wsk_per_pair(int T, int n)
 {
     const int P = (T - 1) << n;
     const size_t rows = (size_t)((P + 63 + BGS - 1) / BGS) * BGS; // whole phases per band
     return (size_t)((P + 63) >> 6) * rows * 64 + 32 * 64; // floats (+ 32 rows in front: the ring's loads need no clamp)
 }
-inline size_t bandp_wsk_bytes(int T, int d, int n)
+// forward-solution scratch: one block per resident pair of the launch
+inline size_t band_wsk_bytes(int T, int d, int n, bool serial)
 {
-    return (((size_t)device_cu_count() * bandp_wg_per_cu(T, d, n) * BPP * bandp_wsk_per_pair(T, n) * sizeof(float)) + 255) & ~(size_t)255;
+    const size_t pairs = (size_t)device_cu_count() * band_wg_per_cu(T, d, n, serial) * (serial ? band_serial_slots(T, d, n) : BPP);
+    return ((pairs * band_wsk_per_pair(T, n) * sizeof(float)) + 255) & ~(size_t)255;
+}
+inline size_t band_need_bytes(int A, int B, int T, int d, int n, int want_grad, bool serial)
+{
+    size_t bytes = band_flag_bytes(A, B) + 512;
+    if (!want_grad) return bytes;
+    const GradGeom o = band_geometry(A, B, T, d, n, false, serial);
+    size_t need = o.rseg_bytes;
+    if (A == B) {
+        const GradGeom y = band_geometry(A, B, T, d, n, true, serial);
+        if (y.rseg_bytes + y.cslab_bytes > need) need = y.rseg_bytes + y.cslab_bytes;
+    }
+    return need + band_wsk_bytes(T, d, n, serial) + band_flag_bytes(A, B) + 1024;
 }
 } // namespace
 
 int band_workspace_bytes(int A, int B, int T, int d, int n, int want_grad, size_t *bytes)
 {
-    *bytes = band_flag_bytes(A, B) + 512;
-    if (!want_grad) return SIGSVGD_OK;
-    const int nwo = band_nw(A, B, false);
-    const GradGeom o = band_geometry(A, B, T, d, n, false, nwo);
-    size_t need = o.rseg_bytes, wsk = band_wsk_bytes(T, d, n, nwo);
-    if (A == B) {
-        const int nwy = band_nw(A, B, true);
-        const GradGeom y = band_geometry(A, B, T, d, n, true, nwy);
-        if (y.rseg_bytes + y.cslab_bytes > need) need = y.rseg_bytes + y.cslab_bytes;
-        if (band_wsk_bytes(T, d, n, nwy) > wsk) wsk = band_wsk_bytes(T, d, n, nwy);
-    }
-    *bytes = need + wsk + band_flag_bytes(A, B) + 1024;
-    { // the band-parallel launch
-        const GradGeom po = bandp_geometry(A, B, T, d, n, false);
-        size_t pneed = po.rseg_bytes;
-        if (A == B) {
-            const GradGeom py = bandp_geometry(A, B, T, d, n, true);
-            if (py.rseg_bytes + py.cslab_bytes > pneed) pneed = py.rseg_bytes + py.cslab_bytes;
-        }
-        const size_t pb = pneed + bandp_wsk_bytes(T, d, n) + band_flag_bytes(A, B) + 1024;
-        if (pb > *bytes) *bytes = pb;
-    }
+    const size_t sb = band_need_bytes(A, B, T, d, n, want_grad, true), pb = band_need_bytes(A, B, T, d, n, want_grad, false);
+    *bytes = sb > pb ? sb : pb; // (either schedule may take the launch)
     return SIGSVGD_OK;
 }
 
 namespace {
 // (the dynamic-LDS limit of an instantiation, raised once per device: see gram_generic.hip)
-template <int DPAD, bool GRAD, bool SYM, bool COMP, int BNW>
+template <int DPAD, bool GRAD, bool SYM, bool COMP, bool SER>
 hipError_t band_raise_lds()
 {
     static std::atomic<unsigned long long> raised{0};
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64 || !((raised.load(std::memory_order_acquire) >> dev) & 1ull)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gram_band_kernel<DPAD, GRAD, SYM, COMP, BNW>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gram_bandp_kernel<DPAD, GRAD, SYM, COMP, SER>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         if (dev >= 0 && dev < 64) raised.fetch_or(1ull << dev, std::memory_order_release);
     }
     return hipSuccess;
 }
-template <int DPAD, int BNW>
+template <int DPAD, bool SER>
 int band_launch_variant(const GramProblem &p, BandArgs &a, const GradGeom &g, bool grad, bool sym)
 {
     if (g.tm.owned <= 0 || g.nitems <= 0) return SIGSVGD_OK;
     a.tm = g.tm;
     a.nitems = g.nitems;
-    dim3 grid((unsigned)g.grid), block(BNW * 64);
+    const int P = (p.T - 1) << p.n, nb = (P + 63) >> 6;
+    const int slots = SER ? band_serial_slots(p.T, p.d, p.n) : 0;
+    dim3 grid((unsigned)g.grid), block((SER ? slots : BPP * nb) * 64);
     const bool comp = p.n >= 5;
-    const unsigned lds = (unsigned)band_lds(p.T, (p.T - 1) << p.n, DPAD, BNW).total;
-#define SIGB_LAUNCH(G, S)                                                                                       \
-    {                                                                                                           \
-        hipError_t ae = comp ? band_raise_lds<DPAD, G, S, true, BNW>() : band_raise_lds<DPAD, G, S, false, BNW>(); \
-        if (ae != hipSuccess) return hip_fail(ae, "hipFuncSetAttribute(gram_band_kernel)");                     \
-        if (comp) hipLaunchKernelGGL((gram_band_kernel<DPAD, G, S, true, BNW>), grid, block, lds, p.stream, a); \
-        else hipLaunchKernelGGL((gram_band_kernel<DPAD, G, S, false, BNW>), grid, block, lds, p.stream, a);     \
+    const unsigned lds = (unsigned)bandp_lds(p.T, P, DPAD, slots).total;
+#define SIGB_LAUNCH(G, S)                                                                                          \
+    {                                                                                                              \
+        hipError_t ae = comp ? band_raise_lds<DPAD, G, S, true, SER>() : band_raise_lds<DPAD, G, S, false, SER>(); \
+        if (ae != hipSuccess) return hip_fail(ae, "hipFuncSetAttribute(gram_bandp_kernel)");                       \
+        if (comp) hipLaunchKernelGGL((gram_bandp_kernel<DPAD, G, S, true, SER>), grid, block, lds, p.stream, a);   \
+        else hipLaunchKernelGGL((gram_bandp_kernel<DPAD, G, S, false, SER>), grid, block, lds, p.stream, a);       \
     }
     if (grad && sym)
         SIGB_LAUNCH(true, true)
@@ -1245,75 +776,29 @@ int band_launch_variant(const GramProblem &p, BandArgs &a, const GradGeom &g, bo
         SIGB_LAUNCH(false, false)
 #undef SIGB_LAUNCH
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(e, "launch gram_band_kernel");
-    return SIGSVGD_OK;
-}
-} // namespace
-
-namespace {
-template <int DPAD, bool GRAD, bool SYM, bool COMP>
-hipError_t bandp_raise_lds()
-{
-    static std::atomic<unsigned long long> raised{0};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev < 0 || dev >= 64 || !((raised.load(std::memory_order_acquire) >> dev) & 1ull)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gram_bandp_kernel<DPAD, GRAD, SYM, COMP>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        if (dev >= 0 && dev < 64) raised.fetch_or(1ull << dev, std::memory_order_release);
-    }
-    return hipSuccess;
-}
-template <int DPAD>
-int bandp_launch_variant(const GramProblem &p, BandArgs &a, const GradGeom &g, bool grad, bool sym)
-{
-    if (g.tm.owned <= 0 || g.nitems <= 0) return SIGSVGD_OK;
-    a.tm = g.tm;
-    a.nitems = g.nitems;
-    const int P = (p.T - 1) << p.n, nb = (P + 63) >> 6;
-    dim3 grid((unsigned)g.grid), block(BPP * nb * 64);
-    const bool comp = p.n >= 5;
-    const unsigned lds = (unsigned)bandp_lds(p.T, P, DPAD).total;
-#define SIGBP_LAUNCH(G, S)                                                                                   \
-    {                                                                                                        \
-        hipError_t ae = comp ? bandp_raise_lds<DPAD, G, S, true>() : bandp_raise_lds<DPAD, G, S, false>();   \
-        if (ae != hipSuccess) return hip_fail(ae, "hipFuncSetAttribute(gram_bandp_kernel)");                 \
-        if (comp) hipLaunchKernelGGL((gram_bandp_kernel<DPAD, G, S, true>), grid, block, lds, p.stream, a);  \
-        else hipLaunchKernelGGL((gram_bandp_kernel<DPAD, G, S, false>), grid, block, lds, p.stream, a);      \
-    }
-    if (grad && sym)
-        SIGBP_LAUNCH(true, true)
-    else if (grad)
-        SIGBP_LAUNCH(true, false)
-    else if (sym)
-        SIGBP_LAUNCH(false, true)
-    else
-        SIGBP_LAUNCH(false, false)
-#undef SIGBP_LAUNCH
-    hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "launch gram_bandp_kernel");
     return SIGSVGD_OK;
 }
-// Which kernel a launch takes.  The band-parallel kernel wins while its workgroups (one pair each) pass through the chip in a
-// few rounds -- its wavefronts idle BLAG (nb - 1) phases of every sweep, which other workgroups on the CU fill, but the sum of
-// a pair's wavefront time is nb / (1 + BLAG (nb - 1) BGS / (P + 63)) times the serial kernel's; measured on MI355X (Gram +
-// gradient, symmetric, ms): 10 points order 4 -- N = 50 / 70 / 100 / 150: 0.103 / 0.186 / 0.363 / 0.82 against 0.152 / 0.231 /
-// 0.471 / 0.78 serial (1,275 .. 11,325 pairs on 1,280 resident workgroups); 30 points order 3 -- N = 35 / 60 / 100: 0.136 /
-// 0.331 / 0.86 against 0.261 / 0.338 / 0.97 (630 .. 5,050 pairs on 1,024).  Rule: at most five rounds.
-// SIGSVGD_BAND_MODE=serial|parallel (read per launch) overrides it: the tests drive both kernels over the same shapes.
+// Which schedule a launch takes.  Band-parallel wins while its workgroups (one pair each) pass through the chip in a few
+// rounds -- its wavefronts idle BLAG (nb - 1) phases of every sweep, which other workgroups on the CU fill, but the sum of a
+// pair's wavefront time is nb / (1 + BLAG (nb - 1) BGS / (P + 63)) times the serial schedule's.  Measured (Gram + gradient,
+// symmetric, ms, parallel / serial): 10 points order 4 (3 bands, 1,280 resident workgroups) -- N = 50 / 70 / 100 / 150: 0.105 /
+// 0.189 / 0.364 / 0.78 against 0.125 / 0.205 / 0.424 / 0.737; 30 points order 3 (4 bands, 1,024) -- N = 35 / 60 / 100: 0.138 /
+// 0.317 / 0.832 against 0.239 / 0.300 / 0.835.  Rule: at most five rounds with two or three bands, one and a half with four.
+// SIGSVGD_BAND_MODE=serial|parallel (read per launch) overrides it: the tests drive both schedules over the same shapes.
 inline bool band_use_parallel(const GramProblem &p, bool sym)
 {
     const char *e = getenv("SIGSVGD_BAND_MODE");
     if (e && e[0] == 's') return false;
     if (e && e[0] == 'p') return true;
     const long long pairs = sym ? (long long)p.A * (p.A + 1) / 2 : (long long)p.A * p.B;
-    return pairs <= 5ll * device_cu_count() * bandp_wg_per_cu(p.T, p.d, p.n, p.gradX_out != nullptr);
+    const int nb = (((p.T - 1) << p.n) + 63) >> 6;
+    return 2 * pairs <= (nb >= 4 ? 3ll : 10ll) * device_cu_count() * band_wg_per_cu(p.T, p.d, p.n, false);
 }
 } // namespace
 
 // Refined grids of 65 .. 128 cells per side (two bands) with r >= 4 -- BASELINE C1, the planning script's shape: the
-// band-parallel kernel takes them from the refined-grid kernel (gram_dyad.hip) while the launch is small (the same rule as
+// band-parallel schedule takes them from the refined-grid kernel (gram_dyad.hip) while the launch is small (the same rule as
 // above; SIGSVGD_BAND_MODE=serial keeps them on gram_dyad.hip).
 bool band_takes_refined(const GramProblem &p)
 {
@@ -1325,24 +810,18 @@ bool band_takes_refined(const GramProblem &p)
 }
 size_t band_refined_workspace_bytes(int A, int B, int T, int d, int n, int want_grad)
 {
-    size_t bytes = band_flag_bytes(A, B) + 512;
-    if (!want_grad) return bytes;
-    const GradGeom po = bandp_geometry(A, B, T, d, n, false);
-    size_t pneed = po.rseg_bytes;
-    if (A == B) {
-        const GradGeom py = bandp_geometry(A, B, T, d, n, true);
-        if (py.rseg_bytes + py.cslab_bytes > pneed) pneed = py.rseg_bytes + py.cslab_bytes;
-    }
-    return pneed + bandp_wsk_bytes(T, d, n) + band_flag_bytes(A, B) + 1024;
+    return band_need_bytes(A, B, T, d, n, want_grad, false);
 }
 
-static int bandp_launch(const GramProblem &p)
+int band_launch(const GramProblem &p)
 {
     const bool grad = p.gradX_out != nullptr;
     const bool sym = (p.flags & SIGSVGD_FLAG_Y_IS_X) && p.A == p.B;
+    // (grids of up to 128 cells come here for the band-parallel schedule only: band_takes_refined)
+    const bool serial = ((p.T - 1) << p.n) > 128 && !band_use_parallel(p, sym);
     BandArgs a;
     a.X = p.X; a.Y = p.Y; a.go = p.grad_out; a.K = p.K_out; a.rseg = nullptr; a.cslab = nullptr; a.wsk = nullptr;
-    a.wsk_per_wave = bandp_wsk_per_pair(p.T, p.n);
+    a.wsk_per_wave = band_wsk_per_pair(p.T, p.n);
     a.io64 = p.dtype == SIGSVGD_F64; a.A = p.A; a.B = p.B; a.T = p.T; a.d = p.d; a.n = p.n;
     a.symw = (p.flags & SIGSVGD_FLAG_SYM) ? 1 : 0; a.inv_h = p.inv_h;
     a.nitems = 0;
@@ -1350,9 +829,9 @@ static int bandp_launch(const GramProblem &p)
         set_error("sym backward needs A == B");
         return SIGSVGD_E_BADARG;
     }
-    const GradGeom g = bandp_geometry(p.A, p.B, p.T, p.d, p.n, sym, grad);
+    const GradGeom g = band_geometry(p.A, p.B, p.T, p.d, p.n, sym, serial);
     const size_t slabs = grad ? (g.rseg_bytes + g.cslab_bytes + 255) & ~(size_t)255 : 0;
-    const size_t need = band_flag_bytes(p.A, p.B) + slabs + (grad ? bandp_wsk_bytes(p.T, p.d, p.n) : 0) + 256;
+    const size_t need = band_flag_bytes(p.A, p.B) + slabs + (grad ? band_wsk_bytes(p.T, p.d, p.n, serial) : 0) + 256;
     if (!p.ws || p.ws_bytes < need) {
         set_error("band: workspace %zu B < required %zu B", p.ws_bytes, need);
         return SIGSVGD_E_WORKSPACE;
@@ -1373,7 +852,11 @@ static int bandp_launch(const GramProblem &p)
         a.stamps = dbg;
     }
 #endif
-    int rc = p.d <= 8 ? bandp_launch_variant<8>(p, a, g, grad, sym) : bandp_launch_variant<16>(p, a, g, grad, sym);
+    int rc;
+    if (serial)
+        rc = p.d <= 8 ? band_launch_variant<8, true>(p, a, g, grad, sym) : band_launch_variant<16, true>(p, a, g, grad, sym);
+    else
+        rc = p.d <= 8 ? band_launch_variant<8, false>(p, a, g, grad, sym) : band_launch_variant<16, false>(p, a, g, grad, sym);
     if (rc) return rc;
 #ifdef SIGSVGD_PHASE_STAMPS
     {
@@ -1382,57 +865,16 @@ static int bandp_launch(const GramProblem &p)
         (void)hipMemcpy(hs, a.stamps, sizeof(hs), hipMemcpyDeviceToHost);
         double tot = 0;
         for (int k = 0; k < 8; ++k) tot += (double)hs[k];
-        static const char *nm[8] = {"staging/other", "static kernel (band 0)", "forward steps", "forward barriers + idle phases",
-                                    "reverse steps", "reverse barriers + idle phases", "verdict + coarse gradient (band 0) / wait", "-"};
-        fprintf(stderr, "[phase stamps band-parallel] A=%d T=%d d=%d n=%d grad=%d sym=%d: ", p.A, p.T, p.d, p.n, grad ? 1 : 0, sym ? 1 : 0);
+        static const char *nm[8] = {"staging/other", "static kernel", "forward steps", "forward barriers + idle phases",
+                                    "reverse steps", "reverse barriers + idle phases", "verdict + coarse gradient / wait", "-"};
+        fprintf(stderr, "[phase stamps band %s] A=%d T=%d d=%d n=%d grad=%d sym=%d: ", serial ? "serial" : "parallel", p.A, p.T, p.d,
+                p.n, grad ? 1 : 0, sym ? 1 : 0);
         for (int k = 0; k < 7; ++k) fprintf(stderr, "%s %.1f%% | ", nm[k], 100.0 * (double)hs[k] / tot);
         fprintf(stderr, "total %.3e wave-cycles\n", tot);
     }
 #endif
-    rc = generic_repair_launch(p, a.kflag, nullptr, sym, g.tm, BPP);
-    if (rc || !grad) return rc;
-    return grad_reduce_launch(g, a.rseg, a.cslab, p.gradX_out, p.dtype == SIGSVGD_F64, p.A, p.B, p.T * p.d, sym, p.stream);
-}
-
-int band_launch(const GramProblem &p)
-{
-    if (((p.T - 1) << p.n) <= 128 || band_use_parallel(p, (p.flags & SIGSVGD_FLAG_Y_IS_X) && p.A == p.B)) return bandp_launch(p);
-    const bool grad = p.gradX_out != nullptr;
-    const bool sym = (p.flags & SIGSVGD_FLAG_Y_IS_X) && p.A == p.B;
-    BandArgs a;
-    a.X = p.X; a.Y = p.Y; a.go = p.grad_out; a.K = p.K_out; a.rseg = nullptr; a.cslab = nullptr; a.wsk = nullptr;
-    a.wsk_per_wave = band_wsk_per_wave(p.T, p.n);
-    a.io64 = p.dtype == SIGSVGD_F64; a.A = p.A; a.B = p.B; a.T = p.T; a.d = p.d; a.n = p.n;
-    a.symw = (p.flags & SIGSVGD_FLAG_SYM) ? 1 : 0; a.inv_h = p.inv_h;
-    a.nitems = 0;
-    if (a.symw && p.A != p.B) {
-        set_error("sym backward needs A == B");
-        return SIGSVGD_E_BADARG;
-    }
-    const int nw = band_nw(p.A, p.B, sym);
-    const GradGeom g = band_geometry(p.A, p.B, p.T, p.d, p.n, sym, nw);
-    const size_t slabs = grad ? (g.rseg_bytes + g.cslab_bytes + 255) & ~(size_t)255 : 0;
-    const size_t need = band_flag_bytes(p.A, p.B) + slabs + (grad ? band_wsk_bytes(p.T, p.d, p.n, nw) : 0) + 256;
-    if (!p.ws || p.ws_bytes < need) {
-        set_error("band: workspace %zu B < required %zu B", p.ws_bytes, need);
-        return SIGSVGD_E_WORKSPACE;
-    }
-    unsigned char *base = reinterpret_cast<unsigned char *>((reinterpret_cast<uintptr_t>(p.ws) + 255) & ~(uintptr_t)255);
-    a.kflag = base;
-    base += band_flag_bytes(p.A, p.B);
-    if (grad) {
-        a.rseg = reinterpret_cast<double *>(base);
-        a.cslab = sym ? reinterpret_cast<float *>(base + g.rseg_bytes) : nullptr;
-        a.wsk = reinterpret_cast<float *>(base + slabs);
-    }
-    int rc;
-    if (nw == 4)
-        rc = p.d <= 8 ? band_launch_variant<8, 4>(p, a, g, grad, sym) : band_launch_variant<16, 4>(p, a, g, grad, sym);
-    else
-        rc = p.d <= 8 ? band_launch_variant<8, 8>(p, a, g, grad, sym) : band_launch_variant<16, 8>(p, a, g, grad, sym);
-    if (rc) return rc;
     // fp64 pass of the coverage kernel over the flagged pairs (a few microseconds when there are none)
-    rc = generic_repair_launch(p, a.kflag, nullptr, sym, g.tm, nw);
+    rc = generic_repair_launch(p, a.kflag, nullptr, sym, g.tm, g.NW);
     if (rc || !grad) return rc;
     return grad_reduce_launch(g, a.rseg, a.cslab, p.gradX_out, p.dtype == SIGSVGD_F64, p.A, p.B, p.T * p.d, sym, p.stream);
 }

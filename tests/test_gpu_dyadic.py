@@ -102,7 +102,7 @@ def test_dyadic_reference_shapes_at_their_sizes(gpu):
     bandwidth 5) and the maze controller's (35 policies x 30 steps x 2, order 3, sigma^2 = 32)"""
     from sigsvgd_amd import ops
 
-    # (150 x 10, order 4: 11,325 pairs, more than five rounds of band-parallel workgroups -- the serial band kernel by the
+    # (150 x 10, order 4: 11,325 pairs, more than five rounds of band-parallel workgroups -- the serial schedule by the
     #  launcher's own rule; the notebook and maze sizes take the band-parallel kernel)
     for N, T, d, n, h in [(30, 5, 2, 5, 0.9), (16, 20, 2, 2, 1.0), (300, 5, 2, 5, 1.0), (100, 10, 2, 4, 5.0), (35, 30, 2, 3, 5.6),
                           (150, 10, 2, 4, 5.0)]:
@@ -140,10 +140,11 @@ def test_band_kernel_rough_and_smooth_extremes(gpu, T, n, d, scale, h, offset):
 @pytest.mark.parametrize("T,n,d", BAND_SHAPES)
 @pytest.mark.parametrize("sym", [True, False])
 def test_band_kernels_agree(gpu, monkeypatch, T, n, d, sym):
-    """gram_band.hip holds two kernels for 129 .. 256 cells per side: one wavefront per pair (launches with many pairs) and one
-    wavefront per BAND of a pair, pipelined over a workgroup (the reference's sizes).  Same arithmetic per cell and the same
-    order in every block sum: K and the flags of the exact pass are equal bit for bit; the gradients differ by the order of
-    the fixed-order reduction only (tiles of 8 or 4 rows against tiles of one).  SIGSVGD_BAND_MODE picks the kernel."""
+    """gram_band.hip runs its kernel on two schedules for 129 .. 256 cells per side: a wavefront per pair that walks the bands
+    in turn (launches with many pairs) and a wavefront per BAND of a pair, pipelined over a workgroup (the reference's sizes).
+    Same arithmetic per cell and the same order in every block sum: K and the flags of the exact pass are equal bit for bit;
+    the gradients differ by the order of the fixed-order reduction only (tiles of up to 8 rows against tiles of one).
+    SIGSVGD_BAND_MODE picks the schedule."""
     from sigsvgd_amd import ops
 
     A, B = 11, 11 if sym else 7
