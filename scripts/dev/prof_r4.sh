@@ -25,6 +25,7 @@ python3 scripts/pmc_summary.py sq $O/r04_sq_counters_refined.csv $O/p_sqb
 for m in sym ordered; do python3 scripts/dev/phase_stamps.py 1024 64 7 $m 2>&1 | grep "phase stamps" >> $O/stamps.txt; done
 python3 scripts/dev/phase_stamps.py 512 64 3 sym 2>&1 | grep "phase stamps" >> $O/stamps.txt
 python3 scripts/dev/phase_stamps.py 256 128 14 sym 2>&1 | grep "phase stamps" >> $O/stamps.txt
+for a in "100 10 2 dyadic4" "35 30 2 dyadic3" "150 10 2 dyadic4" "16 20 2 dyadic2"; do python3 scripts/dev/phase_stamps.py $a 2>&1 | grep "phase stamps band" | tail -1 >> $O/stamps.txt; done
 echo step5 done
 python3 scripts/shard_cost.py > $O/shard_cost.txt 2>&1 || true
 tail -8 $O/shard_cost.txt
