@@ -784,7 +784,9 @@ int band_launch_variant(const GramProblem &p, BandArgs &a, const GradGeom &g, bo
 // pair's wavefront time is nb / (1 + BLAG (nb - 1) BGS / (P + 63)) times the serial schedule's.  Measured (Gram + gradient,
 // symmetric, ms, parallel / serial): 10 points order 4 (3 bands, 1,280 resident workgroups) -- N = 50 / 70 / 100 / 150: 0.105 /
 // 0.189 / 0.364 / 0.78 against 0.125 / 0.205 / 0.424 / 0.737; 30 points order 3 (4 bands, 1,024) -- N = 35 / 60 / 100: 0.138 /
-// 0.317 / 0.832 against 0.239 / 0.300 / 0.835.  Rule: at most five rounds with two or three bands, one and a half with four.
+// 0.317 / 0.832 against 0.239 / 0.300 / 0.835.  Rule: at most five rounds with three bands, one and a half with four.  With
+// two bands (65 .. 128 cells) it beats the refined-grid kernel of gram_dyad.hip at every size measured (N = 64 .. 400: 20 points
+// order 2 0.156 / 0.423 / 1.52 against 0.170 / 0.477 / 1.78; 5 points order 5 0.80 / 3.13 against 0.92 / 3.52): always.
 // SIGSVGD_BAND_MODE=serial|parallel (read per launch) overrides it: the tests drive both schedules over the same shapes.
 inline bool band_use_parallel(const GramProblem &p, bool sym)
 {
@@ -793,13 +795,14 @@ inline bool band_use_parallel(const GramProblem &p, bool sym)
     if (e && e[0] == 'p') return true;
     const long long pairs = sym ? (long long)p.A * (p.A + 1) / 2 : (long long)p.A * p.B;
     const int nb = (((p.T - 1) << p.n) + 63) >> 6;
+    if (nb <= 2) return true;
     return 2 * pairs <= (nb >= 4 ? 3ll : 10ll) * device_cu_count() * band_wg_per_cu(p.T, p.d, p.n, false);
 }
 } // namespace
 
 // Refined grids of 65 .. 128 cells per side (two bands) with r >= 4 -- BASELINE C1, the planning script's shape: the
-// band-parallel schedule takes them from the refined-grid kernel (gram_dyad.hip) while the launch is small (the same rule as
-// above; SIGSVGD_BAND_MODE=serial keeps them on gram_dyad.hip).
+// band-parallel schedule takes them from the refined-grid kernel of gram_dyad.hip (which keeps grids of exactly 64 cells and
+// dyadic order 1; SIGSVGD_BAND_MODE=serial sends them back to it: the tests compare the two).
 bool band_takes_refined(const GramProblem &p)
 {
     if (p.n < 2 || p.n > 7 || p.T < 3 || p.T > BTMAX || p.d > 16) return false;

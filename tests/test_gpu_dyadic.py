@@ -96,6 +96,24 @@ def test_dyadic_symmetric(gpu, T, n, d, weights):
     assert _relK(Kf.cpu().numpy(), Kref) < TOL
 
 
+def test_refined_grid_kernel_large_launch(gpu, monkeypatch):
+    """gram_dyad.hip with more items than workgroups (N = 300: 5,700 items of 8 rows), pinned to it: by default the
+    band-parallel schedule of gram_band.hip takes every launch of 65 .. 128 cells"""
+    from sigsvgd_amd import ops
+
+    monkeypatch.setenv("SIGSVGD_BAND_MODE", "serial")
+    N, T, d, n, h = 300, 5, 2, 5, 1.0
+    X = _paths(N, T, d, 12, 0.3)
+    Xg = torch.as_tensor(X, device=gpu)
+    K, g = ops.gram_fwd_bwd(Xg, Xg, 1.0 / h, n, y_is_x=True)
+    Kref, gref = C.gram_fwd_bwd(X, X, h, n, rows=(0, 6))
+    assert _relK(K.cpu().numpy()[:6], Kref) < TOL
+    assert np.abs(g.cpu().numpy()[:6] - gref).max() / np.abs(g.cpu().numpy()).max() < TOL
+    monkeypatch.setenv("SIGSVGD_BAND_MODE", "parallel")
+    Kp, gp = ops.gram_fwd_bwd(Xg, Xg, 1.0 / h, n, y_is_x=True)
+    assert _relK(Kp.cpu().numpy(), K.double().cpu().numpy()) < TOL and _rel(gp.cpu().numpy(), g.double().cpu().numpy()) < TOL
+
+
 def test_dyadic_reference_shapes_at_their_sizes(gpu):
     """the reference's planning experiment (30 particles x 5 knots in R^2, order 5) and BASELINE C1 (16 x 20 x 2, order 2)
     plus a launch with more items than workgroups (N = 300: 5,700 items); the notebook's experiment (100 x 10 x 2, order 4,
