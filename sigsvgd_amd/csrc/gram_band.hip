@@ -204,22 +204,24 @@ __device__ __forceinline__ void bandp_rev_phase(BandRev &st, const float (&hv)[B
     for (int k = 0; k < BHS; ++k) gq[k] = dcrow[(st.q - k) >> n]; // (a column outside the grid: one of the row's zeros)
 #pragma unroll
     for (int u = 0; u < BHS; ++u) {
-        const bool active = ALLIN || (rowvalid && (unsigned)st.q < (unsigned)P);
         const float g = gq[u];
         const float kf = kfr[(H + u) & (BKR - 1)];
         kfr[(H + u) & (BKR - 1)] = rnext[lanep - 64 * u];
         float down = hv[u]; // (lane 63 has no source lane: it keeps the boundary row's entry)
         asm("s_nop 1\n\tv_mov_b32_dpp %0, %1 wave_shl:1 row_mask:0xf bank_mask:0xf" : "+v"(down) : "v"(st.cur));
-        st.run = __builtin_fmaf(active ? kf : 0.f, st.dprev, st.run);
+        // (no activity test on K_fwd: a lane outside the grid sums garbage that nothing consumes -- ahead of its row the run is
+        //  reset on column P = 0 mod r, the step before the row starts; behind it the run has been handed up on column 0; the
+        //  bottom lane of a coarse row takes nothing from below, so rows outside the grid do not leak in)
+        st.run = __builtin_fmaf(kf, st.dprev, st.run);
         const float recv = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(st.out), 0x130, 0xF, 0xF, true)); // lane 63: 0
         st.out = __builtin_fmaf(recv, chain, st.run);
         if (u == BFU) { // the one step of a group on which the top lanes can end a cell (see BFU): flushed behind the group
             out6 = st.out;
-            cell6 = (top && active) ? st.q >> n : -1;
+            cell6 = (top && (ALLIN || (unsigned)st.q < (unsigned)P)) ? st.q >> n : -1;
         }
         if (u == BFU - 4) { // (r = 4, grids of 65 .. 128 cells: the second such step of a group)
             out2 = st.out;
-            cell2 = (top && active) ? st.q >> n : -1;
+            cell2 = (top && (ALLIN || (unsigned)st.q < (unsigned)P)) ? st.q >> n : -1;
         }
         st.run = (st.q & (r - 1)) == 0 ? 0.f : st.run; // (a lane outside the grid carries run = 0 anyway)
         const float t = st.cur + down;
