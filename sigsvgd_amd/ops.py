@@ -56,21 +56,41 @@ def _io_dtype(t: torch.Tensor) -> int:
     raise TypeError(f"sigsvgd_amd: paths must be float32 or float64, got {t.dtype}")
 
 
+def pad_to_length(P: torch.Tensor, T: int) -> torch.Tensor:
+    """[batch, t, d] -> [batch, T, d] with the LAST point repeated.  Exact for the signature kernel: the repeated points add
+    zero increments, for which the Goursat stencil copies the solution along the added rows / columns (in every kernel of
+    the library: the 4-corner increment of two equal rows of the static kernel is an exact zero), at any dyadic order."""
+    t = P.shape[1]
+    if t == T:
+        return P
+    return torch.cat([P, P[:, -1:, :].expand(-1, T - t, -1)], dim=1)
+
+
+def fold_padded_grad(g: torch.Tensor, t: int) -> torch.Tensor:
+    """gradient w.r.t. a path padded by pad_to_length -> gradient w.r.t. the path itself: the copies of the last point add up"""
+    if g.shape[1] == t:
+        return g
+    out = g[:, :t].clone()
+    out[:, t - 1] += g[:, t:].sum(dim=1)
+    return out
+
+
 def _prep_paths(X: torch.Tensor, Y: torch.Tensor):
+    """-> (X, Y) contiguous, detached, of one dtype and ONE length: upstream sigkernel takes paths of different lengths
+    (no caller in the reference does, src/kernels/_traj_kernels.py:200); the shorter batch is padded with its last point,
+    which leaves every K[i, j] unchanged (pad_to_length).  The callers fold the gradient back (fold_padded_grad)."""
     if X.dim() != 3 or Y.dim() != 3:
         raise ValueError(f"paths must be [batch, length, dim]; got {tuple(X.shape)} and {tuple(Y.shape)}")
-    if X.shape[1:] != Y.shape[1:]:
-        raise ValueError(
-            f"X and Y must share length and dim (got {tuple(X.shape)} vs {tuple(Y.shape)}); "
-            "unequal path lengths are not supported by this build"
-        )
+    if X.shape[2] != Y.shape[2]:
+        raise ValueError(f"X and Y must share the path dimension (got {tuple(X.shape)} vs {tuple(Y.shape)})")
     if X.dtype != Y.dtype:
         Y = Y.to(X.dtype)
     if X.shape[0] == 0 or Y.shape[0] == 0:
         raise ValueError("empty batch")
-    if X.shape[1] < 2:
+    if X.shape[1] < 2 or Y.shape[1] < 2:
         raise ValueError("paths need at least 2 points")
-    return X.detach().contiguous(), Y.detach().contiguous()
+    T = max(X.shape[1], Y.shape[1])
+    return pad_to_length(X.detach(), T).contiguous(), pad_to_length(Y.detach(), T).contiguous()
 
 
 def _flags(naive: bool, sym: bool, y_is_x: bool, force_generic: bool, stored_forward: bool = False) -> int:
@@ -98,6 +118,8 @@ def gram_fwd(X, Y, inv_h: float, dyadic_order: int = 0, static_kind: int = _lib.
     Xc, Yc = _prep_paths(X, Y)
     A, T, d = Xc.shape
     B = Yc.shape[0]
+    if y_is_x and X.shape[1] != Y.shape[1]:
+        raise ValueError("y_is_x needs X and Y of one shape")
     flags = _flags(naive, False, bool(y_is_x) and A == B, force_generic, stored_forward)
     nbytes = ctypes.c_size_t(0)
     _lib.check(L.sigsvgd_gram_workspace_bytes(A, B, T, d, dyadic_order, int(static_kind), 0, flags, ctypes.byref(nbytes)),
@@ -137,6 +159,8 @@ def gram_fwd_bwd(X, Y, inv_h: float, dyadic_order: int = 0, static_kind: int = _
         if tuple(grad_out.shape) != (A, B):
             raise ValueError(f"grad_out must be [{A},{B}], got {tuple(grad_out.shape)}")
         go = grad_out.detach().to(Xc.dtype).contiguous()
+    if (y_is_x or sym) and X.shape[1] != Y.shape[1]:
+        raise ValueError("y_is_x / sym need X and Y of one shape")
     flags = _flags(naive, sym, y_is_x, force_generic, stored_forward)
     nbytes = ctypes.c_size_t(0)
     _lib.check(L.sigsvgd_gram_workspace_bytes(A, B, T, d, dyadic_order, int(static_kind), 1, flags, ctypes.byref(nbytes)),
@@ -150,7 +174,7 @@ def gram_fwd_bwd(X, Y, inv_h: float, dyadic_order: int = 0, static_kind: int = _
                                     go.data_ptr() if go is not None else None, K.data_ptr(), gX.data_ptr(),
                                     ws.data_ptr() if ws is not None else None, wsn, _stream_ptr(dev))
     _lib.check(rc, "gram_fwd_bwd")
-    return K, gX
+    return K, fold_padded_grad(gX, X.shape[1])
 
 
 def svgd_phi(K, score, grad_k, mask=None, X=None, lr: Optional[float] = None, adagrad_state=None,

@@ -193,7 +193,8 @@ class SigKernel:
         self.value_check_min_batch = 32  # below this a launch is latency-bound and the compare would not pay
 
     def compute_Gram(self, X: torch.Tensor, Y: torch.Tensor, sym: bool = False) -> torch.Tensor:
-        """K[i,j] = k_sig(X_i, Y_j), X [A,T,d], Y [B,T,d] on a HIP device; same dtype/device as X."""
+        """K[i,j] = k_sig(X_i, Y_j), X [A,Tx,d], Y [B,Ty,d] on a HIP device; same dtype/device as X.  Paths of different
+        lengths (upstream sigkernel takes them) are padded with their last point, which is exact (ops.pad_to_length)."""
         static_kind, inv_h = _resolve_static(self.static_kernel, X, Y)
         y_is_x = (
             Y.data_ptr() == X.data_ptr() and Y.shape == X.shape and Y.stride() == X.stride() and Y.dtype == X.dtype

@@ -604,3 +604,38 @@ def test_planning_example_runs_on_the_device_and_lowers_the_cost(gpu):
     out = mod.run(steps=60, n_obst=10, seed=0, device=str(gpu))
     assert out["trajectories"].shape == (20, 100, 2) and bool(torch.isfinite(out["trajectories"]).all())
     assert out["cost_final"] < out["cost_initial"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("A,Tx,B,Ty,d,n", [(9, 20, 7, 13, 3, 0), (5, 40, 6, 64, 7, 0), (4, 100, 5, 70, 2, 0), (6, 10, 5, 7, 2, 4),
+                                           (5, 5, 7, 9, 2, 2), (4, 12, 4, 30, 2, 3)])
+def test_unequal_path_lengths(gpu, A, Tx, B, Ty, d, n):
+    """upstream sigkernel's compute_Gram takes X [A, Tx, d] and Y [B, Ty, d]; here the shorter batch is padded with its last
+    point on the host (exact), on whichever kernel the padded shape takes.  Against the numpy oracle's rectangular solve."""
+    import numpy as np
+
+    from oracle import sigkernel_oracle as O
+    from sigsvgd_amd import ops, sigkernel
+
+    rng = np.random.default_rng(7)
+    X = np.cumsum(0.15 * rng.standard_normal((A, Tx, d)), 1).astype(np.float32)
+    Y = np.cumsum(0.15 * rng.standard_normal((B, Ty, d)), 1).astype(np.float32)
+    go = rng.uniform(0.5, 1.5, (A, B)).astype(np.float32)
+    Kref, gref = O.gram_backward(X.astype(np.float64), Y.astype(np.float64), go.astype(np.float64), O.RBF, 1.0, n)
+    Xg, Yg, gog = (torch.as_tensor(t, device=gpu) for t in (X, Y, go))
+    K, g = ops.gram_fwd_bwd(Xg, Yg, 1.0, n, grad_out=gog)
+    Kf = ops.gram_fwd(Xg, Yg, 1.0, n)
+    assert tuple(g.shape) == (A, Tx, d)
+    relK = lambda a: float((np.abs(a.double().cpu().numpy() - Kref) / np.maximum(np.abs(Kref), 1e-6)).max())
+    assert relK(K) < 1e-5 and relK(Kf) < 1e-5
+    assert float(np.abs(g.double().cpu().numpy() - gref).max() / np.abs(gref).max()) < 1e-5
+    with pytest.raises(ValueError):
+        ops.gram_fwd_bwd(Xg, Yg, 1.0, n, y_is_x=True)
+    # through the sigkernel-compatible class and autograd
+    sk = sigkernel.SigKernel(sigkernel.RBFKernel(sigma=1.0), n)
+    Xa = Xg.clone().requires_grad_(True)
+    Ka = sk.compute_Gram(Xa, Yg)
+    (Ka * gog).sum().backward()
+    Kr2, gr2 = Kref, gref  # RBFKernel(sigma): exp(-|x - y|^2 / sigma), sigkernel's convention
+    assert float((np.abs(Ka.detach().double().cpu().numpy() - Kr2) / np.maximum(np.abs(Kr2), 1e-6)).max()) < 1e-5
+    assert float(np.abs(Xa.grad.double().cpu().numpy() - gr2).max() / np.abs(gr2).max()) < 1e-5

@@ -321,3 +321,29 @@ def test_constant_bandwidth_detection():
     assert k2._constant_bandwidth() == 0.5
     k2.get_bandwidth = lambda sq: sq.mean()
     assert k2._constant_bandwidth() is None
+
+
+def test_unequal_lengths_by_padding_is_exact():
+    """ops pads the shorter batch of paths with its last point and folds the gradient of the copies back: zero increments copy
+    the PDE solution along the added rows, so K and the first-slot gradient equal those of the unpadded problem (numpy oracle,
+    which solves rectangular grids directly; reference: upstream sigkernel accepts unequal lengths, no caller uses them)"""
+    import numpy as np
+    import torch
+
+    from oracle import sigkernel_oracle as O
+    from sigsvgd_amd import ops
+
+    rng = np.random.default_rng(0)
+    for (A, Tx, B, Ty, d, n) in [(3, 7, 4, 5, 2, 1), (2, 4, 3, 9, 3, 0), (3, 6, 2, 6, 2, 2)]:
+        X = np.cumsum(0.2 * rng.standard_normal((A, Tx, d)), 1)
+        Y = np.cumsum(0.2 * rng.standard_normal((B, Ty, d)), 1)
+        go = rng.uniform(0.5, 1.5, (A, B))
+        K, g = O.gram_backward(X, Y, go, O.RBF, 1.3, n)
+        T = max(Tx, Ty)
+        Xp = ops.pad_to_length(torch.as_tensor(X), T).numpy()
+        Yp = ops.pad_to_length(torch.as_tensor(Y), T).numpy()
+        assert Xp.shape == (A, T, d) and Yp.shape == (B, T, d)
+        Kp, gp = O.gram_backward(Xp, Yp, go, O.RBF, 1.3, n)
+        gf = ops.fold_padded_grad(torch.as_tensor(gp), Tx).numpy()
+        assert np.abs(K - Kp).max() < 1e-13
+        assert gf.shape == g.shape and np.abs(g - gf).max() < 1e-13
