@@ -212,7 +212,12 @@ __device__ __forceinline__ void bandp_rev_phase(BandRev &st, const float (&hv)[B
         // (no activity test on K_fwd: a lane outside the grid sums garbage that nothing consumes -- ahead of its row the run is
         //  reset on column P = 0 mod r, the step before the row starts; behind it the run has been handed up on column 0; the
         //  bottom lane of a coarse row takes nothing from below, so rows outside the grid do not leak in)
-        st.run = __builtin_fmaf(kf, st.dprev, st.run);
+        // S - 1 is what is summed: on smooth paths S = K_fwd U is 1 + O(increments) in every cell, the 4-corner scatter of the
+        // block sums cancels the constant, and fp32 sums of r values near 1 would keep 6e-8 r of rounding each against a
+        // difference of O(increments) (very smooth paths in one channel: 2.6e-5 on the gradient).  The constant comes back
+        // where the scatter does not cancel it: the four corners of the point grid (the contraction's table) and the
+        // condition number.
+        st.run += __builtin_fmaf(kf, st.dprev, -1.f);
         const float recv = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(st.out), 0x130, 0xF, 0xF, true)); // lane 63: 0
         st.out = __builtin_fmaf(recv, chain, st.run);
         if (u == BFU) { // the one step of a group on which the top lanes can end a cell (see BFU): flushed behind the group
@@ -538,7 +543,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(GRAD && SER
                 const int wtid = band0 * 64 + lanep, wnt = SER ? 64 : nb * 64;
                 for (int e = wtid; e < T * T; e += wnt) {
                     const int m = e / T, nn = e - m * T;
-                    Rt[e] = (Sat(m - 1, nn - 1) + Sat(m, nn)) - (Sat(m - 1, nn) + Sat(m, nn - 1));
+                    // (the table holds sums of S - 1: + r^2 per cell inside the grid, i.e. +-1 at the four corners after the scatter)
+                    const float corner = ((m == 0 || m == Tm) && (nn == 0 || nn == Tm)) ? (m == nn ? 1.f : -1.f) : 0.f;
+                    Rt[e] = (Sat(m - 1, nn - 1) + Sat(m, nn)) - (Sat(m - 1, nn) + Sat(m, nn - 1)) + corner;
                 }
                 for (int e = wtid; e < T * DPAD; e += wnt) {
                     const int m = e / DPAD, c = e - m * DPAD;
@@ -552,7 +559,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(GRAD && SER
                     float cs = 0.f;
                     for (int e = lanep; e < Tm * Tm; e += 64) {
                         const int ra = e / Tm;
-                        cs = __builtin_fmaf(fabsf((float)Sc[e]), fabsf(Dc[ra * DS + BZP + (e - ra * Tm)]), cs);
+                        cs = __builtin_fmaf(fabsf((float)(Sc[e] + (double)(r * r))), fabsf(Dc[ra * DS + BZP + (e - ra * Tm)]), cs);
                     }
 #pragma unroll
                     for (int off = 1; off < 64; off <<= 1) cs += __shfl_xor(cs, off, 64);

@@ -154,8 +154,9 @@ def test_argument_errors(gpu):
     from sigsvgd_amd import ops
 
     x = torch.zeros(4, 10, 3, device=gpu)
+    assert tuple(ops.gram_fwd(x, torch.zeros(4, 9, 3, device=gpu), 1.0).shape) == (4, 4)  # ragged lengths: padded (round 4)
     with pytest.raises(ValueError):
-        ops.gram_fwd(x, torch.zeros(4, 9, 3, device=gpu), 1.0)      # ragged path lengths
+        ops.gram_fwd(x, torch.zeros(4, 9, 3, device=gpu), 1.0, y_is_x=True)   # ... but not declared the same batch
     with pytest.raises(ValueError):
         ops.gram_fwd(x, torch.zeros(4, 10, 2, device=gpu), 1.0)     # channel mismatch
     with pytest.raises(ValueError):
