@@ -175,7 +175,7 @@ __device__ __forceinline__ void bandp_fwd_phase(BandFwd &st, const float (&hv)[B
 // The same for the reverse sweep: the boundary lane is lane 63 of a full band (no DPP source from above: keeps hv[u]); the
 // last band's boundary is U = 1, which lane L - 1 finds in lane L (a row outside the grid never leaves its initial 1).
 struct BandRev {
-    float cur, dprev, V, run, out;
+    float cur, dprev, V, run, out, clo;
     int q;
 };
 // ALLIN: every lane is inside the grid on every step of the phase (no activity test for the block sums).  The state of a lane
@@ -194,7 +194,9 @@ struct BandRev {
 // stays fp64.
 constexpr int BFU = 6;
 constexpr int BKR = 8; // depth of the register ring the forward solution comes back through (16: maze shape -1.6 %, but 142 registers)
-template <bool ALLIN, int H>
+// COMPR: the reverse sweep's full-magnitude add in two floats as well (see COMP; one-channel launches: very smooth paths in one
+// channel keep 1.8e-5 on the gradient with the forward add alone).
+template <bool ALLIN, int H, bool COMPR>
 __device__ __forceinline__ void bandp_rev_phase(BandRev &st, const float (&hv)[BHS], float (&kfr)[BKR], const float *rnext, int lanep,
                                                 const float *dcrow, float chain, bool top, int n, int r, int P, bool rowvalid,
                                                 float *ho, float &out6, int &cell6, float &out2, int &cell2)
@@ -233,8 +235,12 @@ __device__ __forceinline__ void bandp_rev_phase(BandRev &st, const float (&hv)[B
         float y = 1.7320508075688772f * t;
         y = __builtin_fmaf(t + st.dprev, g, y);
         const float Vn = __builtin_fmaf(g, y, st.V);
-        const float nw = down + Vn;
-        ho[BHS - 1 - u] = nw; // (`ho` is the group's LAST entry: LDS offsets are unsigned.  A lane outside the grid writes into the padding, or entries nobody reads)
+        float Vt = Vn, nlo = 0.f;
+        if constexpr (COMPR) Vt += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(st.clo), 0x130, 0xF, 0xF, true));
+        const float nw = down + Vt;
+        if constexpr (COMPR) nlo = Vt - (nw - down);
+        ho[BHS - 1 - u] = COMPR ? nw + nlo : nw; // (`ho` is the group's LAST entry: LDS offsets are unsigned.  A lane outside the grid writes into the padding, or entries nobody reads)
+        if constexpr (COMPR) st.clo = nlo;
         st.cur = nw;
         st.V = Vn;
         st.dprev = down;
@@ -458,7 +464,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(GRAD && SER
                 double *scrow = Sc + arow * Tm;
                 const bool lastband = band == nb - 1;
                 BandRev st;
-                st.cur = 1.f; st.dprev = 1.f; st.V = 0.f; st.run = 0.f; st.out = 0.f;
+                st.cur = 1.f; st.dprev = 1.f; st.V = 0.f; st.run = 0.f; st.out = 0.f; st.clo = 0.f;
                 st.q = P - 1 + (L - 1 - lanep);
                 const int rr = min(r, 64);
                 const float chain = ((p & (rr - 1)) == rr - 1) ? 0.f : 1.f; // the bottom lane of a coarse row takes nothing from below
@@ -510,10 +516,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(GRAD && SER
                             float out6, out2;
                             int cell6, cell2;
                             static_assert(BKR == BHS, "a deeper ring needs the group's position in it as a compile-time constant");
-                            if (plat)
-                                bandp_rev_phase<true, 0>(st, hv, kfr, rnext, lanep, dcrow, chain, top, n, r, P, rowvalid, ho - (BHS - 1), out6, cell6, out2, cell2);
+                            if (COMP && d == 1) // (one channel at the orders of the two-float add)
+                                bandp_rev_phase<false, 0, true>(st, hv, kfr, rnext, lanep, dcrow, chain, top, n, r, P, rowvalid, ho - (BHS - 1), out6, cell6, out2, cell2);
+                            else if (plat)
+                                bandp_rev_phase<true, 0, false>(st, hv, kfr, rnext, lanep, dcrow, chain, top, n, r, P, rowvalid, ho - (BHS - 1), out6, cell6, out2, cell2);
                             else
-                                bandp_rev_phase<false, 0>(st, hv, kfr, rnext, lanep, dcrow, chain, top, n, r, P, rowvalid, ho - (BHS - 1), out6, cell6, out2, cell2);
+                                bandp_rev_phase<false, 0, false>(st, hv, kfr, rnext, lanep, dcrow, chain, top, n, r, P, rowvalid, ho - (BHS - 1), out6, cell6, out2, cell2);
                             rnext -= BHS * 64;
                             ho += hinc;
                             // (step BFU of the group ends the top lanes' cells iff L - 2 - (sp0 + h + BFU) = 0 mod r)
@@ -766,7 +774,7 @@ int band_launch_variant(const GramProblem &p, BandArgs &a, const GradGeom &g, bo
     const int P = (p.T - 1) << p.n, nb = (P + 63) >> 6;
     const int slots = SER ? band_serial_slots(p.T, p.d, p.n) : 0;
     dim3 grid((unsigned)g.grid), block((SER ? slots : BPP * nb) * 64);
-    const bool comp = p.n >= 5;
+    const bool comp = p.n >= 5 || p.d == 1; // (one channel: both sweeps, see COMPR)
     const unsigned lds = (unsigned)bandp_lds(p.T, P, DPAD, slots).total;
 #define SIGB_LAUNCH(G, S)                                                                                          \
     {                                                                                                              \
