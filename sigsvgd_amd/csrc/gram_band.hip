@@ -27,9 +27,9 @@ namespace sigsvgd {
 struct BandArgs {
     const void *X, *Y, *go;
     void *K;
-    double *rseg; // [owned tiles + workgroups][8][T*d]
+    double *rseg; // [owned tiles + workgroups][rows per tile][T*d]
     float *cslab; // [items][T*d] (symmetric launches)
-    float *wsk;   // [gridDim.x][8 waves][bands][steps][64]: forward solution of the pair in work (gradient launches)
+    float *wsk;   // [gridDim.x][pairs per workgroup][bands][steps][64]: forward solution of the pair in work (gradient launches)
     size_t wsk_per_wave;
     unsigned char *kflag; // [A][B]: 1 where the fp32 solution of the pair cancelled (max |K_grid| > r max(|K|, 0.1), r = 2 / 4 / 8) or is ill-conditioned (d <= 3), as in
                           // gram_quad.hip): the launcher lets the coverage kernel solve those pairs' K again in fp64
@@ -72,19 +72,19 @@ __device__ __forceinline__ void b_stany(void *b, size_t i, double v, int io64)
 } // namespace
 
 namespace {
-// ---- band-parallel kernel: one wavefront per BAND of a pair ----------------------------------------------------------
-// The reference's refined call shapes come with few pairs (notebook 5,050, maze 630): one wavefront per pair leaves most of
-// the chip's 1,024 SIMDs with one wavefront or none, and each of them walks nb (P + 63) dependent steps per sweep.  Here the nb
-// bands of a pair run on nb wavefronts of one workgroup, as a pipeline: band b needs, on its step s, the entry lane 63 of band
-// b - 1 wrote on step s + 63, so it runs BLAG phases of BGS steps behind its neighbour, with a workgroup barrier between the
-// phases (every wavefront of the workgroup runs the same phase schedule; a band outside its step range just waits).  A sweep
-// takes ceil((P + 63) / BGS) + BLAG (nb - 1) phases instead of nb (P + 63) steps: 368 against 621 step times at the notebook
-// shape, 544 against 1,180 at the maze shape.  The arithmetic of every cell, the order of every sum (a coarse cell's fine rows
-// lie inside one band, since r divides 64) and hence every result bit are those of the serial band sweep above.
-// A workgroup holds BPP pairs (rows i, i + 1 against the staged column j): 2 nb wavefronts.
+// ---- the band kernel ---------------------------------------------------------------------------------------------------
+// Band-parallel schedule.  The reference's refined call shapes come with few pairs (notebook 5,050, maze 630): one wavefront
+// per pair leaves most of the chip's 1,024 SIMDs with one wavefront or none, each walking nb (P + 63) dependent steps per
+// sweep.  Here the nb bands of a pair run on nb wavefronts of ONE workgroup, as a pipeline: band b needs, on its step s, the
+// entry lane 63 of band b - 1 wrote on ITS step s + 63, so it runs BLAG phases of BGS steps behind its neighbour, with a
+// workgroup barrier between the phases (every wavefront of the workgroup runs the same phase schedule; a band outside its step
+// range just waits).  A sweep takes ceil((P + 63) / BGS) + BLAG (nb - 1) phases instead of nb (P + 63) steps: 368 against 621
+// step times at the notebook's shape, 544 against 1,180 at the maze script's.  A workgroup is one pair: nb wavefronts.
+// Serial schedule (template parameter SER): see the kernel.  The arithmetic of every cell and the order of every sum (a coarse
+// cell's fine rows lie inside one band, since r divides 64) do not depend on the schedule: K is the same bit for bit.
 constexpr int BGS = 16; // steps per phase
 constexpr int BLAG = 5; // phases a band runs behind its neighbour: BLAG * BGS > 62 + BGS + 1 steps (see the refills in the kernel)
-constexpr int BPP = 1;  // pairs per workgroup
+constexpr int BPP = 1;  // pairs per workgroup of the band-parallel schedule (2: measured, slower -- twice the rounds at the reference's sizes)
 constexpr int BUO = 96; // offset of entry 0 in a reverse boundary row (a phase reads down to entry P - 16 - sp0 >= -78)
 // The increment table carries zeros on either side of every row and one row of zeros behind the last: a lane outside the
 // grid (column < 0 or >= P on the ramps of its band, or a row >= P of the last band) reads gamma = 0, for which a step leaves
@@ -95,7 +95,7 @@ __host__ __device__ inline int band_zpad(int r) { return 80 / r + 2; }
 
 struct BandPLds {
     int yd, yf, yref;                        // shared by the workgroup
-    int Sc, Dc, hK, hU, rowacc, misc, dump;  // inside a pair's block (dump: nb blocks of 64 floats + 64 doubles)
+    int Sc, Dc, hK, hU, rowacc, misc, dump;  // inside a pair's block (dump: a block of 96 floats per wavefront of the pair)
     int hn;                                  // floats per boundary row
     int pair0, per_pair, total;
 };
@@ -178,8 +178,9 @@ struct BandRev {
     float cur, dprev, V, run, out, clo;
     int q;
 };
-// ALLIN: every lane is inside the grid on every step of the phase (no activity test for the block sums).  The state of a lane
-// outside the grid needs no protection in this direction (zeros around the rows, see band_zpad; nothing is read from it later).
+// ALLIN: every lane is inside the grid on every step of the group (the top lanes' flush needs no column test).  The state of
+// a lane outside the grid needs no protection in this direction (zeros around the rows, see band_zpad; nothing is read from it
+// later), and neither do its block sums (see `run` below).
 //
 // Block sums of S = K_fwd * U: a lane sums its row over the r fine columns of a coarse cell (`run`), and the r lanes of a coarse
 // row pass the cell's sum UP the lanes -- lane l + 1 ends a cell one step before lane l, so `out` = run + what the lane below
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(GRAD && SER
     float *yf = reinterpret_cast<float *>(band_smem + lay.yf);
     unsigned char *pbase = band_smem + lay.pair0 + slot * lay.per_pair;
     double *Sc = reinterpret_cast<double *>(pbase + lay.Sc);          // [Tm][Tm] block sums of S = K_fwd * U
-    float *Dc = reinterpret_cast<float *>(pbase + lay.Dc);            // [Tm][Tm] coarse increments; later the parked column sums
+    float *Dc = reinterpret_cast<float *>(pbase + lay.Dc);            // [Tm + 1][DS] coarse increments between zeros (band_zpad); later the parked column sums [T][DPAD]
     float *hKall = reinterpret_cast<float *>(pbase + lay.hK);         // row b: K[64 (b + 1)][.], written by band b, read by band b + 1
     float *hUall = reinterpret_cast<float *>(pbase + lay.hU);         // row b: U[64 (b + 1)][.], written by band b + 1, read by band b
     float *rowacc = reinterpret_cast<float *>(pbase + lay.rowacc);
