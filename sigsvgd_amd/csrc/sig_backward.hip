@@ -281,6 +281,163 @@ __global__ __launch_bounds__(256) void signature_bwd_kernel(const T *__restrict_
     __syncthreads();
     if (!basepoint && tid < C) gx[tid] = (T)(-gnext[tid]); // x_0 enters D_1 only
 }
+
+// ---- small signatures: one THREAD per path, everything in registers -----------------------------------------------------
+// For the signatures PathSigKernel meets on low-dimensional paths (C = 2 at depth 2-3, C = 3 or 4 at depth 2: at most 20
+// channels) the workgroup-per-path kernel above spends its time on ten dependent LDS stages per point with 14 of 64 lanes
+// busy: 4.4 us per point, 0.31 ms for 1024 paths x 64 points x 2 channels at depth 3 (25 us forwards).  Here a thread owns a
+// path: signature, adjoint and work arrays are private arrays whose every index is a compile-time constant after unrolling
+// (C and the depth are template parameters), so they live in registers, there is no barrier and no LDS, and a point is a
+// few hundred independent fp64 multiply-adds.  Same formulas, same order of every sum as above.
+// (level sizes and offsets as constant tables: a recursive constexpr function in a loop bound stays a call until the outer loop
+//  is unrolled, the inner loops are then not unrolled, and the private arrays are indexed at run time -- select chains)
+template <int C>
+struct SbTab {
+    static constexpr int pw[6] = {1, C, C * C, C * C * C, C * C * C * C, C * C * C * C * C};                 // C^k
+    static constexpr int off[6] = {0, 0, C, C + C * C, C + C * C + C * C * C, C + C * C + C * C * C + C * C * C * C}; // level k (1-based)
+    static constexpr int poff[5] = {0, 1, 1 + C, 1 + C + C * C, 1 + C + C * C + C * C * C};                  // monomials of degree k
+};
+
+template <typename T, int C, int DEPTH>
+__global__ __launch_bounds__(64) void signature_bwd_small_kernel(const T *__restrict__ X, const T *__restrict__ gsig, int N, int L,
+                                                                 int basepoint, T *__restrict__ gX)
+{
+    using TB = SbTab<C>;
+    constexpr int SD = TB::off[DEPTH + 1];
+    static_assert(DEPTH <= 4, "tables of SbTab");
+    const int path = blockIdx.x * 64 + threadIdx.x;
+    if (path >= N) return;
+    const T *x = X + (size_t)path * L * C;
+    T *gx = gX + (size_t)path * L * C;
+    double S[SD], Sn[SD], G[SD], Gn[SD], A0[SD], A1[SD], inc[C], gnext[C];
+    double rcp[DEPTH + 1], rfact[DEPTH + 1];
+    rcp[0] = 1.0;
+    rfact[0] = 1.0;
+#pragma unroll
+    for (int k = 1; k <= DEPTH; ++k) {
+        rcp[k] = 1.0 / (double)k;
+        rfact[k] = rfact[k - 1] * rcp[k];
+    }
+    auto load_inc = [&](int t, double sign) { // D_t = x_t - x_{t-1} (x_{-1} = 0: the base point)
+#pragma unroll
+        for (int a = 0; a < C; ++a)
+            inc[a] = sign * ((double)x[(size_t)t * C + a] - (t > 0 ? (double)x[(size_t)(t - 1) * C + a] : 0.0));
+    };
+    // dst = src (x) exp(inc): element (a_1 .. a_k) in Horner form, h_r = src_r[a_1..a_r] + h_{r-1} inc[a_r] / (k - r + 1)
+    auto chen = [&](const double (&src)[SD], double (&dst)[SD]) {
+#pragma unroll
+        for (int k = 1; k <= DEPTH; ++k)
+#pragma unroll
+            for (int e = 0; e < TB::pw[k]; ++e) {
+                double h = 1.0;
+#pragma unroll
+                for (int r = 1; r <= k; ++r) {
+                    const int pr = e / TB::pw[k - r];
+                    h = __builtin_fma(h * inc[pr % C], rcp[k - r + 1], src[TB::off[r] + pr]);
+                }
+                dst[TB::off[k] + e] = h;
+            }
+    };
+#pragma unroll
+    for (int e = 0; e < SD; ++e) {
+        S[e] = 0.0;
+        G[e] = (double)gsig[(size_t)path * SD + e];
+    }
+#pragma unroll
+    for (int a = 0; a < C; ++a) gnext[a] = 0.0;
+    const int t0 = basepoint ? 0 : 1;
+    // ---- forward: the signature of the whole path ----
+    for (int t = t0; t < L; ++t) {
+        load_inc(t, 1.0);
+        chen(S, Sn);
+#pragma unroll
+        for (int e = 0; e < SD; ++e) S[e] = Sn[e];
+    }
+    // ---- reverse sweep over the points ----
+    for (int t = L - 1; t >= t0; --t) {
+        load_inc(t, -1.0);
+        chen(S, Sn); // Sn = the signature before point t
+#pragma unroll
+        for (int a = 0; a < C; ++a) inc[a] = -inc[a]; // back to +D_t
+#pragma unroll
+        for (int e = 0; e < SD; ++e) {
+            Gn[e] = G[e];
+            A0[e] = G[e];
+        }
+        // adjoint of the left factor: m rounds of contracting the last letter with D (A0 -> A1 -> A0 ...)
+        auto contract = [&](const double (&src)[SD], double (&dst)[SD], int m) {
+#pragma unroll
+            for (int j = 1; j <= DEPTH - m; ++j)
+#pragma unroll
+                for (int w = 0; w < TB::pw[j]; ++w) {
+                    double s = 0.0;
+#pragma unroll
+                    for (int a = 0; a < C; ++a) s = __builtin_fma(src[TB::off[j + 1] + w * C + a], inc[a], s);
+                    dst[TB::off[j] + w] = s;
+                    Gn[TB::off[j] + w] += s * rfact[m];
+                }
+        };
+#pragma unroll
+        for (int m = 1; m < DEPTH; ++m) {
+            if (m & 1)
+                contract(A0, A1, m);
+            else
+                contract(A1, A0, m);
+        }
+        // adjoint of the right factor dE_m[v] (into dE) and the monomials P_k[w] = prod of D over the letters of w (into Pm)
+        double dE[SD], Pm[TB::poff[DEPTH]];
+#pragma unroll
+        for (int m = 1; m <= DEPTH; ++m)
+#pragma unroll
+            for (int v = 0; v < TB::pw[m]; ++v) {
+                double s = G[TB::off[m] + v];
+#pragma unroll
+                for (int j = 1; j <= DEPTH - m; ++j)
+#pragma unroll
+                    for (int w = 0; w < TB::pw[j]; ++w)
+                        s = __builtin_fma(Sn[TB::off[j] + w], G[TB::off[j + m] + w * TB::pw[m] + v], s);
+                dE[TB::off[m] + v] = s;
+            }
+        Pm[0] = 1.0;
+#pragma unroll
+        for (int k = 1; k < DEPTH; ++k)
+#pragma unroll
+            for (int e = 0; e < TB::pw[k]; ++e) Pm[TB::poff[k] + e] = Pm[TB::poff[k - 1] + e / C] * inc[e % C];
+        // adjoint of the exponential: unit (a, m, r) sums over the words with letter a at position r; units in the order of the
+        // workgroup kernel (a major, then m, then r), summed per channel in that order
+#pragma unroll
+        for (int a = 0; a < C; ++a) {
+            double gd = 0.0;
+#pragma unroll
+            for (int m = 1; m <= DEPTH; ++m)
+#pragma unroll
+                for (int r = 1; r <= m; ++r) {
+                    double s = 0.0;
+#pragma unroll
+                    for (int hi = 0; hi < TB::pw[r - 1]; ++hi) {
+                        double sl = 0.0;
+#pragma unroll
+                        for (int lo = 0; lo < TB::pw[m - r]; ++lo)
+                            sl = __builtin_fma(dE[TB::off[m] + hi * TB::pw[m - r + 1] + a * TB::pw[m - r] + lo],
+                                               Pm[TB::poff[m - r] + lo], sl);
+                        s = __builtin_fma(Pm[TB::poff[r - 1] + hi], sl, s);
+                    }
+                    gd += s * rfact[m];
+                }
+            gx[(size_t)t * C + a] = (T)(gd - gnext[a]);
+            gnext[a] = gd;
+        }
+#pragma unroll
+        for (int e = 0; e < SD; ++e) {
+            S[e] = Sn[e];
+            G[e] = Gn[e];
+        }
+    }
+    if (!basepoint) {
+#pragma unroll
+        for (int a = 0; a < C; ++a) gx[a] = (T)(-gnext[a]); // x_0 enters D_1 only
+    }
+}
 } // namespace
 
 int signature_bwd_launch(const void *X, const void *gsig, int N, int L, int C, int depth, int basepoint, int dtype, void *gX,
@@ -299,6 +456,27 @@ int signature_bwd_launch(const void *X, const void *gsig, int N, int L, int C, i
     if (!basepoint && L < 2) { // no increment at all: the signature is constant
         hipError_t e0 = hipMemsetAsync(gX, 0, (size_t)N * L * C * (dtype == SIGSVGD_F64 ? 8 : 4), stream);
         return e0 == hipSuccess ? SIGSVGD_OK : hip_fail(e0, "hipMemsetAsync(signature_backward)");
+    }
+    { // small signatures: one thread per path, registers only
+        hipError_t es = hipSuccess;
+        bool done = true;
+        auto small = [&](auto kern, auto *Xp, auto *gp, auto *op) {
+            hipLaunchKernelGGL(kern, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, stream, Xp, gp, N, L, basepoint, op);
+            es = hipGetLastError();
+        };
+        auto pick = [&](auto *Xp, auto *gp, auto *op) {
+            using TT = std::remove_cv_t<std::remove_pointer_t<decltype(op)>>;
+            if (C == 2 && depth == 2) small(&signature_bwd_small_kernel<TT, 2, 2>, Xp, gp, op);
+            else if (C == 2 && depth == 3) small(&signature_bwd_small_kernel<TT, 2, 3>, Xp, gp, op);
+            else if (C == 3 && depth == 2) small(&signature_bwd_small_kernel<TT, 3, 2>, Xp, gp, op);
+            else if (C == 4 && depth == 2) small(&signature_bwd_small_kernel<TT, 4, 2>, Xp, gp, op);
+            else done = false;
+        };
+        if (dtype == SIGSVGD_F64)
+            pick(static_cast<const double *>(X), static_cast<const double *>(gsig), static_cast<double *>(gX));
+        else
+            pick(static_cast<const float *>(X), static_cast<const float *>(gsig), static_cast<float *>(gX));
+        if (done) return es == hipSuccess ? SIGSVGD_OK : hip_fail(es, "launch signature_bwd_small_kernel");
     }
     const int threads = sigdim <= 64 ? 64 : (sigdim <= 128 ? 128 : 256);
     // the index table: depth rows of sigdim ints behind the working copies; offsets must fit 23 bits next to the letter byte
