@@ -5,7 +5,7 @@ sys.path.insert(0, ".")
 from sigsvgd_amd import ops
 g = torch.Generator().manual_seed(0)
 dev = torch.device("cuda:0")
-for (N, L, C, depth) in [(1024, 64, 2, 3), (1024, 64, 2, 2), (1024, 64, 3, 2), (1024, 64, 4, 2), (100, 10, 2, 3), (256, 32, 3, 4), (64, 100, 7, 3), (128, 50, 2, 6)]:
+for (N, L, C, depth) in [(1024, 64, 2, 3), (1024, 64, 2, 2), (1024, 64, 3, 2), (1024, 64, 4, 2), (100, 10, 2, 3), (1024, 64, 2, 4), (1024, 64, 3, 3), (1024, 64, 5, 2), (1024, 64, 6, 2), (256, 32, 3, 4), (64, 100, 7, 3), (128, 50, 2, 6)]:
     P = torch.cumsum(0.3 * torch.randn(N, L, C, generator=g), 1).to(dev)
     S = ops.signature(P, depth, basepoint=True)
     gs = torch.randn(S.shape, generator=g).to(dev)

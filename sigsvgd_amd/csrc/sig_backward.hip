@@ -283,8 +283,8 @@ __global__ __launch_bounds__(256) void signature_bwd_kernel(const T *__restrict_
 }
 
 // ---- small signatures: one THREAD per path, everything in registers -----------------------------------------------------
-// For the signatures PathSigKernel meets on low-dimensional paths (C = 2 at depth 2-3, C = 3 or 4 at depth 2: at most 20
-// channels) the workgroup-per-path kernel above spends its time on ten dependent LDS stages per point with 14 of 64 lanes
+// For the signatures PathSigKernel meets on low-dimensional paths (C = 2 at depth 2-4, C = 3 at depth 2-3, C = 4 .. 6 at depth
+// 2: at most 42 channels, 250 registers) the workgroup-per-path kernel above spends its time on ten dependent LDS stages per point with 14 of 64 lanes
 // busy: 4.4 us per point, 0.31 ms for 1024 paths x 64 points x 2 channels at depth 3 (25 us forwards).  Here a thread owns a
 // path: signature, adjoint and work arrays are private arrays whose every index is a compile-time constant after unrolling
 // (C and the depth are template parameters), so they live in registers, there is no barrier and no LDS, and a point is a
@@ -470,6 +470,10 @@ int signature_bwd_launch(const void *X, const void *gsig, int N, int L, int C, i
             else if (C == 2 && depth == 3) small(&signature_bwd_small_kernel<TT, 2, 3>, Xp, gp, op);
             else if (C == 3 && depth == 2) small(&signature_bwd_small_kernel<TT, 3, 2>, Xp, gp, op);
             else if (C == 4 && depth == 2) small(&signature_bwd_small_kernel<TT, 4, 2>, Xp, gp, op);
+            else if (C == 2 && depth == 4) small(&signature_bwd_small_kernel<TT, 2, 4>, Xp, gp, op);
+            else if (C == 5 && depth == 2) small(&signature_bwd_small_kernel<TT, 5, 2>, Xp, gp, op);
+            else if (C == 3 && depth == 3) small(&signature_bwd_small_kernel<TT, 3, 3>, Xp, gp, op);
+            else if (C == 6 && depth == 2) small(&signature_bwd_small_kernel<TT, 6, 2>, Xp, gp, op);
             else done = false;
         };
         if (dtype == SIGSVGD_F64)

@@ -206,9 +206,10 @@ def test_path_sig_kernel_fixture_and_oracle(gpu):
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
 @pytest.mark.parametrize("N,L,C,depth,bp", [(5, 9, 2, 3, True), (4, 7, 3, 2, False), (3, 12, 2, 4, True), (6, 5, 4, 3, False),
                                             (3, 20, 7, 3, True), (2, 1, 3, 2, True), (3, 6, 1, 5, False),
-                                            # the one-thread-per-path kernel of the small signatures (C = 2 at depth 2-3, C = 3, 4 at
-                                            # depth 2), more paths than one workgroup of 64 threads
-                                            (70, 6, 2, 2, False), (130, 5, 4, 2, True), (65, 4, 2, 3, False), (67, 3, 3, 2, True)])
+                                            # the one-thread-per-path kernel of the small signatures (C = 2 at depth 2-4, C = 3 at depth 2-3,
+                                            # C = 4, 5, 6 at depth 2), more paths than one workgroup of 64 threads
+                                            (70, 6, 2, 2, False), (130, 5, 4, 2, True), (65, 4, 2, 3, False), (67, 3, 3, 2, True),
+                                            (9, 7, 2, 4, True), (66, 5, 3, 3, False), (5, 6, 5, 2, True), (4, 9, 6, 2, False)])
 def test_signature_backward_vs_oracle(gpu, N, L, C, depth, bp, dtype):
     """the HIP adjoint of the signature (`sigsvgd_signature_backward`, reached by autograd through `ops.signature`) against
     the oracle's reverse-mode gradient, which tests/test_oracle_vector.py pins with finite differences of the signature"""
