@@ -24,8 +24,8 @@ using ff32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int FM = 64;        // rows per workgroup (16 per wavefront)
 constexpr int FN = 64;        // columns per tile
-constexpr int FK = 32;        // channels per S stage
-constexpr int FKS = FK + 4;   // LDS row stride of the S-stage tiles (floats)
+constexpr int FK_METRIC = 32; // channels per S stage with a metric (four staged tiles) ...
+constexpr int FK_PLAIN = 64;  // ... and without (two): half the stages, half the barriers
 constexpr int FC = 64;        // channels per O stage
 constexpr int FCS = FC + 4;   // LDS row stride of the W tiles (= 4 mod 32: the 16 rows x 4 columns of an A read are conflict-free)
 constexpr int FYS = FC + 16;  // LDS row stride of the YM~ tile (= 16 mod 32: the two k rows a 32-lane B read touches are disjoint)
@@ -48,21 +48,30 @@ __device__ __forceinline__ void f_kernel_fn(int kind, T sq, T half_inv_h2, T &k,
 
 // NT: 16-channel accumulator tiles of the O product (D <= 16 * NT).  VEC4: D % 4 == 0 and 16-B aligned matrices
 // (global loads are float4).  Every stage is fetched into registers while the previous one is multiplied.
+// Round 4: EIGHT wavefronts per workgroup.  Round 2-3's four left one wavefront per SIMD at the shapes that matter (N = 1024:
+// 16 row tiles x 16 column splits = 256 workgroups) and 59 % of the wave time waiting (rocprofv3: MFMA pipe busy 15 %).  The two
+// halves of the workgroup share the staged tiles and split the MFMA work of every stage: columns 0-31 / 32-63 of the S tile
+// (and its elementwise part), channel tiles 0-1 / 2-3 of every O stage -- nothing to combine but the row sums of W.
 template <int NT, bool METRIC, bool VEC4>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void vec_fused_kernel(const float *__restrict__ X, const float *__restrict__ Y,
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void vec_fused_kernel(const float *__restrict__ X, const float *__restrict__ Y,
                                                         const float *__restrict__ XM, const float *__restrict__ YM,
                                                         const float *__restrict__ go, int A, int B, int D, int kind,
                                                         float half_inv_h2, float grad_scale, int tiles_per_split,
                                                         float *__restrict__ Kout, float *__restrict__ dK,
                                                         float *__restrict__ part)
 {
-    __shared__ __align__(16) float xs[FM * FKS], ys[FN * FKS];             // XM~ / Y~ stage  [row][k]
-    __shared__ __align__(16) float xs2[METRIC ? FM * FKS : 4], ys2[METRIC ? FN * FKS : 4]; // X~ / YM~ stage
+    constexpr int FK = METRIC ? FK_METRIC : FK_PLAIN; // channels per S stage
+    constexpr int FKS = FK + 4;                       // LDS row stride of the S-stage tiles (floats)
+    // (two buffers per staged tile, used alternately: one workgroup barrier per stage -- a stage's writes go to the buffer
+    //  that was read two stages ago, and the barrier of the stage in between lies between the two)
+    __shared__ __align__(16) float xs_[2][FM * FKS], ys_[2][FN * FKS];             // XM~ / Y~ stage  [row][k]
+    __shared__ __align__(16) float xs2_[2][METRIC ? FM * FKS : 4], ys2_[2][METRIC ? FN * FKS : 4]; // X~ / YM~ stage
     __shared__ __align__(16) float wt[4 * 16 * FCS];                        // W tile of each wavefront [row][col]
-    __shared__ __align__(16) float ymt[FN * FYS];                           // YM~ stage       [col][channel]
+    __shared__ __align__(16) float ymt_[2][FN * FYS];                       // YM~ stage       [col][channel]
     __shared__ __align__(16) float cyl[16 * NT], cyml[METRIC ? 16 * NT : 4]; // centres: row 0 of Y / YM
-    __shared__ float an[FM], bn[FN];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ float an[FM], bn[FN], wsl[2][FM];
+    const int tid = threadIdx.x, lane = tid & 63, wave8 = tid >> 6;
+    const int wave = wave8 & 3, hf = wave8 >> 2; // row block of 16, half of the column / channel work
     const int row0 = blockIdx.y * FM;
     const int tile_lo = blockIdx.x * tiles_per_split;
     const int ntile = (B + FN - 1) / FN;
@@ -70,12 +79,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const float *YMm = METRIC ? YM : Y;   // the matrix whose rows are subtracted in the gradient (ym)
     const float *XMm = METRIC ? XM : X;
     const float *cymp = METRIC ? cyml : cyl;
-    // staging maps: S stage 64 rows x 32 channels: thread -> row tid / 4, channels (tid % 4) * 8 .. + 7;
-    //               O stage 64 columns x 64 channels: thread -> column tid / 4, channels (tid % 4) * 16 .. + 15
-    const int sr = tid >> 2, sk = (tid & 3) * (FK / 4), so = (tid & 3) * 16;
+    // staging maps: S stage 64 rows x 32 channels: thread -> row tid / 8, channels (tid % 8) * 4 .. + 3;
+    //               O stage 64 columns x 64 channels: thread -> column tid / 8, channels (tid % 8) * 8 .. + 7
+    const int sr = tid >> 3, sk = (tid & 7) * (FK / 8), so = (tid & 7) * 8;
     const int ri = lane & 15, rk = lane >> 4; // MFMA operand indices of this lane
 
-    for (int c = tid; c < 16 * NT; c += 256) {
+    for (int c = tid; c < 16 * NT; c += 512) {
         cyl[c] = c < D ? Y[c] : 0.f;
         if (METRIC) cyml[c] = c < D ? YM[c] : 0.f;
     }
@@ -98,9 +107,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     };
 
-    ff32x4 O[NT];
+    ff32x4 O[NT / 2]; // this half's channel tiles: tiles 2 hf, 2 hf + 1 of every stage of four
 #pragma unroll
-    for (int n = 0; n < NT; ++n) O[n] = ff32x4{0.f, 0.f, 0.f, 0.f};
+    for (int n = 0; n < NT / 2; ++n) O[n] = ff32x4{0.f, 0.f, 0.f, 0.f};
     float wsum[4] = {0.f, 0.f, 0.f, 0.f}; // partial row sums of W: rows 16 wave + 4 rk + r, this lane's columns
     float a_part = 0.f;                   // this thread's share of a_i for row sr (first tile only)
     bool have_a = false;
@@ -108,12 +117,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     for (int tile = tile_lo; tile < tile_hi; ++tile) {
         const int col0 = tile * FN;
-        ff32x4 S[4];
+        ff32x4 S[2]; // this half's column blocks: 2 hf, 2 hf + 1
 #pragma unroll
-        for (int b = 0; b < 4; ++b) S[b] = ff32x4{0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < 2; ++b) S[b] = ff32x4{0.f, 0.f, 0.f, 0.f};
         float b_part = 0.f;
         // ---- S = XM~ Y~^T (+ X~ YM~^T) over the channels, FK at a time ---------------------------------------------
-        constexpr int SE = FK / 4; // elements per thread and matrix in an S stage
+        constexpr int SE = FK / 8; // elements per thread and matrix in an S stage
         float xv[SE], yv[SE], xv2[METRIC ? SE : 1], yv2[METRIC ? SE : 1];
         auto fetchS = [&](int k0) {
             load_row(XMm, row0 + sr, A, k0 + sk, xv, SE);
@@ -124,8 +133,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
         };
         fetchS(0);
-        for (int k0 = 0; k0 < D; k0 += FK) {
-            __syncthreads(); // the previous stage is consumed
+        int pb = 0;
+        for (int k0 = 0; k0 < D; k0 += FK, pb ^= 1) {
+            float *xs = xs_[pb], *ys = ys_[pb], *xs2 = xs2_[pb], *ys2 = ys2_[pb];
             const bool xin = row0 + sr < A, yin = col0 + sr < B;
 #pragma unroll
             for (int u = 0; u < SE; ++u) {
@@ -153,32 +163,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const float av = xs[(16 * wave + ri) * FKS + ks + rk];
                 const float av2 = METRIC ? xs2[(16 * wave + ri) * FKS + ks + rk] : 0.f;
 #pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    S[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, ys[(16 * b + ri) * FKS + ks + rk], S[b], 0, 0, 0);
+                for (int b = 0; b < 2; ++b) {
+                    const int cb = 2 * hf + b;
+                    S[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, ys[(16 * cb + ri) * FKS + ks + rk], S[b], 0, 0, 0);
                     if (METRIC)
-                        S[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av2, ys2[(16 * b + ri) * FKS + ks + rk], S[b], 0, 0, 0);
+                        S[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av2, ys2[(16 * cb + ri) * FKS + ks + rk], S[b], 0, 0, 0);
                 }
             }
         }
         // first YM~ stage of the O product: in flight during the elementwise part
-        float yo[16];
-        if (dK) load_row(YMm, col0 + sr, B, so, yo, 16);
-        // norms: the four threads of a staging row hold its partial sums
+        float yo[8];
+        if (dK) load_row(YMm, col0 + sr, B, so, yo, 8);
+        // norms: the eight threads of a staging row hold its partial sums
         if (!have_a) {
             a_part += __shfl_xor(a_part, 1, 64);
             a_part += __shfl_xor(a_part, 2, 64);
-            if ((tid & 3) == 0) an[sr] = a_part;
+            a_part += __shfl_xor(a_part, 4, 64);
+            if ((tid & 7) == 0) an[sr] = a_part;
             have_a = true;
         }
         b_part += __shfl_xor(b_part, 1, 64);
         b_part += __shfl_xor(b_part, 2, 64);
+        b_part += __shfl_xor(b_part, 4, 64);
         __syncthreads(); // (also: the last S stage is consumed)
-        if ((tid & 3) == 0) bn[sr] = b_part;
+        if ((tid & 7) == 0) bn[sr] = b_part;
         __syncthreads();
         // ---- elementwise: sq -> K, W; C layout: column 16 b + ri, rows 16 wave + 4 rk + r ---------------------------
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int jl = 16 * b + ri, gj = col0 + jl;
+        for (int b = 0; b < 2; ++b) {
+            const int jl = 16 * (2 * hf + b) + ri, gj = col0 + jl;
             const float bj = bn[jl];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -203,39 +216,44 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int nb = 0; nb < NT / 4; ++nb) { // (fully unrolled: the accumulator tiles must be indexed statically)
             const int n0 = nb * FC;
             if (n0 >= D) break;
-            __syncthreads(); // W tiles written / previous YM~ stage consumed
+            float *ymt = ymt_[nb & 1];
+            if (nb == 0) __syncthreads(); // the W tiles are written (later stages: the other YM~ buffer, see above)
             {
                 const bool yin = col0 + sr < B;
 #pragma unroll
-                for (int u = 0; u < 16; ++u) {
+                for (int u = 0; u < 8; ++u) {
                     const int c = n0 + so + u;
                     ymt[sr * FYS + so + u] = (c < D && yin) ? yo[u] - cymp[c < D ? c : 0] : 0.f;
                 }
             }
             __syncthreads();
-            if (n0 + FC < D) load_row(YMm, col0 + sr, B, n0 + FC + so, yo, 16); // next stage, in flight during the MFMAs
+            if (n0 + FC < D) load_row(YMm, col0 + sr, B, n0 + FC + so, yo, 8); // next stage, in flight during the MFMAs
 #pragma unroll
             for (int ks = 0; ks < FN; ks += 4) {
                 const float av = wt[(16 * wave + ri) * FCS + ks + rk]; // A[i = ri][k = column ks + rk]
 #pragma unroll
-                for (int nt = 0; nt < FC / 16; ++nt)
-                    O[nb * 4 + nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, ymt[(ks + rk) * FYS + 16 * nt + ri],
-                                                                          O[nb * 4 + nt], 0, 0, 0);
+                for (int nt = 0; nt < FC / 32; ++nt)
+                    O[nb * 2 + nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, ymt[(ks + rk) * FYS + 16 * (2 * hf + nt) + ri],
+                                                                          O[nb * 2 + nt], 0, 0, 0);
             }
         }
         __syncthreads();
     }
     if (!dK) return;
-    // row sums: add up the 16 lanes that share the rows (ri varies)
+    // row sums: add up the 16 lanes that share the rows (ri varies), then the two halves of the workgroup (columns 0-31 / 32-63)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
 #pragma unroll
         for (int off = 1; off < 16; off <<= 1) wsum[r] += __shfl_xor(wsum[r], off, 64);
+        if (ri == 0) wsl[hf][16 * wave + 4 * rk + r] = wsum[r];
     }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) wsum[r] = wsl[0][16 * wave + 4 * rk + r] + wsl[1][16 * wave + 4 * rk + r];
     // dK[i, c] += s * (xm~_i[c] * wsum_i - O_i[c]);  O layout: channel 16 n + ri, rows 16 wave + 4 rk + r
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        const int c = 16 * n + ri;
+    for (int n = 0; n < NT / 2; ++n) {
+        const int c = 16 * (4 * (n >> 1) + 2 * hf + (n & 1)) + ri; // tile (n & 1) of this half in stage n / 2
         if (c < D) {
             const float cym = cymp[c];
 #pragma unroll
@@ -298,7 +316,7 @@ int fused_launch_nt(const float *X, const float *Y, const float *XM, const float
         hipError_t e = hipMemsetAsync(dK, 0, (size_t)A * D * sizeof(float), stream);
         if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(dK)");
     }
-    dim3 grid(splits, rows), block(256);
+    dim3 grid(splits, rows), block(512);
     auto al = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     const bool vec4 = (D % 4) == 0 && al(X) && al(Y) && al(XM) && al(YM);
 #define SIG_VF_LAUNCH(M, V)                                                                                           \
