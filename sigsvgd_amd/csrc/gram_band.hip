@@ -723,30 +723,58 @@ inline size_t band_wsk_per_pair(int T, int n)
     const size_t rows = (size_t)((P + 63 + BGS - 1) / BGS) * BGS; // whole phases per band
     return (size_t)((P + 63) >> 6) * rows * 64 + 32 * 64; // floats (+ 32 rows in front: the ring's loads need no clamp)
 }
-// forward-solution scratch: one block per resident pair of the launch
-inline size_t band_wsk_bytes(int T, int d, int n, bool serial)
+// Which schedule a launch takes.  Band-parallel wins while its workgroups (one pair each) pass through the chip in a few
+// rounds -- its wavefronts idle BLAG (nb - 1) phases of every sweep, which other workgroups on the CU fill, but the sum of a
+// pair's wavefront time is nb / (1 + BLAG (nb - 1) BGS / (P + 63)) times the serial schedule's.  Measured (Gram + gradient,
+// symmetric, ms, parallel / serial): 10 points order 4 (3 bands, 1,280 resident workgroups) -- N = 50 / 70 / 100 / 150: 0.105 /
+// 0.189 / 0.364 / 0.78 against 0.125 / 0.205 / 0.424 / 0.737; 30 points order 3 (4 bands, 1,024) -- N = 35 / 60 / 100: 0.138 /
+// 0.317 / 0.832 against 0.239 / 0.300 / 0.835.  Rule: at most five rounds with three bands, one and a half with four.  With
+// two bands (65 .. 128 cells) it beats the refined-grid kernel of gram_dyad.hip at every size measured (N = 64 .. 400: 20 points
+// order 2 0.156 / 0.423 / 1.52 against 0.170 / 0.477 / 1.78; 5 points order 5 0.80 / 3.13 against 0.92 / 3.52): always.
+// SIGSVGD_BAND_MODE=serial|parallel (read per launch) overrides it: the tests drive both schedules over the same shapes.
+inline bool band_rule_parallel(int A, int B, int T, int d, int n, bool sym)
 {
-    const size_t pairs = (size_t)device_cu_count() * band_wg_per_cu(T, d, n, serial) * (serial ? band_serial_slots(T, d, n) : BPP);
+    const char *e = getenv("SIGSVGD_BAND_MODE");
+    if (e && e[0] == 's') return false;
+    if (e && e[0] == 'p') return true;
+    const long long pairs = sym ? (long long)A * (A + 1) / 2 : (long long)A * B;
+    const int nb = (((T - 1) << n) + 63) >> 6;
+    if (nb <= 2) return true;
+    return 2 * pairs <= (nb >= 4 ? 3ll : 10ll) * device_cu_count() * band_wg_per_cu(T, d, n, false);
+}
+inline bool band_use_parallel(const GramProblem &p, bool sym) { return band_rule_parallel(p.A, p.B, p.T, p.d, p.n, sym); }
+// (the serial schedule takes grids of 129 .. 256 cells only: smaller ones that are not band-parallel stay on gram_dyad.hip)
+inline bool band_is_serial(int A, int B, int T, int d, int n, bool sym)
+{
+    return ((T - 1) << n) > 128 && !band_rule_parallel(A, B, T, d, n, sym);
+}
+// forward-solution scratch: one block per pair a launch of `grid` workgroups has in flight
+inline size_t band_wsk_bytes(int grid, int T, int d, int n, bool serial)
+{
+    const size_t pairs = (size_t)(grid > 0 ? grid : 1) * (serial ? band_serial_slots(T, d, n) : BPP);
     return ((pairs * band_wsk_per_pair(T, n) * sizeof(float)) + 255) & ~(size_t)255;
 }
-inline size_t band_need_bytes(int A, int B, int T, int d, int n, int want_grad, bool serial)
+// bytes a launch of this shape and orientation needs, on the schedule the launcher will pick for it
+inline size_t band_need_bytes(int A, int B, int T, int d, int n, int want_grad, bool sym)
 {
-    size_t bytes = band_flag_bytes(A, B) + 512;
-    if (!want_grad) return bytes;
-    const GradGeom o = band_geometry(A, B, T, d, n, false, serial);
-    size_t need = o.rseg_bytes;
-    if (A == B) {
-        const GradGeom y = band_geometry(A, B, T, d, n, true, serial);
-        if (y.rseg_bytes + y.cslab_bytes > need) need = y.rseg_bytes + y.cslab_bytes;
-    }
-    return need + band_wsk_bytes(T, d, n, serial) + band_flag_bytes(A, B) + 1024;
+    if (!want_grad) return band_flag_bytes(A, B) + 512;
+    const bool serial = band_is_serial(A, B, T, d, n, sym);
+    const GradGeom g = band_geometry(A, B, T, d, n, sym, serial);
+    return g.rseg_bytes + g.cslab_bytes + band_wsk_bytes(g.grid, T, d, n, serial) + band_flag_bytes(A, B) + 1024;
 }
 } // namespace
 
-int band_workspace_bytes(int A, int B, int T, int d, int n, int want_grad, size_t *bytes)
+int band_workspace_bytes(int A, int B, int T, int d, int n, int want_grad, unsigned flags, size_t *bytes)
 {
-    const size_t sb = band_need_bytes(A, B, T, d, n, want_grad, true), pb = band_need_bytes(A, B, T, d, n, want_grad, false);
-    *bytes = sb > pb ? sb : pb; // (either schedule may take the launch)
+    // a query with SIGSVGD_FLAG_Y_IS_X is the symmetric launch (half the pairs: often the band-parallel schedule, whose
+    // scratch is a third of the serial one's); without the flag it covers both orientations
+    const size_t yb = A == B ? band_need_bytes(A, B, T, d, n, want_grad, true) : 0;
+    if ((flags & SIGSVGD_FLAG_Y_IS_X) && A == B) {
+        *bytes = yb;
+        return SIGSVGD_OK;
+    }
+    const size_t ob = band_need_bytes(A, B, T, d, n, want_grad, false);
+    *bytes = ob > yb ? ob : yb;
     return SIGSVGD_OK;
 }
 
@@ -797,25 +825,6 @@ int band_launch_variant(const GramProblem &p, BandArgs &a, const GradGeom &g, bo
     if (e != hipSuccess) return hip_fail(e, "launch gram_bandp_kernel");
     return SIGSVGD_OK;
 }
-// Which schedule a launch takes.  Band-parallel wins while its workgroups (one pair each) pass through the chip in a few
-// rounds -- its wavefronts idle BLAG (nb - 1) phases of every sweep, which other workgroups on the CU fill, but the sum of a
-// pair's wavefront time is nb / (1 + BLAG (nb - 1) BGS / (P + 63)) times the serial schedule's.  Measured (Gram + gradient,
-// symmetric, ms, parallel / serial): 10 points order 4 (3 bands, 1,280 resident workgroups) -- N = 50 / 70 / 100 / 150: 0.105 /
-// 0.189 / 0.364 / 0.78 against 0.125 / 0.205 / 0.424 / 0.737; 30 points order 3 (4 bands, 1,024) -- N = 35 / 60 / 100: 0.138 /
-// 0.317 / 0.832 against 0.239 / 0.300 / 0.835.  Rule: at most five rounds with three bands, one and a half with four.  With
-// two bands (65 .. 128 cells) it beats the refined-grid kernel of gram_dyad.hip at every size measured (N = 64 .. 400: 20 points
-// order 2 0.156 / 0.423 / 1.52 against 0.170 / 0.477 / 1.78; 5 points order 5 0.80 / 3.13 against 0.92 / 3.52): always.
-// SIGSVGD_BAND_MODE=serial|parallel (read per launch) overrides it: the tests drive both schedules over the same shapes.
-inline bool band_use_parallel(const GramProblem &p, bool sym)
-{
-    const char *e = getenv("SIGSVGD_BAND_MODE");
-    if (e && e[0] == 's') return false;
-    if (e && e[0] == 'p') return true;
-    const long long pairs = sym ? (long long)p.A * (p.A + 1) / 2 : (long long)p.A * p.B;
-    const int nb = (((p.T - 1) << p.n) + 63) >> 6;
-    if (nb <= 2) return true;
-    return 2 * pairs <= (nb >= 4 ? 3ll : 10ll) * device_cu_count() * band_wg_per_cu(p.T, p.d, p.n, false);
-}
 } // namespace
 
 // Refined grids of 65 .. 128 cells per side (two bands) with r >= 4 -- BASELINE C1, the planning script's shape: the
@@ -829,9 +838,11 @@ bool band_takes_refined(const GramProblem &p)
     if (p.kind != SIGSVGD_STATIC_RBF || (p.flags & (SIGSVGD_FLAG_NAIVE_SOLVER | SIGSVGD_FLAG_FORCE_GENERIC))) return false;
     return band_use_parallel(p, (p.flags & SIGSVGD_FLAG_Y_IS_X) && p.A == p.B);
 }
-size_t band_refined_workspace_bytes(int A, int B, int T, int d, int n, int want_grad)
+size_t band_refined_workspace_bytes(int A, int B, int T, int d, int n, int want_grad, unsigned flags)
 {
-    return band_need_bytes(A, B, T, d, n, want_grad, false);
+    size_t bytes = 0;
+    (void)band_workspace_bytes(A, B, T, d, n, want_grad, flags, &bytes);
+    return bytes;
 }
 
 int band_launch(const GramProblem &p)
@@ -839,7 +850,7 @@ int band_launch(const GramProblem &p)
     const bool grad = p.gradX_out != nullptr;
     const bool sym = (p.flags & SIGSVGD_FLAG_Y_IS_X) && p.A == p.B;
     // (grids of up to 128 cells come here for the band-parallel schedule only: band_takes_refined)
-    const bool serial = ((p.T - 1) << p.n) > 128 && !band_use_parallel(p, sym);
+    const bool serial = band_is_serial(p.A, p.B, p.T, p.d, p.n, sym);
     BandArgs a;
     a.X = p.X; a.Y = p.Y; a.go = p.grad_out; a.K = p.K_out; a.rseg = nullptr; a.cslab = nullptr; a.wsk = nullptr;
     a.wsk_per_wave = band_wsk_per_pair(p.T, p.n);
@@ -852,7 +863,7 @@ int band_launch(const GramProblem &p)
     }
     const GradGeom g = band_geometry(p.A, p.B, p.T, p.d, p.n, sym, serial);
     const size_t slabs = grad ? (g.rseg_bytes + g.cslab_bytes + 255) & ~(size_t)255 : 0;
-    const size_t need = band_flag_bytes(p.A, p.B) + slabs + (grad ? band_wsk_bytes(p.T, p.d, p.n, serial) : 0) + 256;
+    const size_t need = band_flag_bytes(p.A, p.B) + slabs + (grad ? band_wsk_bytes(g.grid, p.T, p.d, p.n, serial) : 0) + 256;
     if (!p.ws || p.ws_bytes < need) {
         set_error("band: workspace %zu B < required %zu B", p.ws_bytes, need);
         return SIGSVGD_E_WORKSPACE;

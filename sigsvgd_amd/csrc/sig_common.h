@@ -268,9 +268,9 @@ int dyad_launch(const GramProblem &p);
 
 // the same with 129 .. 256 refined cells per side, swept in bands of 64 rows (fp32 difference form) -- gram_band.hip
 bool band_supported(int A, int B, int T, int d, int n, int kind, unsigned flags);
-int band_workspace_bytes(int A, int B, int T, int d, int n, int want_grad, size_t *bytes);
+int band_workspace_bytes(int A, int B, int T, int d, int n, int want_grad, unsigned flags, size_t *bytes);
 int band_launch(const GramProblem &p);
 bool band_takes_refined(const GramProblem &p); // 65 .. 128 cells, small launches: the band-parallel kernel instead of gram_dyad.hip
-size_t band_refined_workspace_bytes(int A, int B, int T, int d, int n, int want_grad);
+size_t band_refined_workspace_bytes(int A, int B, int T, int d, int n, int want_grad, unsigned flags);
 
 } // namespace sigsvgd
