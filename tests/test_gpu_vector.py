@@ -410,3 +410,26 @@ def test_vec_kernel_fused_metric_and_classes(gpu):
         assert rel(Kx, K1.double().cpu().numpy()) < 1e-5 and rel(dx, d1.double().cpu().numpy()) < 2e-5
     Ki, di = ScaledIMQKernel()(Xs, Xs, M=torch.eye(96, device=gpu), h=2.0)
     assert Ki.shape == (40, 40) and di.shape == (40, 96) and bool(torch.isfinite(di).all())
+
+
+@pytest.mark.parametrize("A,B,D,metric", [(2048, 2048, 40, False), (1500, 2300, 72, False), (1100, 2200, 24, True)])
+def test_vec_kernel_fused_several_tiles_per_workgroup(gpu, A, B, D, metric):
+    """launches whose workgroups walk MORE THAN ONE column tile (more than 512 / row-tiles tiles: the double-buffered stages
+    and the shared W tile are reused across tiles) against the two-launch path of vec_kernels.hip on the same inputs"""
+    from sigsvgd_amd import _lib, ops
+
+    rng = np.random.default_rng(A + B + D)
+    Xg = torch.as_tensor(rng.normal(size=(A, D)).astype(np.float32), device=gpu)
+    Yg = torch.as_tensor((rng.normal(size=(B, D)) * 0.9 + 0.1).astype(np.float32), device=gpu)
+    h = float(np.sqrt(D))
+    XM = YM = None
+    if metric:
+        R = rng.normal(size=(D, D))
+        Mg = torch.as_tensor((R @ R.T / D + np.eye(D)).astype(np.float32), device=gpu)
+        XM, YM = Xg @ Mg, Yg @ Mg
+    K, dK = ops.vec_kernel_fused(Xg, Yg, _lib.VEC_GAUSSIAN, 1 / h**2, -1 / h**2, XM=XM, YM=YM)
+    sq = ops.vec_sqdist(Xg, Yg, XM, YM)
+    K0, dK0 = ops.vec_kernel(sq, XM if metric else Xg, YM if metric else Yg, _lib.VEC_GAUSSIAN, 1 / h**2, -1 / h**2)
+    assert rel(K, K0.double().cpu().numpy()) < 1e-5 and rel(dK, dK0.double().cpu().numpy()) < 2e-5
+    K2, dK2 = ops.vec_kernel_fused(Xg, Yg, _lib.VEC_GAUSSIAN, 1 / h**2, -1 / h**2, XM=XM, YM=YM)
+    assert torch.equal(K, K2) and torch.equal(dK, dK2)
