@@ -52,6 +52,8 @@ def main():
             eK = max(float((np.abs(t.double().cpu().numpy() - Kref) / np.maximum(np.abs(Kref), 1e-6)).max()) for t in (K, Kf))
             eg = float(np.abs(g.double().cpu().numpy() - gref).max() / max(np.abs(gref).max(), 1e-300))
             worstK, worstg = max(worstK, eK), max(worstg, eg)
+            if eK < TOL and eg < TOL and max(eK, eg) > 0.6 * TOL and mode == "":
+                print(f"near case {k} A={A} B={B} T={T} n={n} d={d} sym={sym} go={use_go} scale={scale} h={h} off={off}: K {eK:.2e} g {eg:.2e}", flush=True)
             if not (eK < TOL and eg < TOL):
                 bad += 1
                 print(f"FAIL case {k} mode={mode or 'default'} A={A} B={B} T={T} n={n} d={d} sym={sym} go={use_go} scale={scale} h={h} off={off}: K {eK:.2e} g {eg:.2e}", flush=True)

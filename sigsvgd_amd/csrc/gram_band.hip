@@ -34,6 +34,7 @@ struct BandArgs {
     unsigned char *kflag; // [A][B]: 1 where the fp32 solution of the pair cancelled (max |K_grid| > r max(|K|, 0.1), r = 2 / 4 / 8) or is ill-conditioned (d <= 3), as in
                           // gram_quad.hip): the launcher lets the coverage kernel solve those pairs' K again in fp64
     int io64, A, B, T, d, n, symw;
+    int comprev; // the reverse sweep's full-magnitude add in two floats as well (see band_comp)
     TileMap tm;
     long long nitems;
     double inv_h;
@@ -517,7 +518,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(GRAD && SER
                             float out6, out2;
                             int cell6, cell2;
                             static_assert(BKR == BHS, "a deeper ring needs the group's position in it as a compile-time constant");
-                            if (COMP && d == 1) // (one channel at the orders of the two-float add)
+                            if (COMP && a.comprev) // (one channel, or order 4 on 160 cells and more: band_comp)
                                 bandp_rev_phase<false, 0, true>(st, hv, kfr, rnext, lanep, dcrow, chain, top, n, r, P, rowvalid, ho - (BHS - 1), out6, cell6, out2, cell2);
                             else if (plat)
                                 bandp_rev_phase<true, 0, false>(st, hv, kfr, rnext, lanep, dcrow, chain, top, n, r, P, rowvalid, ho - (BHS - 1), out6, cell6, out2, cell2);
@@ -794,6 +795,19 @@ hipError_t band_raise_lds()
     }
     return hipSuccess;
 }
+// Where the full-magnitude add of a step runs in two floats (template parameter COMP; `rev`: in the reverse sweep too).  The
+// add's rounding has the same sign row after row when neighbouring cells have nearly identical increments, so K drifts by
+// up to 6e-8 per ROW on smooth paths: dyadic order >= 5 (forward sweep: K 1.2e-5 at order 6 without it); one channel at any
+// order and order 4 from 160 cells on in both sweeps (very smooth paths, |step|^2 / h ~ 4e-5: the gradient -- 1e-3 of K there --
+// was 3e-5 in one channel and 1.03e-5 at 208 cells, 6.5e-6 at 160, in two in the refined soak).  The notebook's (144 cells, order 4) and the maze script's (order
+// 3) shapes stay without it: 5e-6 at worst in the sweep of profiles/r04_precision_sweep_refined.md.
+inline bool band_comp(int T, int d, int n, bool *rev)
+{
+    const int P = (T - 1) << n;
+    const bool both = d == 1 || (n == 4 && P >= 160);
+    if (rev) *rev = both;
+    return n >= 5 || both;
+}
 template <int DPAD, bool SER>
 int band_launch_variant(const GramProblem &p, BandArgs &a, const GradGeom &g, bool grad, bool sym)
 {
@@ -803,7 +817,7 @@ int band_launch_variant(const GramProblem &p, BandArgs &a, const GradGeom &g, bo
     const int P = (p.T - 1) << p.n, nb = (P + 63) >> 6;
     const int slots = SER ? band_serial_slots(p.T, p.d, p.n) : 0;
     dim3 grid((unsigned)g.grid), block((SER ? slots : BPP * nb) * 64);
-    const bool comp = p.n >= 5 || p.d == 1; // (one channel: both sweeps, see COMPR)
+    const bool comp = band_comp(p.T, p.d, p.n, nullptr);
     const unsigned lds = (unsigned)bandp_lds(p.T, P, DPAD, slots).total;
 #define SIGB_LAUNCH(G, S)                                                                                          \
     {                                                                                                              \
@@ -856,6 +870,11 @@ int band_launch(const GramProblem &p)
     a.wsk_per_wave = band_wsk_per_pair(p.T, p.n);
     a.io64 = p.dtype == SIGSVGD_F64; a.A = p.A; a.B = p.B; a.T = p.T; a.d = p.d; a.n = p.n;
     a.symw = (p.flags & SIGSVGD_FLAG_SYM) ? 1 : 0; a.inv_h = p.inv_h;
+    {
+        bool rev = false;
+        (void)band_comp(p.T, p.d, p.n, &rev);
+        a.comprev = rev ? 1 : 0;
+    }
     a.nitems = 0;
     if (a.symw && p.A != p.B) {
         set_error("sym backward needs A == B");
