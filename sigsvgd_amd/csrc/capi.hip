@@ -160,7 +160,7 @@ int sigsvgd_gram_workspace_bytes(int A, int B, int T, int d, int dyadic_order, i
         return quad_workspace_bytes(A, B, T, d, want_grad, bytes);
     if (!forced && dyad_supported(A, B, T, d, dyadic_order, static_kind, flags)) {
         const int rc = dyad_workspace_bytes(A, B, T, d, want_grad, bytes);
-        if (rc == SIGSVGD_OK && ((T - 1) << dyadic_order) > 64 && dyadic_order >= 2) { // either kernel may take the launch
+        if (rc == SIGSVGD_OK && ((T - 1) << dyadic_order) >= 64 && dyadic_order >= 2) { // either kernel may take the launch
             const size_t pb = band_refined_workspace_bytes(A, B, T, d, dyadic_order, want_grad, flags);
             if (pb > *bytes) *bytes = pb;
         }

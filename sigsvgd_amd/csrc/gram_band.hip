@@ -578,7 +578,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(GRAD && SER
                 if (lanep == 0) a.kflag[(size_t)i * a.B + j] = (canc_keep || ill) ? 1 : 0;
             }
             __syncthreads(); // the tables are staged; the increments (verdict) are not needed any more
-            if (valid && (SER || band0 <= (SYM ? 1 : 0))) {
+            const int colwave = nb > 1 ? 1 : 0; // the wavefront of the column side (a one-band pair has one wavefront for both)
+            if (valid && (SER || band0 == 0 || (SYM && band0 == colwave))) {
                 float w_ij = 1.f, w_ji = 1.f;
                 if (a.go) {
                     w_ij = (float)b_ldany(a.go, (size_t)i * a.B + j, io64);
@@ -616,7 +617,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(GRAD && SER
                             if (c < d) rowacc[me * DPAD + c] += w_ij * m2h * acc[c];
                     }
                 }
-                if (SYM && (SER || band0 == 1)) { // column side (Y is X): lane n sums over the rows m; the sums are parked in the increment table's place
+                if (SYM && (SER || band0 == colwave)) { // column side (Y is X): lane n sums over the rows m; the sums are parked in the increment table's place
 #pragma unroll
                     for (int c = 0; c < DPAD; ++c) acc[c] = 0.f;
                     const float *yr = yf + me * DPAD;
@@ -848,7 +849,8 @@ bool band_takes_refined(const GramProblem &p)
 {
     if (p.n < 2 || p.n > 7 || p.T < 3 || p.T > BTMAX || p.d > 16) return false;
     const int P = (p.T - 1) << p.n;
-    if (P <= 64 || P > 128) return false;
+    if (P < 64 || P > 128 || (P == 64 && p.d != 1)) return false; // (64 cells, one band: only for the one-channel launches, whose
+                                                                      //  very smooth regime wants the two-float add in both sweeps)
     if (p.kind != SIGSVGD_STATIC_RBF || (p.flags & (SIGSVGD_FLAG_NAIVE_SOLVER | SIGSVGD_FLAG_FORCE_GENERIC))) return false;
     return band_use_parallel(p, (p.flags & SIGSVGD_FLAG_Y_IS_X) && p.A == p.B);
 }
